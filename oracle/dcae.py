@@ -1,0 +1,349 @@
+"""Oracle restatement of ``AutoencoderDC`` and its blocks (models/DCAE.py:67-1087)
+for the shipped configuration (configs/DC_AE_84_pretrain.yaml:1-48): no timestep
+conditioning (``temb_channels=None``), ``rms_norm``, pixel-(un)shuffle sampling.
+
+Parameter names equal the reference's.  RMSNorm comes from
+``oracle.layers`` (PARITY UNPINNED); SphereConv2d from ``oracle.sphere_conv`` (PINNED).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import RMSNorm
+from .sphere_conv import SphereConv2d
+
+
+def _act(name):
+    return {"silu": nn.SiLU(), "relu": nn.ReLU(), "relu6": nn.ReLU6(), "gelu": nn.GELU(), "mish": nn.Mish()}[name]
+
+
+def _chan_rmsnorm(norm: RMSNorm, x):
+    return norm(x.movedim(1, -1)).movedim(-1, 1)
+
+
+class SanaMultiscaleAttentionProjection(nn.Module):
+    """models/DCAE.py:67-93: depthwise sphere conv k then grouped 1x1 (groups = 3*heads)."""
+
+    def __init__(self, in_channels: int, num_attention_heads: int, kernel_size: int):
+        super().__init__()
+        ch = 3 * in_channels
+        self.proj_in = SphereConv2d(ch, ch, kernel_size, padding=kernel_size // 2, groups=ch, bias=False)
+        self.proj_out = nn.Conv2d(ch, ch, 1, 1, 0, groups=3 * num_attention_heads, bias=False)
+
+    def forward(self, x):
+        return self.proj_out(self.proj_in(x))
+
+
+class SanaMultiscaleLinearAttention(nn.Module):
+    """models/DCAE.py:96-267 (processor folded in).  Heads = ``int(C // 32)`` so the
+    inner width is 480 / 992 for C = 504 / 1008; the multi-scale concat is regrouped
+    as consecutive 96-channel groups split (q, k, v) = (32, 32, 32) -- reference quirk,
+    reproduced literally (models/DCAE.py:226-243)."""
+
+    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15, residual_connection=True):
+        super().__init__()
+        self.eps = eps
+        self.attention_head_dim = attention_head_dim
+        self.residual_connection = residual_connection
+        heads = int(in_channels // attention_head_dim * mult)
+        inner = heads * attention_head_dim
+        self.to_q = nn.Linear(in_channels, inner, bias=False)
+        self.to_k = nn.Linear(in_channels, inner, bias=False)
+        self.to_v = nn.Linear(in_channels, inner, bias=False)
+        self.to_qkv_multiscale = nn.ModuleList(
+            [SanaMultiscaleAttentionProjection(inner, heads, ks) for ks in kernel_sizes]
+        )
+        self.to_out = nn.Linear(inner * (1 + len(kernel_sizes)), out_channels, bias=False)
+        self.norm_out = RMSNorm(out_channels, eps=1e-5, elementwise_affine=True, bias=True)  # get_normalization default eps
+
+    def forward(self, x, temb=None):
+        b, _, h, w = x.shape
+        residual = x
+        xl = x.movedim(1, -1)
+        qkv = torch.cat([self.to_q(xl), self.to_k(xl), self.to_v(xl)], dim=3).movedim(-1, 1)
+        multi = [qkv] + [blk(qkv) for blk in self.to_qkv_multiscale]
+        hs = torch.cat(multi, dim=1)
+        if h * w <= self.attention_head_dim:
+            raise NotImplementedError("quadratic branch is never taken at 15x30 / 30x60")
+        hs = hs.to(torch.float32).reshape(b, -1, 3 * self.attention_head_dim, h * w)
+        q, k, v = hs.chunk(3, dim=2)
+        q, k = F.relu(q), F.relu(k)
+        v = F.pad(v, (0, 0, 0, 1), mode="constant", value=1)
+        scores = torch.matmul(v, k.transpose(-1, -2))
+        out = torch.matmul(scores, q)
+        out = out[:, :, :-1] / (out[:, :, -1:] + self.eps)
+        out = out.reshape(b, -1, h, w)
+        out = self.to_out(out.movedim(1, -1)).movedim(-1, 1)
+        out = _chan_rmsnorm(self.norm_out, out)
+        if self.residual_connection:
+            out = out + residual
+        return out
+
+
+class GLUMBConv(nn.Module):
+    """models/DCAE.py:270-324"""
+
+    def __init__(self, in_channels, out_channels, expand_ratio=4):
+        super().__init__()
+        hid = int(expand_ratio * in_channels)
+        self.conv_inverted = nn.Conv2d(in_channels, hid * 2, 1, 1, 0)
+        self.conv_depth = SphereConv2d(hid * 2, hid * 2, 3, 1, 1, groups=hid * 2)
+        self.conv_point = nn.Conv2d(hid, out_channels, 1, 1, 0, bias=False)
+        self.norm = RMSNorm(out_channels, eps=1e-7, elementwise_affine=True, bias=True)
+
+    def forward(self, x):
+        residual = x
+        x = F.silu(self.conv_inverted(x))
+        x = self.conv_depth(x)
+        x, gate = torch.chunk(x, 2, dim=1)
+        x = x * F.silu(gate)
+        x = self.conv_point(x)
+        x = _chan_rmsnorm(self.norm, x)
+        return x + residual
+
+
+class ResBlock(nn.Module):
+    """models/DCAE.py:327-377"""
+
+    def __init__(self, in_channels, out_channels, act_fn="silu"):
+        super().__init__()
+        self.nonlinearity = _act(act_fn)
+        self.conv1 = SphereConv2d(in_channels, in_channels, 3, 1, 1)
+        self.conv2 = SphereConv2d(in_channels, out_channels, 3, 1, 1, bias=False)
+        self.norm = RMSNorm(out_channels, eps=1e-5, elementwise_affine=True, bias=True)
+
+    def forward(self, x, temb=None):
+        residual = x
+        x = self.nonlinearity(self.conv1(x))
+        x = self.conv2(x)
+        x = _chan_rmsnorm(self.norm, x)
+        return x + residual
+
+
+class EfficientViTBlock(nn.Module):
+    """models/DCAE.py:380-414"""
+
+    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,)):
+        super().__init__()
+        self.attn = SanaMultiscaleLinearAttention(
+            in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales
+        )
+        self.conv_out = GLUMBConv(in_channels, in_channels)
+
+    def forward(self, x, temb=None):
+        return self.conv_out(self.attn(x))
+
+
+def get_block(block_type, channels, attention_head_dim, act_fn, qkv_multiscales):
+    if block_type == "ResBlock":
+        return ResBlock(channels, channels, act_fn)
+    if block_type == "EfficientViTBlock":
+        return EfficientViTBlock(channels, attention_head_dim, tuple(qkv_multiscales))
+    raise ValueError(f"Block with {block_type=} is not supported.")
+
+
+class DCDownBlock2d(nn.Module):
+    """models/DCAE.py:447-490 (pixel_unshuffle form)"""
+
+    def __init__(self, in_channels, out_channels, shortcut=True):
+        super().__init__()
+        self.factor = 2
+        self.group_size = in_channels * self.factor**2 // out_channels
+        self.shortcut = shortcut
+        assert out_channels % self.factor**2 == 0
+        self.conv = SphereConv2d(in_channels, out_channels // self.factor**2, 3, 1, 1)
+
+    def forward(self, x, temb=None):
+        y = F.pixel_unshuffle(self.conv(x), self.factor)
+        if self.shortcut:
+            s = F.pixel_unshuffle(x, self.factor)
+            s = s.unflatten(1, (-1, self.group_size)).mean(dim=2)
+            y = y + s
+        return y
+
+
+class DCUpBlock2d(nn.Module):
+    """models/DCAE.py:493-536 (pixel_shuffle form)"""
+
+    def __init__(self, in_channels, out_channels, shortcut=True):
+        super().__init__()
+        self.factor = 2
+        self.repeats = out_channels * self.factor**2 // in_channels
+        self.shortcut = shortcut
+        self.conv = SphereConv2d(in_channels, out_channels * self.factor**2, 3, 1, 1)
+
+    def forward(self, x, temb=None):
+        y = F.pixel_shuffle(self.conv(x), self.factor)
+        if self.shortcut:
+            s = F.pixel_shuffle(x.repeat_interleave(self.repeats, dim=1), self.factor)
+            y = y + s
+        return y
+
+
+class Encoder(nn.Module):
+    """models/DCAE.py:539-631"""
+
+    def __init__(self, in_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales):
+        super().__init__()
+        n = len(block_out_channels)
+        assert layers_per_block[0] > 0
+        self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        self.down_blocks = nn.ModuleList()
+        for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
+            for _ in range(nl):
+                self.down_blocks.append(get_block(block_type[i], ch, attention_head_dim, "silu", qkv_multiscales[i]))
+            if i < n - 1 and nl > 0:
+                self.down_blocks.append(DCDownBlock2d(ch, block_out_channels[i + 1], shortcut=True))
+        self.conv_out = SphereConv2d(block_out_channels[-1], latent_channels, 3, 1, 1)
+        self.out_shortcut_average_group_size = block_out_channels[-1] // latent_channels
+
+    def forward(self, x, temb=None):
+        x = self.conv_in(x)
+        for blk in self.down_blocks:
+            x = blk(x, temb)
+        s = x.unflatten(1, (-1, self.out_shortcut_average_group_size)).mean(dim=2)
+        return self.conv_out(x) + s
+
+
+class Decoder(nn.Module):
+    """models/DCAE.py:634-732"""
+
+    def __init__(self, out_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu"):
+        super().__init__()
+        n = len(block_out_channels)
+        assert layers_per_block[0] > 0
+        self.conv_in = SphereConv2d(latent_channels, block_out_channels[-1], 3, 1, 1)
+        self.in_shortcut_repeats = block_out_channels[-1] // latent_channels
+        self.up_blocks = nn.ModuleList()
+        for i, (ch, nl) in reversed(list(enumerate(zip(block_out_channels, layers_per_block)))):
+            if i < n - 1 and nl > 0:
+                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True))
+            for _ in range(nl):
+                self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i]))
+        ch0 = block_out_channels[0]
+        self.norm_out = RMSNorm(ch0, 1e-7, elementwise_affine=True, bias=True)
+        self.conv_out = SphereConv2d(ch0, out_channels, 3, 1, 1)
+
+    def forward(self, z, temb=None):
+        x = self.conv_in(z) + z.repeat_interleave(self.in_shortcut_repeats, dim=1)
+        for blk in self.up_blocks:
+            x = blk(x, temb)
+        x = F.relu(_chan_rmsnorm(self.norm_out, x))
+        return self.conv_out(x)
+
+
+CONFIG_DCAE_84 = dict(
+    in_channels=89,
+    out_channels=89,
+    latent_channels=84,
+    attention_head_dim=32,
+    encoder_block_types=("ResBlock", "ResBlock", "EfficientViTBlock", "EfficientViTBlock"),
+    decoder_block_types=("ResBlock", "ResBlock", "EfficientViTBlock", "EfficientViTBlock"),
+    encoder_block_out_channels=(252, 504, 504, 1008),
+    decoder_block_out_channels=(252, 504, 504, 1008),
+    encoder_layers_per_block=(4, 4, 4, 4),
+    decoder_layers_per_block=(4, 4, 4, 4),
+    encoder_qkv_multiscales=((), (), (5,), (5,)),
+    decoder_qkv_multiscales=((), (), (5,), (5,)),
+    upsample_block_type="pixel_shuffle",
+    downsample_block_type="pixel_unshuffle",
+    static_channels=5,
+)  # configs/DC_AE_84_pretrain.yaml:1-48
+
+
+class AutoencoderDC(nn.Module):
+    """models/DCAE.py:735-1087"""
+
+    def __init__(
+        self,
+        in_channels: int = 3,
+        out_channels: Optional[int] = None,
+        temb_channels: Optional[int] = None,
+        latent_channels: int = 32,
+        attention_head_dim: int = 32,
+        encoder_block_types="ResBlock",
+        decoder_block_types="ResBlock",
+        encoder_block_out_channels: Tuple[int, ...] = (128, 256, 512, 512, 1024, 1024),
+        decoder_block_out_channels: Tuple[int, ...] = (128, 256, 512, 512, 1024, 1024),
+        encoder_layers_per_block: Tuple[int, ...] = (2, 2, 2, 3, 3, 3),
+        decoder_layers_per_block: Tuple[int, ...] = (3, 3, 3, 3, 3, 3),
+        encoder_qkv_multiscales=((), (), (), (5,), (5,), (5,)),
+        decoder_qkv_multiscales=((), (), (), (5,), (5,), (5,)),
+        upsample_block_type: str = "pixel_shuffle",
+        downsample_block_type: str = "pixel_unshuffle",
+        decoder_norm_types="rms_norm",
+        decoder_act_fns="silu",
+        scaling_factor: float = 1.0,
+        static_channels: int = 0,
+    ):
+        super().__init__()
+        if temb_channels is not None:
+            raise NotImplementedError("timestep-conditioned DCAE is not on the shipped-config path")
+        if upsample_block_type != "pixel_shuffle" or downsample_block_type != "pixel_unshuffle":
+            raise NotImplementedError("only pixel_(un)shuffle sampling is on the shipped-config path")
+        if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
+            raise NotImplementedError
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        n = len(encoder_block_out_channels)
+        ebt = (encoder_block_types,) * n if isinstance(encoder_block_types, str) else tuple(encoder_block_types)
+        dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
+        self.encoder = Encoder(
+            in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales
+        )
+        self.decoder = Decoder(
+            out_channels if out_channels is not None else in_channels,
+            latent_channels,
+            attention_head_dim,
+            dbt,
+            decoder_block_out_channels,
+            decoder_layers_per_block,
+            decoder_qkv_multiscales,
+        )
+        self.spatial_compression_ratio = 2 ** (n - 1)
+        self.static_channels = static_channels
+        self.use_slicing = False
+        self.use_tiling = False
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @classmethod
+    def from_config(cls, cfg: dict):
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    def encode(self, x, return_dict=True, temb=None, embedded_t=False, static_conditioning_tensor=None):
+        if static_conditioning_tensor is not None:
+            x = torch.cat((x, static_conditioning_tensor), dim=1)
+        if self.use_slicing and x.shape[0] > 1:
+            raise NotImplementedError("Slicing is not supported for encoding.")
+        z = self.encoder(x, None)
+        if not return_dict:
+            return (z,)
+        return SimpleNamespace(latent=z)
+
+    def decode(self, z, return_dict=True, temb=None, embedded_t=False, return_static=False):
+        if self.use_slicing and z.size(0) > 1:
+            raise NotImplementedError("Slicing is not supported for decoding.")
+        y = self.decoder(z, None)
+        if not return_static and self.static_channels is not None:
+            y = y[:, : -self.static_channels, :, :]
+        if not return_dict:
+            return (y,)
+        return SimpleNamespace(sample=y)
+
+    def forward(self, sample, return_dict=True, time_elapsed=None, static_conditioning_tensor=None, return_static=False):
+        z = self.encode(sample, return_dict=False, static_conditioning_tensor=static_conditioning_tensor)[0]
+        y = self.decode(z, return_dict=False, return_static=return_static)[0]
+        if not return_dict:
+            return (y,)
+        return SimpleNamespace(sample=y)
