@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ensemble-member-steps/sec of the LaDCast AR rollout on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank: a full
+autoregressive sampler chunk (BASELINE.json configs[1]: 375M AR transformer, 1 ensemble member per
+GPU, 20 solver steps, 1 lead step) -- IC latent resident in HBM in, lead-step latents out.  With
+the shipped return_seq_len = 4 the reference computes one 4-frame chunk for a 1-lead-step request and
+keeps ``pred_selection = 1`` frame (pipelines/utils.py:535-536); the metric counts that 1 lead step.
+Weak scaling: every rank owns ``--members-per-gpu`` members (global ids rank*m .. rank*m+m-1, seeded by
+member id as pipelines/utils.py:703-706), no data-path collective except one RCCL gather of the
+result latents at the end of each step.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    "375M": dict(
+        in_channels=84, out_channels=84, num_attention_heads=12, attention_head_dim=128, num_layers=2, num_single_layers=4,
+        num_refiner_layers=1, mlp_ratio=4, patch_size=1, patch_size_t=1, qk_norm="rms_norm", rope_theta=256.0, rope_axes_dim=(16, 56, 56),
+        rope_spatial_grid_start_pos=(-499.5, 5.25), rope_spatial_grid_end_pos=(508.5, 353.25), spatial_deg2rad=True,
+        conditioning_tensor_in_channels=84, conditioning_tensor_rope_axes_dim=(16, 56, 56), incl_time_elapsed=True,
+    ),  # configs/ladcast_375M.yaml:1-30
+}
+CONFIGS["1.6B"] = dict(CONFIGS["375M"], num_attention_heads=16, num_layers=5, num_single_layers=10, num_refiner_layers=3)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+
+
+def model_flops_per_forward(cfg, R, T_in=1, hw=450):
+    """Analytic 2*MAC count of one forward per member; returns (gemm_flops, attn_flops)."""
+    D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    Nx, Nc = R * hw, T_in * hw
+    S = Nx + Nc
+    F = int(D * cfg["mlp_ratio"])
+    lin = lambda m, n, k: 2.0 * m * n * k  # noqa: E731
+    g = lin(Nx, D, 84) + lin(Nc, D, 84) + lin(Nc, D, D)  # embeds + refiner proj_in
+    g += cfg["num_refiner_layers"] * (lin(Nc, 3 * D, D) + lin(Nc, F, D) + lin(Nc, D, F))
+    g += cfg["num_layers"] * (lin(S, 3 * D, D) + lin(S, D, D) + lin(S, F, D) + lin(S, D, F))
+    g += cfg["num_single_layers"] * (lin(S, 3 * D, D) + lin(S, F, D) + lin(S, D, D + F))
+    g += lin(Nx, 84, D)
+    a = cfg["num_refiner_layers"] * 4.0 * Nc * Nc * D + (cfg["num_layers"] + cfg["num_single_layers"]) * 4.0 * S * S * D
+    return g, a
+
+
+class KernelTimer:
+    """HIP-event bracket around every launch of selected C-ABI kernels on torch's current stream
+    (the stream the kernels are launched on)."""
+
+    def __init__(self):
+        self.records = {}  # name -> list of (start, end, work)
+
+    def install(self, hip):
+        self._hip = hip
+        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd}
+        timer = self
+
+        def gemm(A, W, C, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer._orig["gemm"](A, W, C, **kw)
+            e.record()
+            timer.records.setdefault("gemm_nt_f32_kernel", []).append((s, e, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1)))
+
+        def attn_fwd(Q, K, V, O, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer._orig["attn_fwd"](Q, K, V, O, **kw)
+            e.record()
+            timer.records.setdefault("attn_fwd_f32_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
+
+        hip.gemm, hip.attn_fwd = gemm, attn_fwd
+
+    def uninstall(self):
+        self._hip.gemm, self._hip.attn_fwd = self._orig["gemm"], self._orig["attn_fwd"]
+
+    def clear(self):
+        self.records = {}
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            work = sum(w for _, _, w in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), work_per_launch=work / len(recs),
+                             tflops=work / (ms * 1e-3) / 1e12)
+        return out
+
+
+def cpu_baseline(cfg_name, R, n_forwards):
+    """Time the CPU oracle (kind "port": the reference's own path needs diffusers, absent here) on a
+    bounded sample: `n_forwards` model forwards of the same workload, then scale to one sampler chunk."""
+    from oracle.ar_model import LaDCastTransformer3DModel as OracleModel
+
+    torch.manual_seed(1234)
+    m = OracleModel.from_config(CONFIGS[cfg_name]).eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 84, R, 15, 30, generator=g)
+    known = 0.5 * torch.randn(1, 84, 1, 15, 30, generator=torch.Generator().manual_seed(2))
+    ts = torch.tensor([2018010100])
+    with torch.no_grad():
+        m(x, torch.tensor([0.5]), known, time_elapsed=ts)  # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        for i in range(n_forwards):
+            m(x, torch.tensor([0.5 - 0.1 * i]), known, time_elapsed=ts)
+        dt = (time.perf_counter() - t0) / n_forwards
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="375M", choices=list(CONFIGS))
+    ap.add_argument("--members-per-gpu", type=int, default=1)
+    ap.add_argument("--return-seq-len", type=int, default=4)
+    ap.add_argument("--lead-steps", type=int, default=1, help="lead steps requested per rollout call (1 chunk covers up to return_seq_len)")
+    ap.add_argument("--solver-steps", type=int, default=20)
+    ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = DPM-Solver++(2M), N forwards")
+    ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    import ladcast_amd.hip as hip
+    from ladcast_amd.models import LaDCastTransformer3DModel
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from datetime import datetime
+
+    cfg = CONFIGS[args.model]
+    torch.manual_seed(1234)
+    model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval()
+    pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
+    m = args.members_per_gpu
+    member_ids = [rank * m + i for i in range(m)]
+    R, lead = args.return_seq_len, args.lead_steps
+    ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).to(dev)  # IC latent, resident in HBM
+    targs = {"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5}
+    gathered = [torch.empty(m, 84, 1 + lead, 15, 30, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        out = roll_out_serial(
+            None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
+            latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
+            known_latents_override=ic, member_ids=member_ids,
+        )
+        if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
+            dist.all_gather(gathered, out[0].to(dev))
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = KernelTimer()
+    if not args.no_kernel_timers:
+        timer.install(hip)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if not args.no_kernel_timers:
+        timer.uninstall()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        chunks = -(-lead // R)
+        fwd_per_chunk = (2 * args.solver_steps - 1) if args.sampler == "edm" else args.solver_steps
+        gflops, aflops = model_flops_per_forward(cfg, R)
+        total_members = m * world
+        value = total_members * lead * args.steps / elapsed
+        ks = timer.summary()
+        roof = None
+        if "gemm_nt_f32_kernel" in ks:
+            k = ks["gemm_nt_f32_kernel"]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("gemm_nt_f32_kernel", {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = dict(bound="mfma", kernel="gemm_nt_f32_kernel", achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
+                        flops_per_launch=k["work_per_launch"])
+        line = {
+            "metric": "ensemble-member-steps/sec", "value": round(value, 4), "unit": "member-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: {args.model} AR transformer, {m} member/GPU, {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
+                            f"{lead} lead step(s) = {chunks} chunk(s) of return_seq_len {R}, latent 84x15x30, fp32 weights random-init seed 1234",
+                "sampler": args.sampler, "members_per_gpu": m, "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
+                "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
+            },
+            "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
+            "roofline": roof,
+        }
+        if "attn_fwd_f32_kernel" in ks:
+            k = ks["attn_fwd_f32_kernel"]
+            line["attention_kernel"] = dict(achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                                            launches=k["launches"], avg_launch_us=round(k["avg_us"], 2))
+        if args.cpu_forwards > 0 and world == 1:
+            cores = torch.get_num_threads()
+            dt = cpu_baseline(args.model, R, args.cpu_forwards)
+            cpu_value = lead / (chunks * fwd_per_chunk * dt)
+            line["cpu_baseline"] = dict(
+                value=round(cpu_value, 5), unit="member-steps/s", cores=cores, kind="port",
+                sample=f"{args.cpu_forwards} forwards of the same {args.model} model (1 member, R={R}) by the PyTorch CPU oracle, {dt:.2f} s each, "
+                       f"scaled to {chunks * fwd_per_chunk} forwards per step",
+            )
+            line["gpu_over_cpu"] = round(value / cpu_value, 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

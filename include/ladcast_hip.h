@@ -1,0 +1,163 @@
+/* ladcast_hip.h -- C ABI of libladcast_hip.so (MI355X / gfx950 HIP kernels for the
+ * LaDCast autoregressive latent-diffusion rollout).
+ *
+ * The reference (tonyzyl/ladcast) is pure Python and has NO FFI: its plug-in surface
+ * is Python duck typing (pipeline API, diffusers-style model/scheduler surface,
+ * attention-processor protocol).  This header is therefore
+ * build-defined.  Each entry point names the reference code it replaces
+ * (file:line under the reference tree) so a maintainer can see which torch ops
+ * the call stands in for.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (the caller --
+ *     normally torch -- owns all memory; the library never allocates);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is
+ *     enqueued on it, nothing synchronises the host; safe under hipGraph capture;
+ *   - return value: 0 on success, LDC_ERR_* (<0) on bad arguments, or
+ *     -(1000 + hipError_t) if the launch failed.  Nothing throws across the ABI;
+ *   - all matrices are row-major fp32 unless stated; "ld*" are row strides in
+ *     ELEMENTS; float4 paths need pointers 16-byte aligned and K, ld* % 4 == 0;
+ *   - no global mutable state: reentrant per stream.
+ */
+#ifndef LADCAST_HIP_H
+#define LADCAST_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDC_ABI_VERSION 1
+
+#define LDC_OK 0
+#define LDC_ERR_ARG (-1)       /* null pointer / non-positive size */
+#define LDC_ERR_ALIGN (-2)     /* pointer or stride breaks the 16-byte rule */
+#define LDC_ERR_UNSUPPORTED (-3)
+
+enum ldc_act { LDC_ACT_NONE = 0, LDC_ACT_SILU = 1, LDC_ACT_GELU_TANH = 2, LDC_ACT_RELU = 3 };
+
+int ldc_abi_version(void);
+/* name of the code-object architecture the library was built for ("gfx950") */
+const char* ldc_build_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * Dense contraction  C[b] = epilogue(A[b] . W^T)        (fp32 MFMA, exact fp32)
+ *   A[b]: M x K (lda), W: N x K (ldw, shared by all batches), C[b]: M x N (ldc)
+ *   v = acc + bias[n]; v = act(v); v *= gate[b*gate_bs + n]; v += R[b][m*ldr + n]
+ *   (bias / gate / R may be NULL).  R may alias C.
+ * Replaces nn.Linear + activation + gated residual on the token streams:
+ *   models/LaDCast_3D_model.py:92-94,175-177,214,219 (q/k/v, added q/k/v, to_out,
+ *   to_add_out), :271-276,503-512,558-563 (FeedForward + gate), :422-424,442,
+ *   460-462 (proj_mlp / proj_out of the single block), :1045 (proj_out),
+ *   models/embeddings.py:52-58 (k=1 Conv3d patch embed), and the NHWC 1x1 convs /
+ *   Linear layers of models/DCAE.py:129-131,142-144,286,296.
+ * ------------------------------------------------------------------------- */
+typedef struct ldc_gemm_desc {
+  int M, N, K, batch;
+  int lda, ldw, ldc, ldr;
+  long long a_bs, c_bs, r_bs; /* batch strides (elements) */
+  int gate_bs;                /* batch stride of gate (elements) */
+  int act;                    /* enum ldc_act */
+} ldc_gemm_desc;
+int ldc_sizeof_gemm_desc(void);
+int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const float* gate,
+                      const float* R, float* C, const ldc_gemm_desc* d, void* stream);
+
+/* Small-M linear (M = rows <= 64): y[r] = act_out(W . act_in(x[r % x_rows]) + bias)
+ *                                           + add[r % add_rows]
+ * HBM-bound weight streaming; replaces the timestep / text / AdaLN projection
+ * Linears on (B, D) vectors: diffusers TimestepEmbedding, PixArtAlphaTextProjection,
+ * AdaLayerNormZero/-Single/-Continuous .linear and HunyuanVideoAdaNorm.linear
+ * (models/LaDCast_3D_model.py:224-238,362-364,441,524-529,673-678,1044). */
+int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bias,
+                     const float* add, int add_rows, float* y, int rows, int N, int K,
+                     int act_in, int act_out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Attention   O = softmax(Q K^T / sqrt(128)) V   per (batch, head), no mask
+ *   Q,K,V: token-major [B][S][H][128] views with row stride ld_qkv and batch stride
+ *   qkv_bs (so they can be column slices of one fused QKV buffer);
+ *   O: [B][S][H*128] with row stride ldo, batch stride o_bs.
+ * Replaces F.scaled_dot_product_attention at models/LaDCast_3D_model.py:199-203
+ * (incl. the transpose/flatten back to [B, N, C]).  head_dim must be 128.
+ * ------------------------------------------------------------------------- */
+int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
+                 int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
+
+/* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
+ * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),
+ * for token rows [row0, row0+rows) of every batch of a fused QKV buffer.
+ * Replaces attn.norm_q/norm_k/norm_added_q/norm_added_k + apply_rotary_emb,
+ * models/LaDCast_3D_model.py:103-169,183-186. */
+int ldc_qk_rmsnorm_rope(float* q, float* k, int B, int row0, int rows, int H, int ld, long long bs,
+                        const float* wq, const float* wk, float eps, const float* cos_tab,
+                        const float* sin_tab, void* stream);
+
+/* Row LayerNorm (no affine inside) followed by y = n * mul + add with
+ *   mode 0: mul = 1 + scale[b][c], add = shift[b][c]   (AdaLN modulate)
+ *   mode 1: mul = scale[c],        add = shift[c]      (plain affine LayerNorm)
+ * x: [B][rows][D] (ldx, x_bs) -> y (ldy, y_bs); mod_bs = batch stride of scale/shift.
+ * Replaces AdaLayerNormZero/-Single/-Continuous .norm + modulation, nn.LayerNorm,
+ * models/LaDCast_3D_model.py:257,270,287,299,441,502,507,524-529,546-555,1044. */
+int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs,
+                      int ldy, long long y_bs, const float* scale, const float* shift, int mod_bs,
+                      int mode, float eps, void* stream);
+
+/* y[b][c] = mean over rows of x[b][r][c]   (hidden_states.mean(dim=1),
+ * models/LaDCast_3D_model.py:382,955) */
+int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, void* stream);
+
+/* out[b][r][c] = resid[b][r][c] + gate[b][c] * y[b][r][c]  (refiner gated residual on the
+ * projection-less attention output, models/LaDCast_3D_model.py:296-297) */
+int ldc_gate_residual(const float* resid, const float* y, const float* gate, float* out, int B,
+                      int rows, int D, int ld_res, long long res_bs, int ld_y, long long y_bs,
+                      int gate_bs, void* stream);
+
+/* Layout changes between the reference's channel-major latents (B, C, T*H*W) and
+ * token-major (B, T*H*W, ld) (models/embeddings.py:56-59 flatten/transpose and
+ * models/LaDCast_3D_model.py:1047-1062 un-patchify; also NCHW <-> NHWC for the DCAE).
+ * Columns [C, ldo) of the token-major output are zero-filled. */
+int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, void* stream);
+int ldc_token_to_chan(const float* in, float* out, int B, int C, int N, int ldi, void* stream);
+
+/* Sinusoidal timestep embedding [cos | sin], 256 wide (diffusers Timesteps(256,
+ * flip_sin_to_cos=True, shift=0); models/LaDCast_3D_model.py:362-364,673). */
+int ldc_timestep_embedding(const float* t, float* out, int n, void* stream);
+
+/* temb[b][c] = temb[b][c] * (1 + te[b % te_rows][c]) + te[b % te_rows][D + c]
+ * (time-elapsed scale/shift, models/LaDCast_3D_model.py:966-969) */
+int ldc_temb_modulate(float* temb, const float* te, int B, int D, int te_rows, void* stream);
+
+/* Per-channel affine on (outer, C, inner): forward (x-mean[c])/std[c]*t, inverse
+ * x/t*std[c]+mean[c]  (dataloader/utils.py:223-240). */
+int ldc_chan_affine(const float* x, float* y, const float* mean, const float* std_, float target_std,
+                    long long outer, int C, long long inner, int inverse, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Sampler state updates (pipelines/edm_sampler.py:60-113; fp64 state, fp32 model I/O)
+ * and the DPM-Solver++(2M) step of diffusers.EDMDPMSolverMultistepScheduler.step
+ * (used by pipelines/pipeline_AR.py:100-102).  Scalars are computed on the host
+ * in fp32 exactly as the scheduler does and passed here widened to double.
+ * ------------------------------------------------------------------------- */
+int ldc_edm_scale_f64_to_f32(const double* x, double c_in, float* out, long long n, void* stream);
+int ldc_edm_init_state(const float* noise, double sigma0, double* x, long long n, void* stream);
+/* den = c_skip*x + c_out*F; d = (x-den)/t_hat; x_next = x + dt*d */
+int ldc_edm_euler(const double* x_hat, const float* F, double c_skip, double c_out, double t_hat,
+                  double dt, double* x_next, double* d_cur, long long n, void* stream);
+/* den = c_skip*x_next + c_out*F; d' = (x_next-den)/t_next; x_next = x_hat + dt*(0.5 d_cur + 0.5 d') */
+int ldc_edm_heun(const double* x_hat, double* x_next, const float* F, const double* d_cur,
+                 double c_skip, double c_out, double t_next, double dt, long long n, void* stream);
+int ldc_f64_to_f32(const double* x, float* y, long long n, void* stream);
+/* x0 = c_skip*sample + c_out*F; order 1: prev = a*sample - b*x0;
+ * order 2: prev = a*sample - b*x0 - (0.5*b) * (inv_r0 * (x0 - m1))   (all fp32) */
+int ldc_dpm_step(const float* sample, const float* F, const float* m1, float* x0, float* prev,
+                 float c_skip, float c_out, float a, float b, float inv_r0, int order, long long n,
+                 void* stream);
+int ldc_scale_f32(const float* x, float s, float* y, long long n, void* stream);
+/* out = a*x + b*y (fp32): scheduler.precondition_outputs (c_skip*sample + c_out*F) and
+ * add_noise (x0 + sigma*noise) on whole tensors */
+int ldc_axpby_f32(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LADCAST_HIP_H */

@@ -1,0 +1,4 @@
+#include "common.h"
+
+extern "C" int ldc_abi_version(void) { return LDC_ABI_VERSION; }
+extern "C" const char* ldc_build_arch(void) { return "gfx950"; }

@@ -1,0 +1,225 @@
+// Flash-style joint attention on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32).
+// Replaces F.scaled_dot_product_attention(q, k, v) + the transpose back to [B, N, C]
+// at models/LaDCast_3D_model.py:199-203 for head_dim 128, no mask, non-causal.
+//
+// Layout: Q/K/V are token-major [B][S][H][128] column slices of one fused QKV buffer
+// (row stride ld_qkv), exactly what the QKV projection GEMM writes, so no head transpose
+// ever touches HBM; O is written token-major [B][S][H*128].
+//
+// Work split: workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns
+// 32 query rows and sweeps all keys in tiles of 32.  Per tile and wave:
+//   S^T = K . Q^T   (64 MFMAs, A = K tile from LDS via ds_read_b128, B = Q held in 64 VGPRs)
+//     -> the accumulator has the QUERY on the lane and 16 keys in registers, so the
+//        row-wise softmax is 16 in-lane ops + one cross-half shuffle (64-wide wavefront:
+//        lanes l and l+32 hold the two key halves of the same query);
+//   O^T += V^T . P^T (64 MFMAs, A = V tile from LDS via conflict-free ds_read_b32,
+//        B = the probability registers as they stand -- accumulator register r of half h
+//        holds key (r&3)+8(r>>2)+4h, which is exactly the k-pair {kappa, kappa+4} one
+//        32x32x2 MFMA sums over; no LDS round trip, no lane movement).
+// The softmax scale 1/sqrt(128) and log2(e) are folded into Q once; exp2 is used.
+// K/V tiles are staged HBM -> VGPR -> LDS double-buffered (66 KiB -> 2 workgroups / CU);
+// the K tile uses a 132-float pitch (conflict-free for the b128 lane groups).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;      // head dim
+constexpr int QB = 128;      // query rows per workgroup
+constexpr int KT = 32;       // keys per tile
+constexpr int KP = HD + 4;   // K tile pitch (floats)
+constexpr int STAGE = KT * KP + KT * HD;  // floats per stage
+
+struct AttnArgs {
+  const float* Q;
+  const float* K;
+  const float* V;
+  float* O;
+  int S, H, ld_qkv, ldo;
+  long long qkv_bs, o_bs;
+  float qscale;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int S = p.S;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  const long long base = static_cast<long long>(b) * p.qkv_bs + static_cast<long long>(head) * HD;
+  const float* __restrict__ Qg = p.Q + base;
+  const float* __restrict__ Kg = p.K + base;
+  const float* __restrict__ Vg = p.V + base;
+  const int ld = p.ld_qkv;
+
+  // Q fragments: qf[c][r] = Q[q0 + l31][8c + 4*half + r] * qscale
+  float qf[16][4];
+  {
+    const int qrow = q0 + l31;
+    const bool ok = qrow < S;
+    const float* qp = Qg + static_cast<long long>(ok ? qrow : 0) * ld + 4 * half;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float4 v = ok ? *reinterpret_cast<const float4*>(qp + 8 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[c][0] = v.x * p.qscale;
+      qf[c][1] = v.y * p.qscale;
+      qf[c][2] = v.z * p.qscale;
+      qf[c][3] = v.w * p.qscale;
+    }
+  }
+
+  // staging map: thread t moves float4 column c4 = t&31 of key rows (t>>5) + 8*i
+  const int c4 = tid & 31;
+  const int kr0 = tid >> 5;
+  float4 rk[4], rv[4];
+  auto gload = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = key0 + kr0 + 8 * i;
+      if (key < S) {
+        const long long off = static_cast<long long>(key) * ld + c4 * 4;
+        rk[i] = *reinterpret_cast<const float4*>(Kg + off);
+        rv[i] = *reinterpret_cast<const float4*>(Vg + off);
+      } else {
+        rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto sstore = [&](int stage) {
+    float* Ks = smem + stage * STAGE;
+    float* Vs = Ks + KT * KP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = kr0 + 8 * i;
+      *reinterpret_cast<float4*>(Ks + key * KP + c4 * 4) = rk[i];
+      *reinterpret_cast<float4*>(Vs + key * HD + c4 * 4) = rv[i];
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -1.0e30f;
+  float l_run = 0.f;
+
+  const int nt = (S + KT - 1) / KT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) gload((t + 1) * KT);
+    const float* Ks = smem + (t & 1) * STAGE;
+    const float* Vs = Ks + KT * KP;
+
+    // ---- S^T = K . Q^T ------------------------------------------------------
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* kb = Ks + l31 * KP + 4 * half;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 kf = *reinterpret_cast<const float4*>(kb + 8 * c);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c][0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c][1], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c][2], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c][3], s, 0, 0, 0);
+    }
+
+    // ---- online softmax over the key axis (registers + the other lane half) --
+    const int key_base = t * KT + 4 * half;
+    if (t == nt - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_base + (r & 3) + 8 * (r >> 2);
+        if (key >= S) s[r] = -1.0e30f;
+      }
+    }
+    float m_t = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m_t = fmaxf(m_t, s[r]);
+    m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+    const float m_new = fmaxf(m_run, m_t);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = exp2f(s[r] - m_new);
+      rs += s[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+
+    // ---- O^T += V^T . P^T ------------------------------------------------------
+    const float* vb = Vs + (4 * half) * HD + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kappa = (r & 3) + 8 * (r >> 2);
+      const float* vr = vb + kappa * HD;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 * d], s[r], o[d], 0, 0, 0);
+      }
+    }
+
+    if (t + 1 < nt) sstore((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q0+l31][32d + 8g + 4half + (0..3)] in o[d][4g..4g+3]
+  const int qrow = q0 + l31;
+  if (qrow < S) {
+    const float inv = 1.0f / l_run;
+    float* op = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD + 4 * half;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
+                            int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream) {
+  LDC_CHECK_PTR(Q);
+  LDC_CHECK_PTR(K);
+  LDC_CHECK_PTR(V);
+  LDC_CHECK_PTR(O);
+  if (B <= 0 || S <= 0 || H <= 0) return LDC_ERR_ARG;
+  LDC_CHECK_ALIGN16(Q);
+  LDC_CHECK_ALIGN16(K);
+  LDC_CHECK_ALIGN16(V);
+  LDC_CHECK_ALIGN16(O);
+  if ((ld_qkv & 3) || (ldo & 3) || (qkv_bs & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
+  if (H > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  AttnArgs p{Q, K, V, O, S, H, ld_qkv, ldo, qkv_bs, o_bs,
+             0.08838834764831845f * 1.4426950408889634f};  // 1/sqrt(128) * log2(e)
+  dim3 grid(ldc_cdiv(S, QB), H, B);
+  const size_t lds = 2 * STAGE * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return ldc_launch_status();
+}

@@ -1,0 +1,53 @@
+// Shared helpers for the gfx950 kernels of libladcast_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ladcast_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDC_CHECK_PTR(p) \
+  do {                   \
+    if ((p) == nullptr) return LDC_ERR_ARG; \
+  } while (0)
+#define LDC_CHECK_ALIGN16(p) \
+  do {                       \
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) return LDC_ERR_ALIGN; \
+  } while (0)
+
+static inline int ldc_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LDC_OK : -(1000 + static_cast<int>(e));
+}
+
+static inline int ldc_cdiv(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+__device__ __forceinline__ float ldc_silu(float v) { return v / (1.0f + __expf(-v)); }
+// tanh-approximate GELU, same formula as torch: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float ldc_gelu_tanh(float v) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (v + k1 * v * v * v);
+  return 0.5f * v * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float ldc_apply_act(float v, int act) {
+  switch (act) {
+    case LDC_ACT_SILU: return ldc_silu(v);
+    case LDC_ACT_GELU_TANH: return ldc_gelu_tanh(v);
+    case LDC_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+
+// wave64 butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,205 @@
+"""ctypes binding of the C ABI in ``include/ladcast_hip.h``.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream.  Every wrapper takes
+torch CUDA(=HIP) tensors, passes raw device pointers + sizes + the current stream to the
+shared library and raises ``RuntimeError`` on a non-zero status.  Importing this module
+without the built library raises immediately -- the product path never falls back to
+PyTorch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libladcast_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
+        ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("ldr", c_int),
+        ("a_bs", c_longlong), ("c_bs", c_longlong), ("r_bs", c_longlong),
+        ("gate_bs", c_int), ("act", c_int),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ladcast_amd/csrc`).  ladcast_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, L, F, D = c_void_p, c_int, c_longlong, c_float, c_double
+    sig = {
+        "ldc_abi_version": (I, []),
+        "ldc_build_arch": (c_char_p, []),
+        "ldc_sizeof_gemm_desc": (I, []),
+        "ldc_gemm_bias_act": (I, [P, P, P, P, P, P, POINTER(GemmDesc), P]),
+        "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
+        "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
+        "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
+        "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, P]),
+        "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
+        "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
+        "ldc_chan_to_token": (I, [P, P, I, I, I, I, P]),
+        "ldc_token_to_chan": (I, [P, P, I, I, I, I, P]),
+        "ldc_timestep_embedding": (I, [P, P, I, P]),
+        "ldc_temb_modulate": (I, [P, P, I, I, I, P]),
+        "ldc_chan_affine": (I, [P, P, P, P, F, L, I, L, I, P]),
+        "ldc_edm_scale_f64_to_f32": (I, [P, D, P, L, P]),
+        "ldc_edm_init_state": (I, [P, D, P, L, P]),
+        "ldc_edm_euler": (I, [P, P, D, D, D, D, P, P, L, P]),
+        "ldc_edm_heun": (I, [P, P, P, P, D, D, D, D, L, P]),
+        "ldc_f64_to_f32": (I, [P, P, L, P]),
+        "ldc_dpm_step": (I, [P, P, P, P, P, F, F, F, F, F, I, L, P]),
+        "ldc_scale_f32": (I, [P, F, P, L, P]),
+        "ldc_axpby_f32": (I, [P, F, P, F, P, L, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ldc_abi_version() != 1:
+        raise RuntimeError("libladcast_hip.so ABI version mismatch")
+    if lib.ldc_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc):
+        raise RuntimeError("ldc_gemm_desc layout mismatch between header and binding")
+    return lib, sig
+
+
+lib, SIGNATURES = _load()
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}")
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ladcast_amd kernels need device tensors (no CPU fallback)")
+
+
+# ---------------------------------------------------------------------------
+def gemm(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_bs=0, bias=None, gate=None,
+         gate_bs=0, R=None, ldr=0, r_bs=0, act=ACT_NONE):
+    """C[b] = epilogue(A[b] . W^T); A/C/R may be views (data_ptr carries the offset)."""
+    _dev(A, W, C, bias, gate, R)
+    d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K,
+                 ldc if ldc is not None else N, ldr, a_bs, c_bs, r_bs, gate_bs, act)
+    _check(lib.ldc_gemm_bias_act(_p(A), _p(W), _p(bias), _p(gate), _p(R), _p(C), ctypes.byref(d), _stream()), "ldc_gemm_bias_act")
+
+
+def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE):
+    _dev(x, W, y, bias, add)
+    _check(lib.ldc_linear_small(_p(x), x_rows if x_rows is not None else rows, _p(W), _p(bias), _p(add), add_rows, _p(y),
+                                rows, N, K, act_in, act_out, _stream()), "ldc_linear_small")
+
+
+def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs):
+    _dev(Q, K, V, O)
+    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd")
+
+
+def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, sin=None):
+    _dev(q, k, wq, wk, cos, sin)
+    _check(lib.ldc_qk_rmsnorm_rope(_p(q), _p(k), B, row0, rows, H, ld, bs, _p(wq), _p(wk), eps, _p(cos), _p(sin), _stream()),
+           "ldc_qk_rmsnorm_rope")
+
+
+def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=None, mod_bs=0, mode=0, eps=1e-6):
+    _dev(x, y, scale, shift)
+    _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps, _stream()),
+           "ldc_layernorm_mod")
+
+
+def mean_rows(x, y, *, B, rows, D, ldx, x_bs):
+    _dev(x, y)
+    _check(lib.ldc_mean_rows(_p(x), _p(y), B, rows, D, ldx, x_bs, _stream()), "ldc_mean_rows")
+
+
+def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs):
+    _dev(resid, y, gate, out)
+    _check(lib.ldc_gate_residual(_p(resid), _p(y), _p(gate), _p(out), B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs, _stream()),
+           "ldc_gate_residual")
+
+
+def chan_to_token(x, out, *, B, C, N, ldo):
+    _dev(x, out)
+    _check(lib.ldc_chan_to_token(_p(x), _p(out), B, C, N, ldo, _stream()), "ldc_chan_to_token")
+
+
+def token_to_chan(x, out, *, B, C, N, ldi):
+    _dev(x, out)
+    _check(lib.ldc_token_to_chan(_p(x), _p(out), B, C, N, ldi, _stream()), "ldc_token_to_chan")
+
+
+def timestep_embedding(t, out, n):
+    _dev(t, out)
+    _check(lib.ldc_timestep_embedding(_p(t), _p(out), n, _stream()), "ldc_timestep_embedding")
+
+
+def temb_modulate(temb, te, *, B, D, te_rows):
+    _dev(temb, te)
+    _check(lib.ldc_temb_modulate(_p(temb), _p(te), B, D, te_rows, _stream()), "ldc_temb_modulate")
+
+
+def chan_affine(x, y, mean, std, target_std, *, outer, C, inner, inverse):
+    _dev(x, y, mean, std)
+    _check(lib.ldc_chan_affine(_p(x), _p(y), _p(mean), _p(std), target_std, outer, C, inner, int(inverse), _stream()), "ldc_chan_affine")
+
+
+def edm_scale_f64_to_f32(x, c_in, out):
+    _dev(x, out)
+    _check(lib.ldc_edm_scale_f64_to_f32(_p(x), c_in, _p(out), x.numel(), _stream()), "ldc_edm_scale_f64_to_f32")
+
+
+def edm_init_state(noise, sigma0, x):
+    _dev(noise, x)
+    _check(lib.ldc_edm_init_state(_p(noise), sigma0, _p(x), x.numel(), _stream()), "ldc_edm_init_state")
+
+
+def edm_euler(x_hat, F, c_skip, c_out, t_hat, dt, x_next, d_cur):
+    _dev(x_hat, F, x_next, d_cur)
+    _check(lib.ldc_edm_euler(_p(x_hat), _p(F), c_skip, c_out, t_hat, dt, _p(x_next), _p(d_cur), x_hat.numel(), _stream()), "ldc_edm_euler")
+
+
+def edm_heun(x_hat, x_next, F, d_cur, c_skip, c_out, t_next, dt):
+    _dev(x_hat, x_next, F, d_cur)
+    _check(lib.ldc_edm_heun(_p(x_hat), _p(x_next), _p(F), _p(d_cur), c_skip, c_out, t_next, dt, x_hat.numel(), _stream()), "ldc_edm_heun")
+
+
+def f64_to_f32(x, y):
+    _dev(x, y)
+    _check(lib.ldc_f64_to_f32(_p(x), _p(y), x.numel(), _stream()), "ldc_f64_to_f32")
+
+
+def dpm_step(sample, F, m1, x0, prev, c_skip, c_out, a, b, inv_r0, order):
+    _dev(sample, F, m1, x0, prev)
+    _check(lib.ldc_dpm_step(_p(sample), _p(F), _p(m1), _p(x0), _p(prev), c_skip, c_out, a, b, inv_r0, order, sample.numel(), _stream()),
+           "ldc_dpm_step")
+
+
+def scale_f32(x, s, y):
+    _dev(x, y)
+    _check(lib.ldc_scale_f32(_p(x), s, _p(y), x.numel(), _stream()), "ldc_scale_f32")
+
+
+def axpby_f32(x, a, y, b, out):
+    _dev(x, y, out)
+    _check(lib.ldc_axpby_f32(_p(x), a, _p(y), b, _p(out), x.numel(), _stream()), "ldc_axpby_f32")

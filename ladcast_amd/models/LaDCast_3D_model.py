@@ -1,0 +1,503 @@
+"""``LaDCastTransformer3DModel`` on MI355X HIP kernels.
+
+Drop-in for ``ladcast.models.LaDCast_3D_model.LaDCastTransformer3DModel``
+(models/LaDCast_3D_model.py:569-1071): same constructor kwargs / ``config``, same parameter
+names (a reference ``diffusion_pytorch_model.safetensors`` loads strictly), same
+``forward(hidden_states, timestep, conditioning_tensors, time_elapsed=None, ...)`` returning
+an object with ``.sample`` (or a tuple).  The ``nn.Module`` tree below is a *parameter
+container only*: no torch arithmetic runs in ``forward`` -- every tensor op is a call into
+``libladcast_hip.so`` (``ladcast_amd.hip``).
+
+MI355X-first execution plan (vs the reference's op-by-op torch graph):
+* both token streams live in ONE joint buffer ``h[B, Nx+Nc, D]`` (pred tokens first), so the
+  concatenations at models/LaDCast_3D_model.py:89,188-190,436,457,460 never move data;
+* q/k/v weights are fused into one ``[3D, D]`` matrix per stream at load time, the QKV GEMM
+  writes token-major ``[B, S, 3D]`` which the attention kernel reads in place (no head
+  transposes), and attention writes straight into the ``[attn | mlp]`` concat buffer of the
+  single-stream block;
+* bias, activation, AdaLN gate and the residual add are the GEMM epilogue;
+* RoPE tables, the year embedding MLP and the workspace are cached across the 39 forwards
+  of a sampler chunk (the reference rebuilds them every call, Q11).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .embeddings import get_year_sincos_embedding, rope_tables_from_grid
+from .modeling_utils import ModelMixin
+
+
+# ---------------------------------------------------------------------------
+# parameter containers (names = reference / diffusers attribute names)
+# ---------------------------------------------------------------------------
+class _RMSNormP(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class _TimestepEmbeddingP(nn.Module):
+    def __init__(self, in_channels, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+
+class _CombinedTimestepTextProjP(nn.Module):
+    def __init__(self, dim, pooled_dim):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbeddingP(256, dim)
+        self.text_embedder = _TimestepEmbeddingP(pooled_dim, dim)  # PixArtAlphaTextProjection: same two Linears
+
+
+class _AdaLinearP(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.linear = nn.Linear(dim_in, dim_out)
+
+
+class _ActProjP(nn.Module):
+    def __init__(self, a, b):
+        super().__init__()
+        self.proj = nn.Linear(a, b)
+
+
+class _FeedForwardP(nn.Module):
+    def __init__(self, dim, mult):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([_ActProjP(dim, inner), nn.Identity(), nn.Linear(inner, dim)])
+
+
+class _AttentionP(nn.Module):
+    def __init__(self, dim, heads, head_dim, eps=1e-7, added=False, pre_only=False):
+        super().__init__()
+        inner = heads * head_dim
+        self.heads = heads
+        self.to_q = nn.Linear(dim, inner)
+        self.to_k = nn.Linear(dim, inner)
+        self.to_v = nn.Linear(dim, inner)
+        self.norm_q = _RMSNormP(head_dim, eps)
+        self.norm_k = _RMSNormP(head_dim, eps)
+        if added:
+            self.add_k_proj = nn.Linear(dim, inner)
+            self.add_v_proj = nn.Linear(dim, inner)
+            self.add_q_proj = nn.Linear(dim, inner)
+            self.norm_added_q = _RMSNormP(head_dim, eps)
+            self.norm_added_k = _RMSNormP(head_dim, eps)
+            self.to_add_out = nn.Linear(inner, dim)
+        if not pre_only:
+            self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Identity()])
+        self.processor = None
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+
+class _PatchEmbedP(nn.Module):
+    def __init__(self, in_chans, dim):
+        super().__init__()
+        self.proj = nn.Conv3d(in_chans, dim, kernel_size=(1, 1, 1), stride=(1, 1, 1))
+
+
+class _RefinerBlockP(nn.Module):
+    def __init__(self, heads, head_dim, mlp_width_ratio=4.0):
+        super().__init__()
+        d = heads * head_dim
+        self.norm1 = nn.LayerNorm(d, elementwise_affine=True, eps=1e-7)
+        self.attn = _AttentionP(d, heads, head_dim, pre_only=True)
+        self.norm2 = nn.LayerNorm(d, elementwise_affine=True, eps=1e-7)
+        self.ff = _FeedForwardP(d, mlp_width_ratio)
+        self.norm_out = _AdaLinearP(d, 2 * d)
+
+
+class _IndividualTokenRefinerP(nn.Module):
+    def __init__(self, heads, head_dim, n):
+        super().__init__()
+        self.refiner_blocks = nn.ModuleList([_RefinerBlockP(heads, head_dim) for _ in range(n)])
+
+
+class _TokenRefinerP(nn.Module):
+    def __init__(self, in_channels, heads, head_dim, n):
+        super().__init__()
+        d = heads * head_dim
+        self.time_text_embed = _CombinedTimestepTextProjP(d, in_channels)
+        self.proj_in = nn.Linear(in_channels, d)
+        self.token_refiner = _IndividualTokenRefinerP(heads, head_dim, n)
+
+
+class _SingleBlockP(nn.Module):
+    def __init__(self, heads, head_dim, mlp_ratio):
+        super().__init__()
+        d = heads * head_dim
+        mlp = int(d * mlp_ratio)
+        self.attn = _AttentionP(d, heads, head_dim, pre_only=True)
+        self.norm = _AdaLinearP(d, 3 * d)
+        self.proj_mlp = nn.Linear(d, mlp)
+        self.proj_out = nn.Linear(d + mlp, d)
+
+
+class _DualBlockP(nn.Module):
+    def __init__(self, heads, head_dim, mlp_ratio):
+        super().__init__()
+        d = heads * head_dim
+        self.norm1 = _AdaLinearP(d, 6 * d)
+        self.norm1_context = _AdaLinearP(d, 6 * d)
+        self.attn = _AttentionP(d, heads, head_dim, added=True)
+        self.ff = _FeedForwardP(d, mlp_ratio)
+        self.ff_context = _FeedForwardP(d, mlp_ratio)
+
+
+# ---------------------------------------------------------------------------
+class _Workspace:
+    """Device scratch for one (B, Nx, Nc) problem; allocated once, reused by every forward."""
+
+    def __init__(self, dev, B, Bt, Nx, Nc, D, C_in, C_out):
+        f = dict(device=dev, dtype=torch.float32)
+        S = Nx + Nc
+        self.h = torch.empty(B, S, D, **f)
+        self.nh = torch.empty(B, S, D, **f)
+        self.qkv = torch.empty(B, S, 3 * D, **f)
+        self.att = torch.empty(B, S, D, **f)
+        self.cat = torch.empty(B, S, 5 * D, **f)
+        self.xtok = torch.empty(B, Nx, C_in, **f)
+        self.ctok = torch.empty(B, Nc, C_in, **f)
+        self.ctx0 = torch.empty(B, Nc, D, **f)
+        self.otok = torch.empty(B, Nx, C_out, **f)
+        self.tsin = torch.empty(Bt, 256, **f)
+        self.t1 = torch.empty(Bt, D, **f)
+        self.t2 = torch.empty(Bt, D, **f)
+        self.pooled = torch.empty(B, D, **f)
+        self.p1 = torch.empty(B, D, **f)
+        self.temb_r = torch.empty(B, D, **f)
+        self.temb = torch.empty(B, D, **f)
+        self.mod_a = torch.empty(B, 6 * D, **f)
+        self.mod_b = torch.empty(B, 6 * D, **f)
+
+
+class LaDCastTransformer3DModel(ModelMixin):
+    _supports_gradient_checkpointing = False
+
+    def __init__(
+        self,
+        in_channels: int = 16,
+        out_channels: int = 16,
+        num_attention_heads: int = 24,
+        attention_head_dim: int = 128,
+        num_layers: int = 20,
+        num_single_layers: int = 40,
+        num_refiner_layers: int = 2,
+        mlp_ratio: float = 4.0,
+        patch_size: int = 1,
+        patch_size_t: int = 1,
+        qk_norm: str = "rms_norm",
+        rope_theta: float = 256.0,
+        rope_axes_dim: Tuple[int, ...] = (16, 56, 56),
+        rope_spatial_grid_start_pos=0,
+        rope_spatial_grid_end_pos=None,
+        spatial_deg2rad: bool = False,
+        conditioning_tensor_in_channels: int = None,
+        conditioning_tensor_intermediate_proj_dim: Optional[int] = None,
+        conditioning_tensor_rope_axes_dim: Tuple[int, ...] = (16, 56, 56),
+        incl_time_elapsed: bool = False,
+        nope: bool = False,
+        scale_attn_by_lat: bool = False,
+    ) -> None:
+        super().__init__()
+        self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        if nope or scale_attn_by_lat:
+            raise NotImplementedError("nope / scale_attn_by_lat are not used by any shipped config")
+        if patch_size != 1 or patch_size_t != 1:
+            raise NotImplementedError("shipped configs use patch size 1 (configs/ladcast_375M.yaml:11-12)")
+        if attention_head_dim != 128 or qk_norm != "rms_norm":
+            raise NotImplementedError("the attention kernel is built for head_dim 128 + rms_norm q/k")
+        if in_channels % 4 or (conditioning_tensor_in_channels or in_channels) % 4:
+            raise NotImplementedError("channel counts must be multiples of 4 (16-byte rows)")
+        heads, hd = num_attention_heads, attention_head_dim
+        d = heads * hd
+        out_channels = out_channels or in_channels
+        self.inner_dim = d
+        self.x_embedder = _PatchEmbedP(in_channels, d)
+        if conditioning_tensor_intermediate_proj_dim is None:
+            conditioning_tensor_intermediate_proj_dim = d
+        self.context_embedder = _PatchEmbedP(conditioning_tensor_in_channels, d)
+        self.context_refiner = _TokenRefinerP(conditioning_tensor_intermediate_proj_dim, heads, hd, num_refiner_layers)
+        self.time_text_embed = _CombinedTimestepTextProjP(d, d)
+        self.time_elapsed_embed = _TimestepEmbeddingP(256, 2 * d) if incl_time_elapsed else None
+        if spatial_deg2rad:
+            rope_spatial_grid_start_pos = [float(np.deg2rad(v)) for v in rope_spatial_grid_start_pos]
+            rope_spatial_grid_end_pos = [float(np.deg2rad(v)) for v in rope_spatial_grid_end_pos]
+        self.rope_spatial_grid_start_pos = rope_spatial_grid_start_pos
+        self.rope_spatial_grid_end_pos = rope_spatial_grid_end_pos
+        assert sum(rope_axes_dim) == hd, "sum(rope_axes_dim) must equal attention_head_dim"
+        assert sum(conditioning_tensor_rope_axes_dim) == hd
+        self.transformer_blocks = nn.ModuleList([_DualBlockP(heads, hd, mlp_ratio) for _ in range(num_layers)])
+        self.single_transformer_blocks = nn.ModuleList([_SingleBlockP(heads, hd, mlp_ratio) for _ in range(num_single_layers)])
+        self.norm_out = _AdaLinearP(d, 2 * d)
+        self.proj_out = nn.Linear(d, out_channels)
+        self.requires_grad_(False)
+        self._plan = None
+        self._ws = {}
+        self._rope = {}
+        self._te_cache = None
+
+    # -- diffusers-style processor surface (models/LaDCast_3D_model.py:763-827) --------------
+    @property
+    def attn_processors(self):
+        out = {}
+        for name, mod in self.named_modules():
+            if isinstance(mod, _AttentionP):
+                out[f"{name}.processor"] = mod.get_processor()
+        return out
+
+    def set_attn_processor(self, processor):
+        mods = {f"{n}.processor": m for n, m in self.named_modules() if isinstance(m, _AttentionP)}
+        if isinstance(processor, dict):
+            if len(processor) != len(mods):
+                raise ValueError(
+                    f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                    f" number of attention layers: {len(mods)}. Please make sure to pass {len(mods)} processor classes."
+                )
+            for k, m in mods.items():
+                m.set_processor(processor[k])
+        else:
+            for m in mods.values():
+                m.set_processor(processor)
+
+    # -- plan: fused weights ---------------------------------------------------------------
+    def _apply(self, fn, *a, **k):  # any .to()/.cuda() invalidates the fused copies + caches
+        self._plan = None
+        self._ws = {}
+        self._rope = {}
+        self._te_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    @staticmethod
+    def _fuse_qkv(q, k, v):
+        return (
+            torch.cat([q.weight, k.weight, v.weight], dim=0).contiguous(),
+            torch.cat([q.bias, k.bias, v.bias], dim=0).contiguous(),
+        )
+
+    def _build_plan(self):
+        if self.dtype != torch.float32:
+            raise NotImplementedError("this build computes in fp32 (exact-fp32 MFMA); cast the model to float32")
+        if not next(self.parameters()).is_cuda:
+            raise RuntimeError("LaDCastTransformer3DModel must live on a HIP device (no CPU fallback)")
+        plan = SimpleNamespace(attn={})
+        for name, mod in self.named_modules():
+            if isinstance(mod, _AttentionP):
+                e = SimpleNamespace()
+                e.wqkv, e.bqkv = self._fuse_qkv(mod.to_q, mod.to_k, mod.to_v)
+                if hasattr(mod, "add_q_proj"):
+                    e.wqkv_c, e.bqkv_c = self._fuse_qkv(mod.add_q_proj, mod.add_k_proj, mod.add_v_proj)
+                plan.attn[id(mod)] = e
+        d = self.inner_dim
+        plan.wx = self.x_embedder.proj.weight.reshape(d, -1).contiguous()
+        plan.wc = self.context_embedder.proj.weight.reshape(d, -1).contiguous()
+        self._plan = plan
+
+    # -- cached tables -----------------------------------------------------------------------
+    def _rope_tables(self, r, t_in, h, w, dev):
+        key = (r, t_in, h, w, str(dev))
+        if key not in self._rope:
+            c = self.config
+            cond_t = torch.arange(-t_in + 1, 1, dtype=torch.float32)
+            pred_t = torch.arange(1, r + 1, dtype=torch.float32)
+            lat = torch.linspace(self.rope_spatial_grid_start_pos[0], self.rope_spatial_grid_end_pos[0], steps=h, dtype=torch.float32)
+            lon = torch.linspace(self.rope_spatial_grid_start_pos[1], self.rope_spatial_grid_end_pos[1], steps=w, dtype=torch.float32)
+            pc, ps = rope_tables_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
+            cc, cs = rope_tables_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
+            self._rope[key] = tuple(t.to(dev) for t in (pc, ps, cc, cs))
+        return self._rope[key]
+
+    def _time_elapsed_embedding(self, time_elapsed, dev):
+        """(rows, 2D) device tensor = time_elapsed_embed(year_sincos(time_elapsed)); cached while the caller
+        keeps passing the same timestamp tensor (the sampler does, 39 times per chunk)."""
+        key = (time_elapsed.data_ptr(), time_elapsed._version, tuple(time_elapsed.shape), str(time_elapsed.device))
+        if self._te_cache is not None and self._te_cache[0] == key:
+            return self._te_cache[1]
+        stamps = [int(v) for v in time_elapsed.reshape(-1).tolist()]  # host sync once per chunk (reference: every call)
+        n, d2 = len(stamps), 2 * self.inner_dim
+        emb = get_year_sincos_embedding(stamps, 256).to(dev)
+        te = self.time_elapsed_embed
+        mid = torch.empty(n, d2, device=dev, dtype=torch.float32)
+        out = torch.empty(n, d2, device=dev, dtype=torch.float32)
+        hip.linear_small(emb, te.linear_1.weight, mid, rows=n, N=d2, K=256, bias=te.linear_1.bias, act_out=hip.ACT_SILU)
+        hip.linear_small(mid, te.linear_2.weight, out, rows=n, N=d2, K=d2, bias=te.linear_2.bias)
+        self._te_cache = (key, out, time_elapsed)  # keep the tensor alive so data_ptr cannot be recycled
+        return out
+
+    # -- building blocks ---------------------------------------------------------------------
+    def _combined_embed(self, emb, tsin, Bt, pooled, B, pooled_dim, ws, out):
+        """CombinedTimestepTextProjEmbeddings: timestep MLP (Bt rows) + text MLP (B rows)."""
+        D = self.inner_dim
+        te, tx = emb.timestep_embedder, emb.text_embedder
+        hip.linear_small(tsin, te.linear_1.weight, ws.t1, rows=Bt, N=D, K=256, bias=te.linear_1.bias, act_out=hip.ACT_SILU)
+        hip.linear_small(ws.t1, te.linear_2.weight, ws.t2, rows=Bt, N=D, K=D, bias=te.linear_2.bias)
+        hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=pooled_dim, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
+        hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
+
+    def _attention(self, ws, B, S, row0, q_ld_buf, out, ldo, o_bs):
+        """attention over token rows [row0, row0+S) of the fused qkv buffer -> out"""
+        D, H = self.inner_dim, self.config.num_attention_heads
+        qkv = q_ld_buf
+        full = qkv.shape[1]
+        q = qkv[:, row0:, 0:D]
+        k = qkv[:, row0:, D : 2 * D]
+        v = qkv[:, row0:, 2 * D : 3 * D]
+        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs)
+
+    def _qk_norm_rope(self, ws, B, row0, rows, norm_q, norm_k, cos, sin):
+        D, H = self.inner_dim, self.config.num_attention_heads
+        full = ws.qkv.shape[1]
+        hip.qk_rmsnorm_rope(
+            ws.qkv[:, :, 0:D], ws.qkv[:, :, D : 2 * D], B=B, row0=row0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
+            wq=norm_q.weight, wk=norm_k.weight, eps=norm_q.eps, cos=cos, sin=sin,
+        )
+
+    # -- forward -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self,
+        hidden_states: torch.Tensor,
+        timestep: torch.Tensor,
+        conditioning_tensors: torch.Tensor,
+        time_elapsed: Optional[torch.Tensor] = None,
+        attention_kwargs=None,
+        return_dict: bool = True,
+        coords=None,
+    ):
+        if self._plan is None:
+            self._build_plan()
+        plan = self._plan
+        dev = self.device
+        cfg = self.config
+        D, H = self.inner_dim, cfg.num_attention_heads
+        B, C_in, R, Hh, Ww = hidden_states.shape
+        T_in = conditioning_tensors.shape[2]
+        Cc = conditioning_tensors.shape[1]
+        Nx, Nc = R * Hh * Ww, T_in * Hh * Ww
+        S = Nx + Nc
+        C_out = cfg.out_channels or cfg.in_channels
+        hidden_states = hidden_states.to(device=dev, dtype=torch.float32).contiguous()
+        conditioning_tensors = conditioning_tensors.to(device=dev, dtype=torch.float32)
+        if conditioning_tensors.shape[0] != B:
+            conditioning_tensors = conditioning_tensors.expand(B, -1, -1, -1, -1)
+        conditioning_tensors = conditioning_tensors.contiguous()
+        timestep = timestep.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        Bt = timestep.shape[0]
+        if Bt not in (1, B):
+            raise ValueError(f"timestep must have 1 or {B} entries, got {Bt}")
+
+        key = (B, Bt, Nx, Nc)
+        if key not in self._ws:
+            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(C_in, Cc), C_out)
+        ws = self._ws[key]
+        pc, ps, cc, cs = self._rope_tables(R, T_in, Hh, Ww, dev)
+        SD = S * D
+        h_x, h_c = ws.h[:, :Nx], ws.h[:, Nx:]
+        nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
+
+        # 1. patch embeds (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
+        hip.chan_to_token(hidden_states, ws.xtok, B=B, C=C_in, N=Nx, ldo=C_in)
+        hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
+        hip.chan_to_token(conditioning_tensors, ws.ctok, B=B, C=Cc, N=Nc, ldo=Cc)
+        hip.gemm(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias)
+
+        # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
+        ref = self.context_refiner
+        hip.timestep_embedding(timestep, ws.tsin, Bt)
+        hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
+        self._combined_embed(ref.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb_r)
+        hip.gemm(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
+        for blk in ref.token_refiner.refiner_blocks:
+            pa = plan.attn[id(blk.attn)]
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps)
+            hip.gemm(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
+            self._attention(ws, B, Nc, Nx, ws.qkv, ws.att[:, Nx:], D, SD)
+            hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
+            hip.gate_residual(h_c, ws.att[:, Nx:], ws.mod_a, h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps)
+            f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
+            F = f0.weight.shape[0]
+            hip.gemm(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
+            hip.gemm(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
+                     gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD)
+
+        # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
+        hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
+        self._combined_embed(self.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb)
+        if time_elapsed is not None and self.time_elapsed_embed is not None:
+            te = self._time_elapsed_embedding(time_elapsed, dev)
+            if te.shape[0] not in (1, B):
+                raise ValueError("time_elapsed must have 1 or batch entries")
+            hip.temb_modulate(ws.temb, te, B=B, D=D, te_rows=te.shape[0])
+
+        # 4. dual-stream blocks, models/LaDCast_3D_model.py:514-566
+        for blk in self.transformer_blocks:
+            pa = plan.attn[id(blk.attn)]
+            mx, mc = ws.mod_a, ws.mod_b
+            hip.linear_small(ws.temb, blk.norm1.linear.weight, mx, rows=B, N=6 * D, K=D, bias=blk.norm1.linear.bias, act_in=hip.ACT_SILU)
+            hip.linear_small(ws.temb, blk.norm1_context.linear.weight, mc, rows=B, N=6 * D, K=D, bias=blk.norm1_context.linear.bias, act_in=hip.ACT_SILU)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=6 * D, mode=0, eps=1e-6)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=6 * D, mode=0, eps=1e-6)
+            hip.gemm(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            hip.gemm(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c)
+            self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
+            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)
+            self._attention(ws, B, S, 0, ws.qkv, ws.att, D, SD)
+            o, oc = blk.attn.to_out[0], blk.attn.to_add_out
+            hip.gemm(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=6 * D, R=h_x, ldr=D, r_bs=SD)
+            hip.gemm(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=6 * D, R=h_c, ldr=D, r_bs=SD)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
+            for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
+                f0, f2 = ff.net[0].proj, ff.net[2]
+                F = f0.weight.shape[0]
+                hid = ws.cat.view(-1)[off * B * F :]  # [B, rows, F] slab inside the concat scratch
+                hip.gemm(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH)
+                hip.gemm(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
+                         gate=mod[:, 5 * D :], gate_bs=6 * D, R=hs, ldr=D, r_bs=SD)
+
+        # 5. single-stream blocks, models/LaDCast_3D_model.py:426-468
+        for blk in self.single_transformer_blocks:
+            pa = plan.attn[id(blk.attn)]
+            mod = ws.mod_a
+            F = blk.proj_mlp.weight.shape[0]
+            W5 = D + F
+            hip.linear_small(ws.temb, blk.norm.linear.weight, mod, rows=B, N=3 * D, K=D, bias=blk.norm.linear.bias, act_in=hip.ACT_SILU)
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=3 * D, mode=0, eps=1e-6)
+            hip.gemm(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH)
+            hip.gemm(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
+            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
+            self._attention(ws, B, S, 0, ws.qkv, ws.cat, W5, S * W5)
+            hip.gemm(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
+                     gate=mod[:, 2 * D :], gate_bs=3 * D, R=ws.h, ldr=D, r_bs=SD)
+
+        # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
+        hip.linear_small(ws.temb, self.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=self.norm_out.linear.bias, act_in=hip.ACT_SILU)
+        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=ws.mod_a, shift=ws.mod_a[:, D:], mod_bs=2 * D, mode=0, eps=1e-7)
+        hip.gemm(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
+        out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
+        hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
+
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)

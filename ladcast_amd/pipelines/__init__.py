@@ -1,0 +1,8 @@
+from .edm_sampler import edm_AR_sampler  # noqa: F401
+from .pipeline_AR import AutoRegressive2DPipeline  # noqa: F401
+from .utils import (  # noqa: F401
+    Fields2DPipelineOutput,
+    decode_latent_ens,
+    ensemble_AR_sampler,
+    roll_out_serial,
+)

@@ -1,0 +1,80 @@
+"""``edm_AR_sampler`` -- deterministic EDM Heun sampler (pipelines/edm_sampler.py:10-120) with
+the fp64 state kept on the device and every update fused into one HIP kernel per half-step.
+
+Per solver step the reference issues ~15 separate fp64 torch ops (clone, scale, cast, c_skip /
+c_out axpy, subtract, divide, axpy ...) around each model call; here a step is
+``ldc_edm_scale_f64_to_f32 -> net -> ldc_edm_euler`` and, for the 2nd-order correction,
+``ldc_edm_scale_f64_to_f32 -> net -> ldc_edm_heun``.  The scalar coefficients are computed on
+the host in fp32 with the scheduler's own expressions and widened to double, so given the
+same network output the state is bit-identical to the reference's.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import torch
+
+from .. import hip
+from .torch_utils import randn_tensor
+
+
+@torch.no_grad()
+def edm_AR_sampler(
+    net,
+    noise_scheduler,
+    batch_size=1,
+    return_seq_len=1,
+    randn_like=torch.randn_like,
+    num_inference_steps=18,
+    S_churn=0,
+    S_min=0,
+    S_max=float("inf"),
+    S_noise=0,
+    deterministic=True,
+    known_latents=None,
+    timestamps: Optional[torch.LongTensor] = None,
+    generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+    device="cpu",
+):
+    if isinstance(generator, list) and len(generator) != batch_size:
+        raise ValueError(
+            f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+            f" size of {batch_size}. Make sure the batch size matches the length of the generators."
+        )
+    assert known_latents is not None, "known_latents must be provided"
+    if not deterministic:
+        raise NotImplementedError("S_churn > 0 is never used by the reference rollout (pipelines/utils.py:716-727)")
+    if isinstance(device, str):
+        device = torch.device(device)
+
+    shape = (batch_size, net.config.out_channels, return_seq_len, *known_latents.shape[-2:])
+    latents = randn_tensor(shape, generator=generator, device=device, dtype=net.dtype).contiguous()
+    noise_scheduler.set_timesteps(num_inference_steps, device=device)
+    t_steps = noise_scheduler.sigmas  # (N+1,) fp32 on the host
+    c_noise = noise_scheduler.precondition_noise(t_steps[:-1]).to(device)  # (N,) fed to the model as (1,) views
+    known = known_latents.to(device)
+    if known.shape[0] != batch_size:
+        known = known.expand(batch_size, *known.shape[1:])
+    known = known.contiguous()
+
+    x_hat = torch.empty(shape, device=device, dtype=torch.float64)
+    x_next = torch.empty_like(x_hat)
+    d_cur = torch.empty_like(x_hat)
+    x_in = torch.empty(shape, device=device, dtype=torch.float32)
+    hip.edm_init_state(latents, float(t_steps[0]), x_next)
+
+    for i in range(num_inference_steps):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_hat, x_next = x_next, x_hat  # x_hat = previous x_next
+        c_skip, c_out = noise_scheduler._c_skip_out(t_cur)
+        hip.edm_scale_f64_to_f32(x_hat, float(noise_scheduler._c_in(t_cur)), x_in)
+        F = net(x_in, c_noise[i : i + 1], known, time_elapsed=timestamps).sample
+        hip.edm_euler(x_hat, F, float(c_skip), float(c_out), float(t_cur), float(t_next - t_cur), x_next, d_cur)
+        if i < num_inference_steps - 1:
+            c_skip, c_out = noise_scheduler._c_skip_out(t_next)
+            hip.edm_scale_f64_to_f32(x_next, float(noise_scheduler._c_in(t_next)), x_in)
+            F = net(x_in, c_noise[i + 1 : i + 2], known, time_elapsed=timestamps).sample
+            hip.edm_heun(x_hat, x_next, F, d_cur, float(c_skip), float(c_out), float(t_next), float(t_next - t_cur))
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    hip.f64_to_f32(x_next, out)
+    return out

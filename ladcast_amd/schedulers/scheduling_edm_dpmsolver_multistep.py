@@ -1,0 +1,209 @@
+"""``EDMDPMSolverMultistepScheduler`` with the diffusers (v0.32.1) surface the reference uses.
+
+The reference builds ``diffusers.EDMDPMSolverMultistepScheduler`` with default kwargs
+(evaluate/pred_rollout.py:49-52,333 -- the ``"param"`` typo drops its kwargs) and calls
+``set_timesteps / sigmas / timesteps / precondition_* / scale_model_input / step``
+(pipelines/edm_sampler.py:56-58,81-91; pipelines/pipeline_AR.py:85-102).
+
+Split of work: the schedule (Karras sigmas, step indices, the per-step scalar coefficients)
+is host arithmetic on fp32 torch CPU scalars, exactly where diffusers computes it, so the
+indexing is bit-exact; every whole-tensor update runs in a HIP kernel
+(``ldc_scale_f32`` / ``ldc_axpby_f32`` / ``ldc_dpm_step``).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from .. import hip
+
+
+class EDMDPMSolverMultistepScheduler:
+    order = 1
+
+    def __init__(
+        self,
+        sigma_min: float = 0.002,
+        sigma_max: float = 80.0,
+        sigma_data: float = 0.5,
+        sigma_schedule: str = "karras",
+        num_train_timesteps: int = 1000,
+        prediction_type: str = "epsilon",
+        rho: float = 7.0,
+        solver_order: int = 2,
+        thresholding: bool = False,
+        dynamic_thresholding_ratio: float = 0.995,
+        sample_max_value: float = 1.0,
+        algorithm_type: str = "dpmsolver++",
+        solver_type: str = "midpoint",
+        lower_order_final: bool = True,
+        euler_at_final: bool = False,
+        final_sigmas_type: str = "zero",
+    ):
+        if sigma_schedule != "karras":
+            raise NotImplementedError("only sigma_schedule='karras' (the default the reference runs with)")
+        if algorithm_type != "dpmsolver++" or solver_type != "midpoint" or solver_order not in (1, 2):
+            raise NotImplementedError("only dpmsolver++ / midpoint / order <= 2 (the defaults the reference runs with)")
+        if thresholding:
+            raise NotImplementedError("thresholding is off on the reference path")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"Prediction type {prediction_type} is not supported")
+        if final_sigmas_type not in ("zero", "sigma_min"):
+            raise ValueError(f"`final_sigmas_type` must be one of 'zero', or 'sigma_min', but got {final_sigmas_type}")
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k != "self"})
+        ramp = torch.linspace(0, 1, num_train_timesteps)
+        sigmas = self._compute_karras_sigmas(ramp)
+        self.timesteps = self.precondition_noise(sigmas)
+        self.sigmas = torch.cat([sigmas, torch.zeros(1)]).to("cpu")
+        self.num_inference_steps = None
+        self.model_outputs = [None] * solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+        self._begin_index = None
+
+    # -- schedule (host) ---------------------------------------------------------------------
+    def _compute_karras_sigmas(self, ramp):
+        c = self.config
+        lo, hi = c.sigma_min ** (1 / c.rho), c.sigma_max ** (1 / c.rho)
+        return (hi + ramp * (lo - hi)) ** c.rho
+
+    @property
+    def init_noise_sigma(self):
+        return (self.config.sigma_max**2 + 1) ** 0.5
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    def set_timesteps(self, num_inference_steps: int = None, device=None):
+        self.num_inference_steps = num_inference_steps
+        sigmas = self._compute_karras_sigmas(torch.linspace(0, 1, num_inference_steps)).to(torch.float32)
+        last = self.config.sigma_min if self.config.final_sigmas_type == "sigma_min" else 0
+        self.sigmas = torch.cat([sigmas, torch.tensor([last], dtype=torch.float32)])  # lives on the host, as in diffusers
+        self.timesteps = self.precondition_noise(sigmas)  # host copy drives the loop ...
+        self._timesteps_dev = self.timesteps.to(device) if device is not None else None  # ... device copy feeds the model
+        self.model_outputs = [None] * self.config.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+        self._begin_index = None
+
+    # -- EDM preconditioning: scalar coefficients on the host, tensors on the device --------------
+    def _c_in(self, sigma):
+        return 1 / ((sigma**2 + self.config.sigma_data**2) ** 0.5)
+
+    def _c_skip_out(self, sigma):
+        sd = self.config.sigma_data
+        c_skip = sd**2 / (sigma**2 + sd**2)
+        c_out = sigma * sd / (sigma**2 + sd**2) ** 0.5
+        if self.config.prediction_type == "v_prediction":
+            c_out = -c_out
+        return c_skip, c_out
+
+    def precondition_noise(self, sigma):
+        if not isinstance(sigma, torch.Tensor):
+            sigma = torch.tensor([sigma])
+        return 0.25 * torch.log(sigma)
+
+    def precondition_inputs(self, sample, sigma):
+        out = torch.empty_like(sample)
+        hip.scale_f32(_f32_dev(sample), float(self._c_in(_host_scalar(sigma))), out)
+        return out
+
+    def precondition_outputs(self, sample, model_output, sigma):
+        c_skip, c_out = self._c_skip_out(_host_scalar(sigma))
+        out = torch.empty_like(sample)
+        hip.axpby_f32(_f32_dev(sample), float(c_skip), _f32_dev(model_output), float(c_out), out)
+        return out
+
+    # -- stepping ------------------------------------------------------------------------------
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        if schedule_timesteps is None:
+            schedule_timesteps = self.timesteps
+        if isinstance(timestep, torch.Tensor):
+            timestep = timestep.to(schedule_timesteps.device)
+        cand = (schedule_timesteps == timestep).nonzero()
+        if len(cand) == 0:
+            return len(self.timesteps) - 1
+        if len(cand) > 1:
+            return cand[1].item()
+        return cand[0].item()
+
+    def _init_step_index(self, timestep):
+        if self._begin_index is None:
+            self._step_index = self.index_for_timestep(timestep)
+        else:
+            self._step_index = self._begin_index
+
+    def scale_model_input(self, sample, timestep):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        return self.precondition_inputs(sample, self.sigmas[self._step_index])
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        c = self.config
+        i, n = self._step_index, len(self.timesteps)
+        lower_order_final = (i == n - 1) and (c.euler_at_final or (c.lower_order_final and n < 15) or c.final_sigmas_type == "zero")
+        first_order = c.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final
+        # host scalars, fp32, same expressions as diffusers' dpm_solver_first_order_update /
+        # multistep_dpm_solver_second_order_update with alpha_t == 1
+        sigma_t, sigma_s0 = self.sigmas[i + 1], self.sigmas[i]
+        c_skip, c_out = self._c_skip_out(sigma_s0)
+        lam_t, lam_s0 = -torch.log(sigma_t), -torch.log(sigma_s0)
+        h = lam_t - lam_s0
+        a = sigma_t / sigma_s0
+        b = torch.exp(-h) - 1.0
+        inv_r0 = 0.0
+        if not first_order:
+            lam_s1 = -torch.log(self.sigmas[i - 1])
+            r0 = (lam_s0 - lam_s1) / h
+            inv_r0 = float(1.0 / r0)
+        sample = _f32_dev(sample)
+        x0 = torch.empty_like(sample)
+        prev = torch.empty_like(sample)
+        m1 = self.model_outputs[-1]  # previous x0 prediction (becomes m1 once the new one is pushed)
+        hip.dpm_step(sample, _f32_dev(model_output), None if first_order else m1, x0, prev, float(c_skip), float(c_out), float(a), float(b),
+                     inv_r0, 1 if first_order else 2)
+        for j in range(c.solver_order - 1):
+            self.model_outputs[j] = self.model_outputs[j + 1]
+        self.model_outputs[-1] = x0
+        if self.lower_order_nums < c.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        if not return_dict:
+            return (prev,)
+        return SimpleNamespace(prev_sample=prev)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """x0 + sigma(t) * noise, one sigma per sample (train_AR.py:911; not on the inference path)."""
+        out = torch.empty_like(original_samples)
+        for j, t in enumerate(timesteps):
+            sigma = float(self.sigmas[self.index_for_timestep(t.cpu(), self.timesteps.cpu())])
+            hip.axpby_f32(_f32_dev(original_samples[j]), 1.0, _f32_dev(noise[j]), sigma, out[j])
+        return out
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+def _host_scalar(sigma):
+    if isinstance(sigma, torch.Tensor):
+        return sigma.detach().to("cpu", torch.float32).reshape(())
+    return torch.tensor(float(sigma), dtype=torch.float32)
+
+
+def _f32_dev(t):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError("scheduler tensor ops run in HIP kernels: need a contiguous fp32 device tensor")
+    return t

@@ -1,0 +1,226 @@
+"""Parity of every C-ABI kernel against a CPU restatement on the same seeded inputs.
+All calls go through the C ABI (ladcast_amd.hip -> libladcast_hip.so)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import layers as L  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    import ladcast_amd.hip as h
+
+    return h
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize(
+    "M,N,K,batch",
+    [(128, 128, 32, 1), (2250, 1536, 1536, 1), (450, 84, 1536, 2), (1800, 1536, 84, 1), (37, 200, 260, 3), (2250, 1536, 7680, 1), (1, 5, 4, 1)],
+)
+def test_gemm_plain(hip, M, N, K, batch):
+    A, W, b = rnd(batch, M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    C = torch.full((batch, M, N), float("nan"), device="cuda")
+    hip.gemm(dev(A), dev(W), C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b))
+    want = A.double() @ W.double().T + b.double()
+    assert rel(C, want) < 2e-6
+    assert torch.isfinite(C).all()
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogue_and_strides(hip, act):
+    """bias + act + per-batch gate + residual, written in place into a strided slab of a wider buffer"""
+    B, M, N, K, LDC = 2, 300, 260, 132, 520
+    A, W, b = rnd(B, M + 7, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    gate, buf = rnd(B, 3 * N, seed=4), rnd(B, M, LDC, seed=5)
+    d_buf = dev(buf)
+    Cv = d_buf[:, :, 100:]
+    hip.gemm(dev(A), dev(W), Cv, M=M, N=N, K=K, batch=B, a_bs=(M + 7) * K, ldc=LDC, c_bs=M * LDC, bias=dev(b),
+             gate=dev(gate)[:, N:], gate_bs=3 * N, R=Cv, ldr=LDC, r_bs=M * LDC, act=act)
+    v = A[:, :M].double() @ W.double().T + b.double()
+    v = [v, F.silu(v), F.gelu(v, approximate="tanh"), F.relu(v)][act]
+    want = buf.clone().double()
+    want[:, :, 100 : 100 + N] = buf[:, :, 100 : 100 + N].double() + v * gate[:, None, N : 2 * N].double()
+    assert rel(d_buf, want) < 2e-6
+    assert torch.equal(d_buf[:, :, :100].cpu(), buf[:, :, :100])  # untouched columns
+
+
+def test_gemm_rejects_bad_arguments(hip):
+    a = torch.zeros(8, 6, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip.gemm(a, a, a, M=8, N=8, K=6)  # K % 4 != 0
+    with pytest.raises(RuntimeError):
+        hip.gemm(torch.zeros(4, 4), a, a, M=4, N=4, K=4)  # host tensor
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1)])
+def test_attention(hip, B, S, H):
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 2.0  # wider logits than unit variance
+    d_qkv = dev(qkv)
+    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D,
+                 ldo=D + 64, o_bs=S * (D + 64))
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+    assert rel(out[:, :, :D], want) < 2e-6
+    assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
+
+
+def test_attention_online_softmax_rescale_branch(hip):
+    """Force the running max to jump at a late key tile (a spiked key row) and force early tiles to be
+    negligible: exercises the O/l rescale path and the skip-rescale fast path (guide rule 26)."""
+    S, H = 200, 1
+    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
+    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0  # key 150 aligned with query 7
+    d_qkv = dev(qkv)
+    out = torch.empty(1, S, 128, device="cuda")
+    hip.attn_fwd(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], out, B=1, S=S, H=H, ld_qkv=384, qkv_bs=S * 384, ldo=128, o_bs=S * 128)
+    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
+    assert rel(out, want) < 2e-6
+    assert rel(out[0, 7], want[0, 7]) < 2e-6
+
+
+def test_qk_rmsnorm_rope(hip):
+    B, Nx, Nc, H = 2, 37, 11, 3
+    D, S = H * 128, 48
+    qkv = rnd(B, S, 3 * D, seed=1)
+    wq, wk = 1 + 0.1 * rnd(128, seed=2), 1 + 0.1 * rnd(128, seed=3)
+    cos, sin = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
+    d = dev(qkv.clone())
+    hip.qk_rmsnorm_rope(d[:, :, :D], d[:, :, D : 2 * D], B=B, row0=0, rows=Nx, H=H, ld=3 * D, bs=S * 3 * D, wq=dev(wq), wk=dev(wk), eps=1e-7,
+                        cos=dev(cos), sin=dev(sin))
+    hip.qk_rmsnorm_rope(d[:, :, :D], d[:, :, D : 2 * D], B=B, row0=Nx, rows=Nc, H=H, ld=3 * D, bs=S * 3 * D, wq=dev(wk), wk=dev(wq), eps=1e-7)
+    nq, nk = L.RMSNorm(128, 1e-7), L.RMSNorm(128, 1e-7)
+    nq.weight.data, nk.weight.data = wq, wk
+    want = qkv.clone()
+    with torch.no_grad():
+        for j, (norm_a, norm_b) in enumerate([(nq, nk), (nk, nq)]):  # j=0 -> q columns, j=1 -> k columns
+            x = qkv[:, :, j * D : (j + 1) * D].reshape(B, S, H, 128).transpose(1, 2)
+            a = L.apply_rotary_emb(norm_a(x[:, :, :Nx]), (cos, sin))
+            b = norm_b(x[:, :, Nx:])
+            want[:, :, j * D : (j + 1) * D] = torch.cat([a, b], dim=2).transpose(1, 2).reshape(B, S, D)
+    assert rel(d, want) < 1e-6
+    assert torch.equal(d[:, :, 2 * D :].cpu(), qkv[:, :, 2 * D :])  # v untouched
+
+
+@pytest.mark.parametrize("D", [1536, 2048, 256])
+def test_layernorm_mod(hip, D):
+    B, rows = 2, 53
+    x = rnd(B, rows + 3, D, seed=1) * 3 + 0.5
+    mod = rnd(B, 3 * D, seed=2) * 0.3
+    y = torch.empty(B, rows, D, device="cuda")
+    hip.layernorm_mod(dev(x), y, B=B, rows=rows, D=D, ldx=D, x_bs=(rows + 3) * D, ldy=D, y_bs=rows * D, scale=dev(mod)[:, D:], shift=dev(mod),
+                      mod_bs=3 * D, mode=0, eps=1e-6)
+    want = F.layer_norm(x[:, :rows].double(), (D,), eps=1e-6) * (1 + mod[:, None, D : 2 * D].double()) + mod[:, None, :D].double()
+    assert rel(y, want) < 1e-6
+    w, b = rnd(D, seed=3), rnd(D, seed=4)
+    hip.layernorm_mod(dev(x), y, B=B, rows=rows, D=D, ldx=D, x_bs=(rows + 3) * D, ldy=D, y_bs=rows * D, scale=dev(w), shift=dev(b), mode=1, eps=1e-7)
+    assert rel(y, F.layer_norm(x[:, :rows].double(), (D,), w.double(), b.double(), eps=1e-7)) < 1e-6
+
+
+def test_small_row_ops(hip):
+    B, rows, D = 3, 450, 1536
+    x = rnd(B, rows, D, seed=1)
+    y = torch.empty(B, D, device="cuda")
+    hip.mean_rows(dev(x), y, B=B, rows=rows, D=D, ldx=D, x_bs=rows * D)
+    assert rel(y, x.double().mean(dim=1)) < 1e-6
+    g, a = rnd(B, 2 * D, seed=2), rnd(B, rows, D, seed=3)
+    out = dev(x.clone())
+    hip.gate_residual(out, dev(a), dev(g)[:, D:], out, B=B, rows=rows, D=D, ld_res=D, res_bs=rows * D, ld_y=D, y_bs=rows * D, gate_bs=2 * D)
+    assert rel(out, x.double() + a.double() * g[:, None, D:].double()) < 1e-6
+
+
+@pytest.mark.parametrize("rows,x_rows,add_rows", [(1, 1, 1), (3, 3, 1), (11, 1, 11), (64, 64, 64)])
+def test_linear_small(hip, rows, x_rows, add_rows):
+    N, K = 300, 256
+    x, W, b, add = rnd(x_rows, K, seed=1), rnd(N, K, seed=2) / 16, rnd(N, seed=3), rnd(add_rows, N, seed=4)
+    y = torch.empty(rows, N, device="cuda")
+    hip.linear_small(dev(x), dev(W), y, rows=rows, N=N, K=K, x_rows=x_rows, bias=dev(b), add=dev(add), add_rows=add_rows, act_in=1, act_out=1)
+    xi = F.silu(x.double())[torch.arange(rows) % x_rows]
+    want = F.silu(xi @ W.double().T + b.double()) + add.double()[torch.arange(rows) % add_rows]
+    assert rel(y, want) < 1e-6
+
+
+def test_layout_and_embedding_kernels(hip):
+    B, C, N = 2, 84, 1800
+    x = rnd(B, C, N, seed=1)
+    tok = torch.full((B, N, 96), float("nan"), device="cuda")
+    hip.chan_to_token(dev(x), tok, B=B, C=C, N=N, ldo=96)
+    assert torch.equal(tok[:, :, :C].cpu(), x.transpose(1, 2))
+    assert (tok[:, :, C:] == 0).all()
+    back = torch.empty(B, C, N, device="cuda")
+    hip.token_to_chan(tok, back, B=B, C=C, N=N, ldi=96)
+    assert torch.equal(back.cpu(), x)
+    t = torch.tensor([1.0955067, -1.553652, 0.0])
+    e = torch.empty(3, 256, device="cuda")
+    hip.timestep_embedding(dev(t), e, 3)
+    assert (e.cpu() - L.get_timestep_embedding(t, 256)).abs().max() < 2e-6
+    temb, te = rnd(4, 512, seed=2), rnd(1, 1024, seed=3)
+    d = dev(temb.clone())
+    hip.temb_modulate(d, dev(te), B=4, D=512, te_rows=1)
+    assert rel(d, temb * (1 + te[:, :512]) + te[:, 512:]) < 1e-6
+    lat, mu, sd = rnd(3, 84, 4, 15, 30, seed=4), rnd(84, seed=5), rnd(84, seed=6).abs() + 0.3
+    y = torch.empty(3, 84, 4, 15, 30, device="cuda")
+    hip.chan_affine(dev(lat), y, dev(mu), dev(sd), 0.5, outer=3, C=84, inner=4 * 450, inverse=False)
+    want = (lat - mu[None, :, None, None, None]) / sd[None, :, None, None, None] * 0.5
+    assert torch.equal(y.cpu(), want)
+    z = torch.empty_like(y)
+    hip.chan_affine(y, z, dev(mu), dev(sd), 0.5, outer=3, C=84, inner=4 * 450, inverse=True)
+    assert torch.equal(z.cpu(), (want / 0.5) * sd[None, :, None, None, None] + mu[None, :, None, None, None])
+
+
+def test_sampler_state_kernels_are_bit_exact(hip):
+    """fp64 Heun state and fp32 DPM++ updates reproduce torch's elementwise rounding exactly."""
+    n = 84 * 4 * 450
+    noise, Fm = rnd(n, seed=1), rnd(n, seed=2)
+    s0, s1 = torch.tensor(79.999985, dtype=torch.float32), torch.tensor(59.657501, dtype=torch.float32)
+    sd = 0.5
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    hip.edm_init_state(dev(noise), float(s0), x)
+    x_ref = noise.double() * s0
+    assert torch.equal(x.cpu(), x_ref)
+    c_in = 1 / ((s0**2 + sd**2) ** 0.5)
+    xin = torch.empty(n, device="cuda")
+    hip.edm_scale_f64_to_f32(x, float(c_in), xin)
+    assert torch.equal(xin.cpu(), (x_ref * c_in).float())
+    c_skip, c_out = sd**2 / (s0**2 + sd**2), s0 * sd / (s0**2 + sd**2) ** 0.5
+    xn, dc = torch.empty_like(x), torch.empty_like(x)
+    hip.edm_euler(x, dev(Fm), float(c_skip), float(c_out), float(s0), float(s1 - s0), xn, dc)
+    den = c_skip * x_ref + c_out * Fm.double()
+    d_ref = (x_ref - den) / s0
+    xn_ref = x_ref + (s1 - s0) * d_ref
+    assert torch.equal(dc.cpu(), d_ref) and torch.equal(xn.cpu(), xn_ref)
+    c_skip1, c_out1 = sd**2 / (s1**2 + sd**2), s1 * sd / (s1**2 + sd**2) ** 0.5
+    hip.edm_heun(x, xn, dev(Fm), dc, float(c_skip1), float(c_out1), float(s1), float(s1 - s0))
+    den = c_skip1 * xn_ref + c_out1 * Fm.double()
+    dp = (xn_ref - den) / s1
+    assert torch.equal(xn.cpu(), x_ref + (s1 - s0) * (0.5 * d_ref + 0.5 * dp))
+    # DPM-Solver++ (2M) update in fp32
+    smp, m1 = rnd(n, seed=3), rnd(n, seed=4)
+    x0, prev = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    a, b, inv_r0 = torch.tensor(0.7457), torch.tensor(-0.2543), torch.tensor(1.25)
+    hip.dpm_step(dev(smp), dev(Fm), dev(m1), x0, prev, float(c_skip), float(c_out), float(a), float(b), float(inv_r0), 2)
+    m0 = c_skip * smp + c_out * Fm
+    want = a * smp - b * m0 - (0.5 * b) * (inv_r0 * (m0 - m1))
+    assert torch.equal(x0.cpu(), m0) and torch.equal(prev.cpu(), want)
