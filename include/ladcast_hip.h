@@ -115,8 +115,9 @@ int ldc_gate_residual(const float* resid, const float* y, const float* gate, flo
 /* Layout changes between the reference's channel-major latents (B, C, T*H*W) and
  * token-major (B, T*H*W, ld) (models/embeddings.py:56-59 flatten/transpose and
  * models/LaDCast_3D_model.py:1047-1062 un-patchify; also NCHW <-> NHWC for the DCAE).
- * Columns [C, ldo) of the token-major output are zero-filled. */
-int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, void* stream);
+ * Columns [C, fill_cols) of the token-major output are zero-filled (fill_cols <= ldo; lets two
+ * calls concatenate channels into one padded row). */
+int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols, void* stream);
 int ldc_token_to_chan(const float* in, float* out, int B, int C, int N, int ldi, void* stream);
 
 /* Sinusoidal timestep embedding [cos | sin], 256 wide (diffusers Timesteps(256,
@@ -156,6 +157,43 @@ int ldc_scale_f32(const float* x, float s, float* y, long long n, void* stream);
 /* out = a*x + b*y (fp32): scheduler.precondition_outputs (c_skip*sample + c_out*F) and
  * add_noise (x0 + sigma*noise) on whole tensors */
 int ldc_axpby_f32(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * DCAE encoder / decoder (models/DCAE.py, models/sphere_conv.py) in NHWC layout
+ * ([B][H][W][C], channel stride 1, pixel stride ld*).
+ * ------------------------------------------------------------------------- */
+/* Dense SphereConv2d (stride 1, ksize 3 or 5, even W) as an implicit GEMM on the fp32 MFMA:
+ *   Y[pix][co] = act(bias[co] + sum_{ky,kx,ci} Wt[co][(ky*ks+kx)*cin + ci] * X[src(pix,ky,kx)][ci]) (+ R[pix][co])
+ * with the reference's pole padding / kernel-row flip (models/sphere_conv.py:62-129,174-192).
+ * Wt is the conv weight repacked [cout][ks*ks][cin] (cin % 4 == 0, zero-padded if needed). */
+int ldc_sphere_conv_nhwc(const float* X, const float* Wt, const float* bias, const float* R, float* Y, int B,
+                         int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act,
+                         void* stream);
+/* Depthwise SphereConv2d, weights [ks*ks][C]; glu != 0: y[c] = d[c] * silu(d[c + C/2]) for c < C/2
+ * (GLUMBConv conv_depth + gate, models/DCAE.py:287-295,311-313; multiscale proj_in, :77-85). */
+int ldc_sphere_dwconv_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                           int C, int ldx, int ldy, int ksize, int glu, void* stream);
+/* Grouped 1x1 conv with 32 channels per group, weights [groups*32][32] (models/DCAE.py:86-88). */
+int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* y, long long M, int groups, int ldx, int ldy,
+                             void* stream);
+/* ReLU linear attention over consecutive 96-channel groups (q|k|v = 32|32|32) of qkv[B][P][ldq];
+ * y[B][P][groups*32] (models/DCAE.py:158-175,239-253; fp32, eps 1e-15). */
+int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
+                              void* stream);
+/* y = act(RMSNorm_C(x) * w + b (+ resid)) per pixel row (models/DCAE.py:259-260,317-322,371-377,729-730). */
+int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y, long long rows,
+                     int C, int ldx, int ldr, int ldy, float eps, int act, void* stream);
+/* DCDownBlock2d tail: pixel_unshuffle(cv) + channel-group-mean(pixel_unshuffle(x)) (models/DCAE.py:477-490).
+ * cv: [B][2*H2][2*W2][cout/4], x: [B][2*H2][2*W2][cin], y: [B][H2][W2][cout]. */
+int ldc_pixel_unshuffle_shortcut(const float* cv, const float* x, float* y, int B, int H2, int W2, int cout, int cin,
+                                 void* stream);
+/* DCUpBlock2d tail: pixel_shuffle(cv) + pixel_shuffle(repeat_interleave(x)) (models/DCAE.py:526-532).
+ * cv: [B][H][W][4*cout], x: [B][H][W][cin], y: [B][2H][2W][cout]. */
+int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B, int H, int W, int cout, int cin,
+                               void* stream);
+/* Channel regroup of [M][cin] -> [M][cout]: group mean (cin > cout; encoder out shortcut, models/DCAE.py:624-627)
+ * or repeat_interleave (cin < cout; decoder in shortcut, :720-722). */
+int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, void* stream);
 
 #ifdef __cplusplus
 }

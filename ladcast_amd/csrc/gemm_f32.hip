@@ -31,8 +31,33 @@ struct GemmArgs {
   const float* R;
   float* C;
   ldc_gemm_desc d;
+  // implicit-GEMM sphere convolution (CONV = true): A is an NHWC image [B][H][W][lda], M = B*H*W,
+  // the reduction runs over ks*ks taps x cin channels, W is [N][ks*ks*cin] (tap-major, channel-minor)
+  int cH, cW, cin, ks;
 };
 
+// Source pixel of tap (ky, kx) for output pixel (h, w) under SphereConv2d's padding and pole rule
+// (models/sphere_conv.py:62-129,174-192): rows beyond a pole are the first/last p rows mirrored and
+// rolled by W/2; columns wrap; output row 0 (H-1) sees the first (last) p kernel rows flipped
+// horizontally, which equals gathering the mirrored column with the unflipped weight.
+__device__ __forceinline__ int sphere_src_pixel(int h, int w, int ky, int kx, int H, int W, int ks) {
+  const int p = ks >> 1;
+  if ((h == 0 && ky < p) || (h == H - 1 && ky >= ks - p)) kx = ks - 1 - kx;
+  int r = h + ky - p;
+  int c = w + kx - p;
+  if (r < 0) {
+    r = -1 - r;
+    c -= W >> 1;
+  } else if (r >= H) {
+    r = 2 * H - 1 - r;
+    c -= W >> 1;
+  }
+  c %= W;
+  if (c < 0) c += W;
+  return r * W + c;
+}
+
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -51,18 +76,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(GemmArgs p) {
   const int r0 = tid >> 3;
   float4 ra[4], rb[4];
 
-  auto gload = [&](int k0) {
-    const int kk = k0 + c4 * 4;
-    const bool kin = kk < K;
+  // CONV: per staged row, its image base pixel index and (h, w); k-tiles never straddle a tap
+  int pix_b[4], pix_h[4], pix_w[4];
+  int ktpt = 1;  // k-tiles per tap
+  if constexpr (CONV) {
+    ktpt = (p.cin + BK - 1) / BK;
+    const int hw = p.cH * p.cW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = r0 + 32 * i;
-      const int gm = bm * BM + row;
-      const int gn = bn * BN + row;
-      ra[i] = (kin && gm < M) ? *reinterpret_cast<const float4*>(A + static_cast<long long>(gm) * lda + kk)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4*>(W + static_cast<long long>(gn) * ldw + kk)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gm = bm * BM + r0 + 32 * i;
+      const int gmc = gm < M ? gm : 0;
+      const int bimg = gmc / hw;
+      const int rem = gmc - bimg * hw;
+      pix_b[i] = bimg * hw;
+      pix_h[i] = rem / p.cW;
+      pix_w[i] = rem - pix_h[i] * p.cW;
+    }
+  }
+
+  auto gload = [&](int kt) {
+    if constexpr (CONV) {
+      const int tap = kt / ktpt;
+      const int kc = (kt - tap * ktpt) * BK + c4 * 4;  // channel offset inside the tap
+      const bool kin = kc < p.cin;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const int kw = tap * p.cin + kc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 32 * i;
+        const int gm = bm * BM + row;
+        const int gn = bn * BN + row;
+        const int src = pix_b[i] + sphere_src_pixel(pix_h[i], pix_w[i], ky, kx, p.cH, p.cW, p.ks);
+        ra[i] = (kin && gm < M) ? *reinterpret_cast<const float4*>(A + static_cast<long long>(src) * lda + kc)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4*>(W + static_cast<long long>(gn) * ldw + kw)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int kk = kt * BK + c4 * 4;
+      const bool kin = kk < K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 32 * i;
+        const int gm = bm * BM + row;
+        const int gn = bn * BN + row;
+        ra[i] = (kin && gm < M) ? *reinterpret_cast<const float4*>(A + static_cast<long long>(gm) * lda + kk)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4*>(W + static_cast<long long>(gn) * ldw + kk)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto sstore = [&](int stage) {
@@ -84,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = CONV ? ktpt * p.ks * p.ks : (K + BK - 1) / BK;
   gload(0);
   sstore(0);
   __syncthreads();
@@ -93,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(GemmArgs p) {
   const int frag_k = (lane >> 5) * 4;
 
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) gload(kt + 1);
     const float* As = smem + (kt & 1) * STAGE_FLOATS;
     const float* Bs = As + BM * LDP;
     const float* a_base = As + (wm * 64 + frag_row) * LDP + frag_k;
@@ -161,15 +223,53 @@ extern "C" int ldc_gemm_bias_act(const float* A, const float* W, const float* bi
   if ((d->K & 3) || (d->lda & 3) || (d->ldw & 3) || (d->a_bs & 3)) return LDC_ERR_ALIGN;
   if (d->act < LDC_ACT_NONE || d->act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
   if (d->batch > 65535 || ldc_cdiv(d->M, BM) > 65535) return LDC_ERR_UNSUPPORTED;
-  GemmArgs p{A, W, bias, gate, R, C, *d};
+  GemmArgs p{A, W, bias, gate, R, C, *d, 0, 0, 0, 0};
   dim3 grid(ldc_cdiv(d->N, BN), ldc_cdiv(d->M, BM), d->batch);
   const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_sphere_conv_nhwc(const float* X, const float* Wt, const float* bias, const float* R, float* Y,
+                                    int B, int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize,
+                                    int act, void* stream) {
+  LDC_CHECK_PTR(X);
+  LDC_CHECK_PTR(Wt);
+  LDC_CHECK_PTR(Y);
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
+  if (ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
+  if ((W & 1) || H < 2 || H < ksize / 2) return LDC_ERR_UNSUPPORTED;  // reference asserts even width
+  LDC_CHECK_ALIGN16(X);
+  LDC_CHECK_ALIGN16(Wt);
+  if ((cin & 3) || (ldx & 3) || ldx < cin || ldy < cout) return LDC_ERR_ALIGN;
+  if (act < LDC_ACT_NONE || act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
+  const long long M = static_cast<long long>(B) * H * W;
+  if (M > 0x7fffffffLL || ldc_cdiv(M, BM) > 65535) return LDC_ERR_UNSUPPORTED;
+  ldc_gemm_desc d{};
+  d.M = static_cast<int>(M);
+  d.N = cout;
+  d.K = ksize * ksize * cin;
+  d.batch = 1;
+  d.lda = ldx;
+  d.ldw = ksize * ksize * cin;
+  d.ldc = ldy;
+  d.ldr = ldr;
+  d.act = act;
+  GemmArgs p{X, Wt, bias, nullptr, R, Y, d, H, W, cin, ksize};
+  dim3 grid(ldc_cdiv(cout, BN), ldc_cdiv(M, BM), 1);
+  const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }

@@ -7,7 +7,7 @@ namespace {
 // in: (B, C, N) channel-major, out: (B, N, ldo) token-major; 32x32 LDS tile transpose
 // (33-float pitch: conflict-free column reads).  Columns [C, ldo) are zero-filled.
 __global__ __launch_bounds__(256) void chan_to_token_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                            int C, int N, int ldo) {
+                                                            int C, int N, int ldo, int fill) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void chan_to_token_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, c = c0 + tx;
-    if (n < N && c < ldo) ob[static_cast<long long>(n) * ldo + c] = tile[tx][ty + 8 * i];
+    if (n < N && c < fill) ob[static_cast<long long>(n) * ldo + c] = tile[tx][ty + 8 * i];
   }
 }
 
@@ -80,12 +80,14 @@ __global__ void chan_affine_kernel(const float* __restrict__ x, float* __restric
 
 }  // namespace
 
-extern "C" int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, void* stream) {
+extern "C" int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols,
+                                 void* stream) {
   LDC_CHECK_PTR(in);
   LDC_CHECK_PTR(out);
-  if (B <= 0 || C <= 0 || N <= 0 || ldo < C) return LDC_ERR_ARG;
-  dim3 grid(ldc_cdiv(N, 32), ldc_cdiv(ldo, 32), B);
-  hipLaunchKernelGGL(chan_to_token_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, C, N, ldo);
+  if (B <= 0 || C <= 0 || N <= 0 || fill_cols < C || ldo < fill_cols) return LDC_ERR_ARG;
+  dim3 grid(ldc_cdiv(N, 32), ldc_cdiv(fill_cols, 32), B);
+  hipLaunchKernelGGL(chan_to_token_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, C, N, ldo,
+                     fill_cols);
   return ldc_launch_status();
 }
 

@@ -48,7 +48,7 @@ def _load():
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
-        "ldc_chan_to_token": (I, [P, P, I, I, I, I, P]),
+        "ldc_chan_to_token": (I, [P, P, I, I, I, I, I, P]),
         "ldc_token_to_chan": (I, [P, P, I, I, I, I, P]),
         "ldc_timestep_embedding": (I, [P, P, I, P]),
         "ldc_temb_modulate": (I, [P, P, I, I, I, P]),
@@ -61,6 +61,14 @@ def _load():
         "ldc_dpm_step": (I, [P, P, P, P, P, F, F, F, F, F, I, L, P]),
         "ldc_scale_f32": (I, [P, F, P, L, P]),
         "ldc_axpby_f32": (I, [P, F, P, F, P, L, P]),
+        "ldc_sphere_conv_nhwc": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+        "ldc_sphere_dwconv_nhwc": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+        "ldc_grouped_conv1x1_nhwc": (I, [P, P, P, L, I, I, I, P]),
+        "ldc_relu_linear_attn_nhwc": (I, [P, P, I, I, I, I, I, F, P]),
+        "ldc_rmsnorm_rows": (I, [P, P, P, P, P, L, I, I, I, I, F, I, P]),
+        "ldc_pixel_unshuffle_shortcut": (I, [P, P, P, I, I, I, I, I, P]),
+        "ldc_pixel_shuffle_shortcut": (I, [P, P, P, I, I, I, I, I, P]),
+        "ldc_chan_regroup": (I, [P, P, L, I, I, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -139,9 +147,9 @@ def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs
            "ldc_gate_residual")
 
 
-def chan_to_token(x, out, *, B, C, N, ldo):
+def chan_to_token(x, out, *, B, C, N, ldo, fill_cols=None):
     _dev(x, out)
-    _check(lib.ldc_chan_to_token(_p(x), _p(out), B, C, N, ldo, _stream()), "ldc_chan_to_token")
+    _check(lib.ldc_chan_to_token(_p(x), _p(out), B, C, N, ldo, ldo if fill_cols is None else fill_cols, _stream()), "ldc_chan_to_token")
 
 
 def token_to_chan(x, out, *, B, C, N, ldi):
@@ -203,3 +211,48 @@ def scale_f32(x, s, y):
 def axpby_f32(x, a, y, b, out):
     _dev(x, y, out)
     _check(lib.ldc_axpby_f32(_p(x), a, _p(y), b, _p(out), x.numel(), _stream()), "ldc_axpby_f32")
+
+
+# -- DCAE (NHWC) -------------------------------------------------------------------------------
+def sphere_conv_nhwc(X, Wt, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE):
+    _dev(X, Wt, Y, bias, R)
+    _check(lib.ldc_sphere_conv_nhwc(_p(X), _p(Wt), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx if ldx is not None else cin, cout,
+                                    ldy if ldy is not None else cout, ldr, ksize, act, _stream()), "ldc_sphere_conv_nhwc")
+
+
+def sphere_dwconv_nhwc(x, wt, y, *, B, H, W, C, ldx=None, ldy=None, bias=None, ksize=3, glu=False):
+    _dev(x, wt, y, bias)
+    cy = C // 2 if glu else C
+    _check(lib.ldc_sphere_dwconv_nhwc(_p(x), _p(wt), _p(bias), _p(y), B, H, W, C, ldx if ldx is not None else C,
+                                      ldy if ldy is not None else cy, ksize, int(glu), _stream()), "ldc_sphere_dwconv_nhwc")
+
+
+def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
+    _dev(x, wt, y)
+    _check(lib.ldc_grouped_conv1x1_nhwc(_p(x), _p(wt), _p(y), M, groups, ldx, ldy, _stream()), "ldc_grouped_conv1x1_nhwc")
+
+
+def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
+    _dev(qkv, y)
+    _check(lib.ldc_relu_linear_attn_nhwc(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, _stream()), "ldc_relu_linear_attn_nhwc")
+
+
+def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE):
+    _dev(x, w, b, resid, y)
+    _check(lib.ldc_rmsnorm_rows(_p(x), _p(w), _p(b), _p(resid), _p(y), rows, C, ldx if ldx is not None else C,
+                                ldr if ldr is not None else C, ldy if ldy is not None else C, eps, act, _stream()), "ldc_rmsnorm_rows")
+
+
+def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin):
+    _dev(cv, x, y)
+    _check(lib.ldc_pixel_unshuffle_shortcut(_p(cv), _p(x), _p(y), B, H2, W2, cout, cin, _stream()), "ldc_pixel_unshuffle_shortcut")
+
+
+def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin):
+    _dev(cv, x, y)
+    _check(lib.ldc_pixel_shuffle_shortcut(_p(cv), _p(x), _p(y), B, H, W, cout, cin, _stream()), "ldc_pixel_shuffle_shortcut")
+
+
+def chan_regroup(x, y, *, M, cin, cout):
+    _dev(x, y)
+    _check(lib.ldc_chan_regroup(_p(x), _p(y), M, cin, cout, _stream()), "ldc_chan_regroup")

@@ -1,0 +1,396 @@
+"""``AutoencoderDC`` (models/DCAE.py:735-1087) on MI355X HIP kernels, shipped-config path
+(configs/DC_AE_84_pretrain.yaml: ResBlock / EfficientViTBlock stages, rms_norm, pixel-(un)shuffle,
+static conditioning channels, no timestep conditioning).
+
+Same constructor kwargs / ``config`` / parameter names as the reference (a reference safetensors
+file loads strictly) and the same ``encode`` / ``decode`` / ``forward`` signatures and outputs.
+The module tree is a parameter container; all arithmetic is HIP.
+
+MI355X-first layout: the reference is NCHW and pays a ``movedim`` round trip around every channel
+RMSNorm, Linear and attention reshape (models/DCAE.py:222-260,317-319,371-373,729).  Here the
+whole network runs NHWC (``[B*H*W, C]`` rows): 1x1 convs and Linears are plain GEMMs on the fp32
+matrix cores, 3x3 sphere convs are implicit GEMMs with the pole/wrap gather done in the loader,
+channel RMSNorm is a contiguous-row wave reduction, and NCHW appears only at the API boundary.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from .modeling_utils import ModelMixin
+from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_depthwise_weight
+
+
+class EncoderOutput(SimpleNamespace):
+    def __getitem__(self, i):
+        return (self.latent,)[i]
+
+
+class DecoderOutput(SimpleNamespace):
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+# ---------------------------------------------------------------------------
+# parameter containers (attribute names = reference)
+# ---------------------------------------------------------------------------
+class _RMSNormP(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class SanaMultiscaleAttentionProjection(nn.Module):
+    def __init__(self, in_channels, num_attention_heads, kernel_size):
+        super().__init__()
+        ch = 3 * in_channels
+        self.proj_in = SphereConv2d(ch, ch, kernel_size, padding=kernel_size // 2, groups=ch, bias=False)
+        self.proj_out = nn.Conv2d(ch, ch, 1, 1, 0, groups=3 * num_attention_heads, bias=False)
+
+
+class SanaMultiscaleLinearAttention(nn.Module):
+    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15):
+        super().__init__()
+        if attention_head_dim != 32:
+            raise NotImplementedError("the linear-attention kernel is built for attention_head_dim 32")
+        self.eps = eps
+        self.attention_head_dim = attention_head_dim
+        self.heads = int(in_channels // attention_head_dim * mult)
+        inner = self.heads * attention_head_dim
+        self.inner = inner
+        self.to_q = nn.Linear(in_channels, inner, bias=False)
+        self.to_k = nn.Linear(in_channels, inner, bias=False)
+        self.to_v = nn.Linear(in_channels, inner, bias=False)
+        self.to_qkv_multiscale = nn.ModuleList([SanaMultiscaleAttentionProjection(inner, self.heads, ks) for ks in kernel_sizes])
+        self.to_out = nn.Linear(inner * (1 + len(kernel_sizes)), out_channels, bias=False)
+        self.norm_out = _RMSNormP(out_channels, 1e-5)  # diffusers get_normalization("rms_norm") default eps
+        self.processor = None
+
+
+class GLUMBConv(nn.Module):
+    def __init__(self, in_channels, out_channels, expand_ratio=4):
+        super().__init__()
+        hid = int(expand_ratio * in_channels)
+        self.conv_inverted = nn.Conv2d(in_channels, hid * 2, 1, 1, 0)
+        self.conv_depth = SphereConv2d(hid * 2, hid * 2, 3, 1, 1, groups=hid * 2)
+        self.conv_point = nn.Conv2d(hid, out_channels, 1, 1, 0, bias=False)
+        self.norm = _RMSNormP(out_channels, 1e-7)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, act_fn="silu"):
+        super().__init__()
+        self.act = {"silu": hip.ACT_SILU, "relu": hip.ACT_RELU}[act_fn]
+        self.conv1 = SphereConv2d(in_channels, in_channels, 3, 1, 1)
+        self.conv2 = SphereConv2d(in_channels, out_channels, 3, 1, 1, bias=False)
+        self.norm = _RMSNormP(out_channels, 1e-5)
+
+
+class EfficientViTBlock(nn.Module):
+    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,)):
+        super().__init__()
+        self.attn = SanaMultiscaleLinearAttention(in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales)
+        self.conv_out = GLUMBConv(in_channels, in_channels)
+
+
+class DCDownBlock2d(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        assert out_channels % 4 == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv = SphereConv2d(in_channels, out_channels // 4, 3, 1, 1)
+
+
+class DCUpBlock2d(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv = SphereConv2d(in_channels, out_channels * 4, 3, 1, 1)
+
+
+def _get_block(block_type, ch, head_dim, act_fn, multiscales):
+    if block_type == "ResBlock":
+        return ResBlock(ch, ch, act_fn)
+    if block_type == "EfficientViTBlock":
+        return EfficientViTBlock(ch, head_dim, tuple(multiscales))
+    raise ValueError(f"Block with {block_type=} is not supported.")
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales):
+        super().__init__()
+        n = len(block_out_channels)
+        if layers_per_block[0] <= 0:
+            raise NotImplementedError("layers_per_block[0] == 0 variant is not used by any shipped config")
+        self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        self.down_blocks = nn.ModuleList()
+        for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
+            for _ in range(nl):
+                self.down_blocks.append(_get_block(block_type[i], ch, head_dim, "silu", qkv_multiscales[i]))
+            if i < n - 1 and nl > 0:
+                self.down_blocks.append(DCDownBlock2d(ch, block_out_channels[i + 1]))
+        self.conv_out = SphereConv2d(block_out_channels[-1], latent_channels, 3, 1, 1)
+
+
+class Decoder(nn.Module):
+    def __init__(self, out_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu"):
+        super().__init__()
+        n = len(block_out_channels)
+        if layers_per_block[0] <= 0:
+            raise NotImplementedError("layers_per_block[0] == 0 variant is not used by any shipped config")
+        self.conv_in = SphereConv2d(latent_channels, block_out_channels[-1], 3, 1, 1)
+        self.up_blocks = nn.ModuleList()
+        for i, (ch, nl) in reversed(list(enumerate(zip(block_out_channels, layers_per_block)))):
+            if i < n - 1 and nl > 0:
+                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch))
+            for _ in range(nl):
+                self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i]))
+        self.norm_out = _RMSNormP(block_out_channels[0], 1e-7)
+        self.conv_out = SphereConv2d(block_out_channels[0], out_channels, 3, 1, 1)
+
+
+# ---------------------------------------------------------------------------
+class AutoencoderDC(ModelMixin):
+    _supports_gradient_checkpointing = False
+
+    def __init__(
+        self,
+        in_channels: int = 3,
+        out_channels: Optional[int] = None,
+        temb_channels: Optional[int] = None,
+        latent_channels: int = 32,
+        attention_head_dim: int = 32,
+        encoder_block_types: Union[str, Tuple[str]] = "ResBlock",
+        decoder_block_types: Union[str, Tuple[str]] = "ResBlock",
+        encoder_block_out_channels: Tuple[int, ...] = (128, 256, 512, 512, 1024, 1024),
+        decoder_block_out_channels: Tuple[int, ...] = (128, 256, 512, 512, 1024, 1024),
+        encoder_layers_per_block: Tuple[int] = (2, 2, 2, 3, 3, 3),
+        decoder_layers_per_block: Tuple[int] = (3, 3, 3, 3, 3, 3),
+        encoder_qkv_multiscales=((), (), (), (5,), (5,), (5,)),
+        decoder_qkv_multiscales=((), (), (), (5,), (5,), (5,)),
+        upsample_block_type: str = "pixel_shuffle",
+        downsample_block_type: str = "pixel_unshuffle",
+        decoder_norm_types: Union[str, Tuple[str]] = "rms_norm",
+        decoder_act_fns: Union[str, Tuple[str]] = "silu",
+        scaling_factor: float = 1.0,
+        static_channels: int = 0,
+    ) -> None:
+        super().__init__()
+        self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        if temb_channels is not None:
+            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
+        if upsample_block_type != "pixel_shuffle" or downsample_block_type != "pixel_unshuffle":
+            raise NotImplementedError("only pixel_(un)shuffle sampling (configs/DC_AE_84_pretrain.yaml:45-46)")
+        if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
+            raise NotImplementedError("only rms_norm / silu decoders")
+        n = len(encoder_block_out_channels)
+        ebt = (encoder_block_types,) * n if isinstance(encoder_block_types, str) else tuple(encoder_block_types)
+        dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
+        self.encoder = Encoder(in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales)
+        self.decoder = Decoder(out_channels if out_channels is not None else in_channels, latent_channels, attention_head_dim, dbt,
+                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales)
+        self.spatial_compression_ratio = 2 ** (n - 1)
+        self.temporal_compression_ratio = 1
+        self.use_slicing = False
+        self.use_tiling = False
+        self.static_channels = static_channels
+        self.requires_grad_(False)
+        self._plan = None
+
+    def enable_tiling(self, *a, **k):
+        self.use_tiling = True
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    # -- plan: repacked weights (NHWC / tap-major) ------------------------------------------------
+    def _build_plan(self):
+        if self.dtype != torch.float32:
+            raise NotImplementedError("this build computes in fp32; cast the model to float32")
+        if not next(self.parameters()).is_cuda:
+            raise RuntimeError("AutoencoderDC must live on a HIP device (no CPU fallback)")
+        plan = {}
+        for mod in self.modules():
+            if isinstance(mod, SphereConv2d):
+                plan[id(mod)] = pack_dense_weight(mod.weight) if mod.groups == 1 else pack_depthwise_weight(mod.weight)
+            elif isinstance(mod, nn.Conv2d):  # 1x1 convs
+                plan[id(mod)] = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
+            elif isinstance(mod, SanaMultiscaleLinearAttention):
+                plan[id(mod)] = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], dim=0).contiguous()
+        self._plan = plan
+
+    # -- NHWC building blocks ---------------------------------------------------------------------
+    def _conv(self, x, B, H, W, conv, act=hip.ACT_NONE, R=None, ldx=None):
+        cin_p = ceil4(conv.in_channels)
+        y = torch.empty(B * H * W, conv.out_channels, device=x.device, dtype=torch.float32)
+        hip.sphere_conv_nhwc(x, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=ldx if ldx is not None else cin_p,
+                             cout=conv.out_channels, bias=conv.bias, R=R, ldr=conv.out_channels if R is not None else 0, ksize=3, act=act)
+        return y
+
+    def _resblock(self, blk, x, B, H, W):
+        t = self._conv(x, B, H, W, blk.conv1, act=blk.act)
+        u = self._conv(t, B, H, W, blk.conv2)
+        C = blk.conv2.out_channels
+        y = torch.empty_like(u)
+        hip.rmsnorm_rows(u, blk.norm.weight, y, rows=B * H * W, C=C, eps=blk.norm.eps, b=blk.norm.bias, resid=x)
+        return y
+
+    def _evit(self, blk, x, B, H, W):
+        M = B * H * W
+        at = blk.attn
+        C, inner, heads = at.to_q.in_features, at.inner, at.heads
+        dev = x.device
+        n_ms = len(at.to_qkv_multiscale)
+        wide = 3 * inner * (1 + n_ms)
+        qkv = torch.empty(M, wide, device=dev, dtype=torch.float32)
+        hip.gemm(x, self._plan[id(at)], qkv, M=M, N=3 * inner, K=C, ldc=wide)
+        for s, ms in enumerate(at.to_qkv_multiscale):
+            dw = torch.empty(M, 3 * inner, device=dev, dtype=torch.float32)
+            hip.sphere_dwconv_nhwc(qkv, self._plan[id(ms.proj_in)], dw, B=B, H=H, W=W, C=3 * inner, ldx=wide, ksize=ms.proj_in.kernel_size[0])
+            hip.grouped_conv1x1_nhwc(dw, self._plan[id(ms.proj_out)], qkv[:, 3 * inner * (1 + s) :], M=M, groups=3 * heads, ldx=3 * inner, ldy=wide)
+        groups = wide // 96  # consecutive 96-channel groups of the concat, split (q, k, v) -- models/DCAE.py:239-243 (Q8)
+        att = torch.empty(M, groups * 32, device=dev, dtype=torch.float32)
+        hip.relu_linear_attn_nhwc(qkv, att, B=B, P=H * W, groups=groups, ldq=wide, ldy=groups * 32, eps=at.eps)
+        o = torch.empty(M, C, device=dev, dtype=torch.float32)
+        hip.gemm(att, at.to_out.weight, o, M=M, N=C, K=groups * 32)
+        y = torch.empty_like(o)
+        hip.rmsnorm_rows(o, at.norm_out.weight, y, rows=M, C=C, eps=at.norm_out.eps, b=at.norm_out.bias, resid=x)
+        # GLUMBConv, models/DCAE.py:304-324
+        g = blk.conv_out
+        hid2 = g.conv_inverted.out_channels
+        h1 = torch.empty(M, hid2, device=dev, dtype=torch.float32)
+        hip.gemm(y, self._plan[id(g.conv_inverted)], h1, M=M, N=hid2, K=C, bias=g.conv_inverted.bias, act=hip.ACT_SILU)
+        h2 = torch.empty(M, hid2 // 2, device=dev, dtype=torch.float32)
+        hip.sphere_dwconv_nhwc(h1, self._plan[id(g.conv_depth)], h2, B=B, H=H, W=W, C=hid2, bias=g.conv_depth.bias, ksize=3, glu=True)
+        h3 = torch.empty(M, C, device=dev, dtype=torch.float32)
+        hip.gemm(h2, self._plan[id(g.conv_point)], h3, M=M, N=C, K=hid2 // 2)
+        out = torch.empty_like(h3)
+        hip.rmsnorm_rows(h3, g.norm.weight, out, rows=M, C=C, eps=g.norm.eps, b=g.norm.bias, resid=y)
+        return out
+
+    def _run_blocks(self, blocks, x, B, H, W):
+        for blk in blocks:
+            if isinstance(blk, ResBlock):
+                x = self._resblock(blk, x, B, H, W)
+            elif isinstance(blk, EfficientViTBlock):
+                x = self._evit(blk, x, B, H, W)
+            elif isinstance(blk, DCDownBlock2d):
+                cv = self._conv(x, B, H, W, blk.conv)
+                y = torch.empty(B * (H // 2) * (W // 2), blk.out_channels, device=x.device, dtype=torch.float32)
+                hip.pixel_unshuffle_shortcut(cv, x, y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels)
+                x, H, W = y, H // 2, W // 2
+            elif isinstance(blk, DCUpBlock2d):
+                cv = self._conv(x, B, H, W, blk.conv)
+                y = torch.empty(B * 4 * H * W, blk.out_channels, device=x.device, dtype=torch.float32)
+                hip.pixel_shuffle_shortcut(cv, x, y, B=B, H=H, W=W, cout=blk.out_channels, cin=blk.in_channels)
+                x, H, W = y, 2 * H, 2 * W
+            else:
+                raise TypeError(type(blk))
+        return x, H, W
+
+    # -- public API ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x, return_dict: bool = True, temb=None, embedded_t: bool = False, static_conditioning_tensor=None):
+        if temb is not None:
+            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
+        if self.use_slicing and x.shape[0] > 1:
+            raise NotImplementedError("Slicing is not supported for encoding.")
+        if self._plan is None:
+            self._build_plan()
+        dev = self.device
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        B, C, H, W = x.shape
+        if self.use_tiling and (W > 512 or H > 512):
+            raise NotImplementedError("Tiling is not supported for encoding.")
+        enc = self.encoder
+        cs = 0
+        if static_conditioning_tensor is not None:
+            st = static_conditioning_tensor.to(device=dev, dtype=torch.float32)
+            if st.shape[0] != B:
+                st = st.expand(B, -1, -1, -1)
+            st = st.contiguous()
+            cs = st.shape[1]
+        assert C + cs == enc.conv_in.in_channels, "channel count does not match conv_in"
+        cp = ceil4(C + cs)
+        tok = torch.empty(B * H * W, cp, device=dev, dtype=torch.float32)
+        # torch.cat((x, static), dim=1) + NCHW->NHWC in one pass each (models/DCAE.py:988-989)
+        hip.chan_to_token(x, tok, B=B, C=C, N=H * W, ldo=cp, fill_cols=C if cs else cp)
+        if cs:
+            hip.chan_to_token(st, tok[:, C:], B=B, C=cs, N=H * W, ldo=cp, fill_cols=cp - C)
+        h = self._conv(tok, B, H, W, enc.conv_in)
+        h, H, W = self._run_blocks(enc.down_blocks, h, B, H, W)
+        lc = enc.conv_out.out_channels
+        sc = torch.empty(B * H * W, lc, device=dev, dtype=torch.float32)
+        hip.chan_regroup(h, sc, M=B * H * W, cin=enc.conv_out.in_channels, cout=lc)  # out shortcut, :624-627
+        z = self._conv(h, B, H, W, enc.conv_out, R=sc)
+        out = torch.empty(B, lc, H, W, device=dev, dtype=torch.float32)
+        hip.token_to_chan(z, out, B=B, C=lc, N=H * W, ldi=lc)
+        if not return_dict:
+            return (out,)
+        return EncoderOutput(latent=out)
+
+    @torch.no_grad()
+    def decode(self, z, return_dict: bool = True, temb=None, embedded_t: bool = False, return_static=False):
+        if temb is not None:
+            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
+        if self.use_slicing and z.size(0) > 1:
+            raise NotImplementedError("Slicing is not supported for decoding.")
+        if self._plan is None:
+            self._build_plan()
+        dev = self.device
+        z = z.to(device=dev, dtype=torch.float32).contiguous()
+        B, C, H, W = z.shape
+        if self.use_tiling and (W > 512 // self.spatial_compression_ratio or H > 512 // self.spatial_compression_ratio):
+            raise NotImplementedError("Tiling is not supported for decoding.")
+        dec = self.decoder
+        if C % 4:
+            raise NotImplementedError("latent_channels must be a multiple of 4")
+        tok = torch.empty(B * H * W, C, device=dev, dtype=torch.float32)
+        hip.chan_to_token(z, tok, B=B, C=C, N=H * W, ldo=C)
+        c0 = dec.conv_in.out_channels
+        rep = torch.empty(B * H * W, c0, device=dev, dtype=torch.float32)
+        hip.chan_regroup(tok, rep, M=B * H * W, cin=C, cout=c0)
+        h = self._conv(tok, B, H, W, dec.conv_in, R=rep)  # in shortcut = repeat_interleave, :720-722
+        h, H, W = self._run_blocks(dec.up_blocks, h, B, H, W)
+        n = torch.empty_like(h)
+        hip.rmsnorm_rows(h, dec.norm_out.weight, n, rows=B * H * W, C=dec.norm_out.weight.numel(), eps=dec.norm_out.eps, b=dec.norm_out.bias, act=hip.ACT_RELU)
+        y = self._conv(n, B, H, W, dec.conv_out)
+        co = dec.conv_out.out_channels
+        keep = co
+        if not return_static and self.static_channels is not None:
+            keep = co - self.static_channels if self.static_channels else 0  # reference: decoded[:, :-static_channels] (:1050-1052)
+        out = torch.empty(B, keep, H, W, device=dev, dtype=torch.float32)
+        if keep:
+            hip.token_to_chan(y, out, B=B, C=keep, N=H * W, ldi=co)
+        if not return_dict:
+            return (out,)
+        return DecoderOutput(sample=out)
+
+    def forward(self, sample, return_dict: bool = True, time_elapsed=None, static_conditioning_tensor=None, return_static: bool = False):
+        if time_elapsed is not None:
+            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
+        z = self.encode(sample, return_dict=False, static_conditioning_tensor=static_conditioning_tensor)[0]
+        y = self.decode(z, return_dict=False, return_static=return_static)[0]
+        if not return_dict:
+            return (y,)
+        return DecoderOutput(sample=y)

@@ -1,0 +1,187 @@
+"""Parity of the HIP DCAE path (NHWC kernels behind the reference's AutoencoderDC / SphereConv2d API)
+against the reference-pinned sphere-conv fixtures and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dcae as OD  # noqa: E402
+from tests.synth import make_dcae, rel_l2, synth_field, tiny_dcae_config  # noqa: E402
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def test_sphere_conv_matches_reference_fixtures(golden_dir):
+    """fixtures = outputs of ladcast.models.sphere_conv.SphereConv2d (tests/golden/make_golden.py)"""
+    from ladcast_amd.models import SphereConv2d
+
+    g = np.load(os.path.join(golden_dir, "sphere_conv_ref.npz"))
+    seen = 0
+    i = 0
+    while f"c{i}_meta" in g:
+        ci, co, k, grp, b, H, W = [int(v) for v in g[f"c{i}_meta"]]
+        i += 1
+        if grp not in (1, ci) or (grp == ci and (ci != co or ci % 4)):
+            continue  # grouped-but-not-depthwise cases are not used by the DCAE
+        j = i - 1
+        m = SphereConv2d(ci, co, k, 1, k // 2, groups=grp, bias=bool(b))
+        m.weight.data = torch.from_numpy(g[f"c{j}_w"])
+        if b:
+            m.bias.data = torch.from_numpy(g[f"c{j}_b"])
+        m = m.cuda()
+        y = m(torch.from_numpy(g[f"c{j}_x"]).cuda())
+        assert rel_l2(y.cpu(), torch.from_numpy(g[f"c{j}_y"])) < 2e-6, f"case {j}"
+        seen += 1
+    assert seen >= 3
+    # docstring KAT (models/sphere_conv.py:142-172): exact small integers
+    c = SphereConv2d(1, 1, 5, 1, 2)
+    c.weight.data = torch.tensor([[[[0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 1, 0]]]], dtype=torch.float32)
+    c.bias.data = torch.tensor([0.0])
+    y = c.cuda()(torch.arange(0, 24).view(1, 1, 3, 8).float().cuda())
+    assert torch.equal(y.cpu(), torch.from_numpy(g["kat_y"]))
+
+
+@pytest.mark.parametrize("k,depthwise", [(3, False), (3, True), (5, True)])
+def test_sphere_conv_pole_rows_vs_oracle(k, depthwise):
+    from ladcast_amd.models import SphereConv2d
+    from oracle.sphere_conv import SphereConv2d as OSC
+
+    ci = co = 8
+    o = OSC(ci, co, k, 1, k // 2, groups=ci if depthwise else 1, bias=True)
+    with torch.no_grad():
+        o.weight.copy_(rnd(*o.weight.shape, seed=1))
+        o.bias.copy_(rnd(co, seed=2))
+    m = SphereConv2d(ci, co, k, 1, k // 2, groups=ci if depthwise else 1, bias=True)
+    m.load_state_dict(o.state_dict())
+    x = rnd(2, ci, 9, 16, seed=3)
+    with torch.no_grad():
+        want = o(x)
+    got = m.cuda()(x.cuda()).cpu()
+    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 2e-6 and rel_l2(got[:, :, -1], want[:, :, -1]) < 2e-6  # pole rows use the flipped kernel rows
+    assert rel_l2(got[:, :, 1], want[:, :, 1]) < 2e-6  # row 1 of a 5x5 sees reflected input with the unflipped kernel
+
+
+def test_dcae_elementwise_kernels():
+    import ladcast_amd.hip as hip
+
+    B, H, W, C = 2, 6, 8, 16
+    x = rnd(B, C, H, W, seed=1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    # down: conv output has cout/4 channels at full res
+    cout = 32
+    cv = rnd(B, cout // 4, H, W, seed=2)
+    want = F.pixel_unshuffle(cv, 2) + F.pixel_unshuffle(x, 2).unflatten(1, (-1, C * 4 // cout)).mean(dim=2)
+    y = torch.empty(B, H // 2, W // 2, cout, device="cuda")
+    hip.pixel_unshuffle_shortcut(cv.permute(0, 2, 3, 1).contiguous().cuda(), xn.cuda(), y, B=B, H2=H // 2, W2=W // 2, cout=cout, cin=C)
+    assert rel_l2(y.cpu().permute(0, 3, 1, 2), want) < 1e-6
+    # up
+    cout = 8
+    cv = rnd(B, cout * 4, H, W, seed=3)
+    want = F.pixel_shuffle(cv, 2) + F.pixel_shuffle(x.repeat_interleave(cout * 4 // C, dim=1), 2)
+    y = torch.empty(B, 2 * H, 2 * W, cout, device="cuda")
+    hip.pixel_shuffle_shortcut(cv.permute(0, 2, 3, 1).contiguous().cuda(), xn.cuda(), y, B=B, H=H, W=W, cout=cout, cin=C)
+    assert rel_l2(y.cpu().permute(0, 3, 1, 2), want) < 1e-6
+    # regroup both ways
+    m = rnd(50, 48, seed=4)
+    y = torch.empty(50, 12, device="cuda")
+    hip.chan_regroup(m.cuda(), y, M=50, cin=48, cout=12)
+    assert rel_l2(y.cpu(), m.unflatten(1, (-1, 4)).mean(dim=2)) < 1e-6
+    y = torch.empty(50, 144, device="cuda")
+    hip.chan_regroup(m.cuda(), y, M=50, cin=48, cout=144)
+    assert torch.equal(y.cpu(), m.repeat_interleave(3, dim=1))
+    # rmsnorm rows with residual + relu
+    xr, w, b, r = rnd(37, 252, seed=5), rnd(252, seed=6), rnd(252, seed=7), rnd(37, 252, seed=8)
+    y = torch.empty(37, 252, device="cuda")
+    hip.rmsnorm_rows(xr.cuda(), w.cuda(), y, rows=37, C=252, eps=1e-5, b=b.cuda(), resid=r.cuda(), act=hip.ACT_RELU)
+    want = F.relu(xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w + b + r)
+    assert rel_l2(y.cpu(), want) < 1e-6
+
+
+def test_linear_attention_and_grouped_conv():
+    import ladcast_amd.hip as hip
+
+    B, P, groups = 2, 450, 6
+    qkv = rnd(B, P, groups * 96, seed=1)
+    y = torch.empty(B, P, groups * 32, device="cuda")
+    hip.relu_linear_attn_nhwc(qkv.cuda(), y, B=B, P=P, groups=groups, ldq=groups * 96, ldy=groups * 32, eps=1e-15)
+    hs = qkv.permute(0, 2, 1).reshape(B, groups, 96, P).double()
+    q, k, v = hs.chunk(3, dim=2)
+    q, k = F.relu(q), F.relu(k)
+    v = F.pad(v, (0, 0, 0, 1), value=1.0)
+    out = (v @ k.transpose(-1, -2)) @ q
+    want = (out[:, :, :-1] / (out[:, :, -1:] + 1e-15)).reshape(B, groups * 32, P).permute(0, 2, 1)
+    assert rel_l2(y.cpu(), want) < 2e-6
+    M, G = 77, 5
+    x, w = rnd(M, G * 32, seed=2), rnd(G * 32, 32, seed=3)
+    y = torch.empty(M, G * 32, device="cuda")
+    hip.grouped_conv1x1_nhwc(x.cuda(), w.cuda(), y, M=M, groups=G, ldx=G * 32, ldy=G * 32)
+    want = F.conv2d(x.t().reshape(1, G * 32, M, 1), w.reshape(G * 32, 32, 1, 1), groups=G).reshape(G * 32, M).t()
+    assert rel_l2(y.cpu(), want) < 2e-6
+
+
+def _pair(cfg):
+    from ladcast_amd.models import AutoencoderDC
+
+    o = make_dcae(cfg)
+    g = AutoencoderDC.from_config(cfg)
+    g.load_state_dict(o.state_dict(), strict=True)
+    return o, g.cuda().eval()
+
+
+def test_tiny_dcae_matches_oracle_and_pin(golden_dir):
+    o, g = _pair(tiny_dcae_config())
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        yo = o.decode(zo).sample
+    zg = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+    assert zg.shape == zo.shape and rel_l2(zg.cpu(), zo) < 2e-5
+    yg = g.decode(zo.cuda()).sample
+    assert yg.shape == yo.shape == (2, 8, 48, 64) and rel_l2(yg.cpu(), yo) < 2e-5
+    full = g(f.cuda(), static_conditioning_tensor=st.cuda(), return_static=True).sample
+    assert full.shape == (2, 13, 48, 64)
+    pin = np.load(os.path.join(golden_dir, "oracle_pins.npz"))
+    z1 = g.encode(f[:1].cuda(), static_conditioning_tensor=st.cuda()).latent
+    got = z1.cpu().double().flatten()[::13][:4096]
+    want = torch.from_numpy(pin["tiny_dcae_z"])
+    assert ((got - want).norm() / want.norm()).item() < 2e-5
+
+
+def test_full_dcae_single_frame_matches_oracle():
+    """BASELINE configs[0]: one 240x121(->120)x84 frame, encode + decode."""
+    o, g = _pair(dict(OD.CONFIG_DCAE_84))
+    f, st = synth_field(1, 84, 120, 240), synth_field(1, 5, 120, 240, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st).latent
+        yo = o.decode(zo).sample
+    zg = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+    assert zg.shape == (1, 84, 15, 30) and rel_l2(zg.cpu(), zo) < 5e-5
+    yg = g.decode(zg).sample
+    assert yg.shape == (1, 84, 120, 240) and rel_l2(yg.cpu(), yo) < 1e-4
+
+
+def test_decode_latent_ens_and_error_conventions():
+    from ladcast_amd.pipelines import decode_latent_ens
+    from oracle.pipelines import decode_latent_ens as o_decode
+
+    o, g = _pair(tiny_dcae_config())
+    lat = rnd(2, 8, 3, 6, 8, seed=4)
+    mu, sd = rnd(8, seed=5), rnd(8, seed=6).abs() + 0.5
+    with torch.no_grad():
+        want = o_decode(o, lat, mu, sd, extract_first=2)
+    got = decode_latent_ens(g, lat.cuda(), mu, sd, extract_first=2)
+    assert got.shape == want.shape == (2, 8, 2, 48, 64)
+    assert rel_l2(got.cpu(), want) < 2e-5
+    g.enable_slicing()
+    with pytest.raises(NotImplementedError):
+        g.decode(lat[:, :, 0].cuda())
+    with pytest.raises(NotImplementedError):
+        g.encode(synth_field(2, 13, 48, 64).cuda())
+    g.disable_slicing()
