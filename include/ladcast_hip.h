@@ -62,6 +62,28 @@ int ldc_sizeof_gemm_desc(void);
 int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const float* gate,
                       const float* R, float* C, const ldc_gemm_desc* d, void* stream);
 
+/* Same contraction for up to LDC_GEMM_MAX_PROBLEMS independent problems in ONE persistent launch
+ * with stream-K scheduling (work = (tile, 32-deep k-step) units cut into equal contiguous ranges,
+ * 2 workgroups per CU) plus a fix-up launch for the tiles whose K range was split.  Built for the
+ * small grids of the AR transformer (e.g. the pred- and cond-stream projections of a dual block,
+ * models/LaDCast_3D_model.py:92-94,175-177,558-563).  `workspace` is caller-owned device scratch of
+ * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned); contents are undefined after
+ * the call.  C of one problem must not overlap A/R of another problem of the same call. */
+#define LDC_GEMM_MAX_PROBLEMS 4
+typedef struct ldc_gemm_problem {
+  const float* A;
+  const float* W;
+  const float* bias;
+  const float* gate;
+  const float* R;
+  float* C;
+  ldc_gemm_desc d;
+} ldc_gemm_problem;
+int ldc_sizeof_gemm_problem(void);
+long long ldc_gemm_grouped_workspace_bytes(void);
+int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                     void* stream);
+
 /* Small-M linear (M = rows <= 64): y[r] = act_out(W . act_in(x[r % x_rows]) + bias)
  *                                           + add[r % add_rows]
  * HBM-bound weight streaming; replaces the timestep / text / AdaLN projection

@@ -29,6 +29,13 @@ class GemmDesc(Structure):
     ]
 
 
+class GemmProblem(Structure):
+    _fields_ = [("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("gate", c_void_p), ("R", c_void_p), ("C", c_void_p), ("d", GemmDesc)]
+
+
+MAX_GROUPED = 4
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -42,6 +49,9 @@ def _load():
         "ldc_build_arch": (c_char_p, []),
         "ldc_sizeof_gemm_desc": (I, []),
         "ldc_gemm_bias_act": (I, [P, P, P, P, P, P, POINTER(GemmDesc), P]),
+        "ldc_sizeof_gemm_problem": (I, []),
+        "ldc_gemm_grouped_workspace_bytes": (L, []),
+        "ldc_gemm_grouped": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
@@ -76,8 +86,8 @@ def _load():
         fn.argtypes = args
     if lib.ldc_abi_version() != 1:
         raise RuntimeError("libladcast_hip.so ABI version mismatch")
-    if lib.ldc_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc):
-        raise RuntimeError("ldc_gemm_desc layout mismatch between header and binding")
+    if lib.ldc_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc) or lib.ldc_sizeof_gemm_problem() != ctypes.sizeof(GemmProblem):
+        raise RuntimeError("ldc_gemm_desc / ldc_gemm_problem layout mismatch between header and binding")
     return lib, sig
 
 
@@ -111,6 +121,41 @@ def gemm(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_b
     d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K,
                  ldc if ldc is not None else N, ldr, a_bs, c_bs, r_bs, gate_bs, act)
     _check(lib.ldc_gemm_bias_act(_p(A), _p(W), _p(bias), _p(gate), _p(R), _p(C), ctypes.byref(d), _stream()), "ldc_gemm_bias_act")
+
+
+_grouped_ws = {}
+
+
+def _grouped_workspace(device):
+    key = str(device)
+    if key not in _grouped_ws:
+        _grouped_ws[key] = torch.empty(lib.ldc_gemm_grouped_workspace_bytes() // 4, device=device, dtype=torch.float32)
+    return _grouped_ws[key]
+
+
+def gemm_problem(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_bs=0, bias=None, gate=None, gate_bs=0, R=None,
+                 ldr=0, r_bs=0, act=ACT_NONE):
+    """one entry of a grouped launch (same argument meaning as `gemm`)"""
+    _dev(A, W, C, bias, gate, R)
+    d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K, ldc if ldc is not None else N, ldr,
+                 a_bs, c_bs, r_bs, gate_bs, act)
+    pv = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    return GemmProblem(pv(A), pv(W), pv(bias), pv(gate), pv(R), pv(C), d), (A, W, C, bias, gate, R)
+
+
+def gemm_grouped(problems):
+    """Up to MAX_GROUPED independent GEMMs in one persistent stream-K launch (+ fix-up launch)."""
+    n = len(problems)
+    if not 1 <= n <= MAX_GROUPED:
+        raise ValueError(f"gemm_grouped takes 1..{MAX_GROUPED} problems")
+    arr = (GemmProblem * n)(*[p[0] for p in problems])
+    ws = _grouped_workspace(problems[0][1][2].device)
+    _check(lib.ldc_gemm_grouped(arr, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped")
+
+
+def gemm_sk(A, W, C, **kw):
+    """single GEMM through the stream-K scheduler"""
+    gemm_grouped([gemm_problem(A, W, C, **kw)])
 
 
 def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE):

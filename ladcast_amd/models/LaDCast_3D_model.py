@@ -414,21 +414,24 @@ class LaDCastTransformer3DModel(ModelMixin):
         nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
 
         # 1. patch embeds (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
+        G = hip.gemm_problem
         hip.chan_to_token(hidden_states, ws.xtok, B=B, C=C_in, N=Nx, ldo=C_in)
-        hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
         hip.chan_to_token(conditioning_tensors, ws.ctok, B=B, C=Cc, N=Nc, ldo=Cc)
-        hip.gemm(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias)
+        hip.gemm_grouped([
+            G(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias),
+            G(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
+        ])
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
         hip.timestep_embedding(timestep, ws.tsin, Bt)
         hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
         self._combined_embed(ref.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb_r)
-        hip.gemm(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
+        hip.gemm_sk(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps)
-            hip.gemm(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            hip.gemm_sk(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
             self._attention(ws, B, Nc, Nx, ws.qkv, ws.att[:, Nx:], D, SD)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
@@ -436,9 +439,9 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
-            hip.gemm(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
-            hip.gemm(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
-                     gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD)
+            hip.gemm_sk(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
+            hip.gemm_sk(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
+                        gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD)
 
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
         hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
@@ -457,23 +460,30 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.linear_small(ws.temb, blk.norm1_context.linear.weight, mc, rows=B, N=6 * D, K=D, bias=blk.norm1_context.linear.bias, act_in=hip.ACT_SILU)
             hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=6 * D, mode=0, eps=1e-6)
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=6 * D, mode=0, eps=1e-6)
-            hip.gemm(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
-            hip.gemm(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c)
+            hip.gemm_grouped([
+                G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
+                G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c),
+            ])
             self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)
             self._attention(ws, B, S, 0, ws.qkv, ws.att, D, SD)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
-            hip.gemm(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=6 * D, R=h_x, ldr=D, r_bs=SD)
-            hip.gemm(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=6 * D, R=h_c, ldr=D, r_bs=SD)
+            hip.gemm_grouped([
+                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=6 * D, R=h_x, ldr=D, r_bs=SD),
+                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=6 * D, R=h_c, ldr=D, r_bs=SD),
+            ])
             hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
+            up, down = [], []
             for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
                 f0, f2 = ff.net[0].proj, ff.net[2]
                 F = f0.weight.shape[0]
                 hid = ws.cat.view(-1)[off * B * F :]  # [B, rows, F] slab inside the concat scratch
-                hip.gemm(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH)
-                hip.gemm(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
-                         gate=mod[:, 5 * D :], gate_bs=6 * D, R=hs, ldr=D, r_bs=SD)
+                up.append(G(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH))
+                down.append(G(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
+                              gate=mod[:, 5 * D :], gate_bs=6 * D, R=hs, ldr=D, r_bs=SD))
+            hip.gemm_grouped(up)
+            hip.gemm_grouped(down)
 
         # 5. single-stream blocks, models/LaDCast_3D_model.py:426-468
         for blk in self.single_transformer_blocks:
@@ -483,18 +493,20 @@ class LaDCastTransformer3DModel(ModelMixin):
             W5 = D + F
             hip.linear_small(ws.temb, blk.norm.linear.weight, mod, rows=B, N=3 * D, K=D, bias=blk.norm.linear.bias, act_in=hip.ACT_SILU)
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=3 * D, mode=0, eps=1e-6)
-            hip.gemm(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH)
-            hip.gemm(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            hip.gemm_grouped([
+                G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH),
+                G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
+            ])
             self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
             self._attention(ws, B, S, 0, ws.qkv, ws.cat, W5, S * W5)
-            hip.gemm(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
-                     gate=mod[:, 2 * D :], gate_bs=3 * D, R=ws.h, ldr=D, r_bs=SD)
+            hip.gemm_sk(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
+                        gate=mod[:, 2 * D :], gate_bs=3 * D, R=ws.h, ldr=D, r_bs=SD)
 
         # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
         hip.linear_small(ws.temb, self.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=self.norm_out.linear.bias, act_in=hip.ACT_SILU)
         hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=ws.mod_a, shift=ws.mod_a[:, D:], mod_bs=2 * D, mode=0, eps=1e-7)
-        hip.gemm(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
+        hip.gemm_sk(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
 

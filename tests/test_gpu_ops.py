@@ -63,6 +63,44 @@ def test_gemm_epilogue_and_strides(hip, act):
     assert torch.equal(d_buf[:, :, :100].cpu(), buf[:, :, :100])  # untouched columns
 
 
+@pytest.mark.parametrize(
+    "M,N,K,batch",
+    [(128, 128, 32, 1), (2250, 1536, 1536, 1), (450, 84, 1536, 2), (1800, 1536, 84, 1), (37, 200, 260, 3), (2250, 1536, 7680, 1), (1, 5, 4, 1),
+     (450, 1536, 6144, 1), (4500, 4608, 1536, 1)],
+)
+def test_gemm_streamk_single(hip, M, N, K, batch):
+    A, W, b = rnd(batch, M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    C = torch.full((batch, M, N), float("nan"), device="cuda")
+    hip.gemm_sk(dev(A), dev(W), C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b))
+    want = A.double() @ W.double().T + b.double()
+    assert torch.isfinite(C).all()
+    assert rel(C, want) < 2e-6
+
+
+def test_gemm_streamk_grouped_with_epilogues(hip):
+    """four different problems (shapes, weights, epilogues, in-place residuals) in one persistent launch"""
+    specs = [(1800, 1536, 1536, 2, 1), (450, 1536, 1536, 2, 2), (300, 260, 132, 1, 0), (77, 96, 6144, 1, 3)]
+    probs, checks = [], []
+    for i, (M, N, K, B, act) in enumerate(specs):
+        A, W, b = rnd(B, M, K, seed=10 + i), rnd(N, K, seed=20 + i) / math.sqrt(K), rnd(N, seed=30 + i)
+        gate, res = rnd(B, N, seed=40 + i), rnd(B, M, N, seed=50 + i)
+        Cd = dev(res.clone())
+        probs.append(hip.gemm_problem(dev(A), dev(W), Cd, M=M, N=N, K=K, batch=B, a_bs=M * K, c_bs=M * N, bias=dev(b), gate=dev(gate), gate_bs=N,
+                                      R=Cd, ldr=N, r_bs=M * N, act=act))
+        v = A.double() @ W.double().T + b.double()
+        v = [v, F.silu(v), F.gelu(v, approximate="tanh"), F.relu(v)][act]
+        checks.append((Cd, res.double() + v * gate[:, None, :].double()))
+    hip.gemm_grouped(probs)
+    for Cd, want in checks:
+        assert rel(Cd, want) < 2e-6
+    # determinism: the same launch twice gives bit-identical results
+    A, W = dev(rnd(2250, 1536, seed=1)), dev(rnd(1536, 1536, seed=2))
+    c1, c2 = torch.empty(2250, 1536, device="cuda"), torch.empty(2250, 1536, device="cuda")
+    hip.gemm_sk(A, W, c1, M=2250, N=1536, K=1536)
+    hip.gemm_sk(A, W, c2, M=2250, N=1536, K=1536)
+    assert torch.equal(c1, c2)
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a = torch.zeros(8, 6, device="cuda")
     with pytest.raises(RuntimeError):
