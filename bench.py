@@ -9,7 +9,7 @@ autoregressive sampler chunk (BASELINE.json configs[1]: 375M AR transformer, 1 e
 GPU, 20 solver steps, 1 lead step) -- IC latent resident in HBM in, lead-step latents out.  With
 the shipped return_seq_len = 4 the reference computes one 4-frame chunk for a 1-lead-step request and
 keeps ``pred_selection = 1`` frame (pipelines/utils.py:535-536); the metric counts that 1 lead step.
-Weak scaling: every rank owns ``--members-per-gpu`` members (global ids rank*m .. rank*m+m-1, seeded by
+Weak scaling: every rank owns ``--members-per-gpu`` members (global ids {k : k mod N == rank}, seeded by
 member id as pipelines/utils.py:703-706), no data-path collective except one RCCL gather of the
 result latents at the end of each step.
 
@@ -67,8 +67,16 @@ class KernelTimer:
 
     def install(self, hip):
         self._hip = hip
-        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd}
+        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped}
         timer = self
+
+        def gemm_grouped(problems):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer._orig["gemm_grouped"](problems)
+            e.record()
+            work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
+            timer.records.setdefault("gemm_streamk_kernel", []).append((s, e, work))
 
         def gemm(A, W, C, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,10 +92,10 @@ class KernelTimer:
             e.record()
             timer.records.setdefault("attn_fwd_f32_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
-        hip.gemm, hip.attn_fwd = gemm, attn_fwd
+        hip.gemm, hip.attn_fwd, hip.gemm_grouped = gemm, attn_fwd, gemm_grouped
 
     def uninstall(self):
-        self._hip.gemm, self._hip.attn_fwd = self._orig["gemm"], self._orig["attn_fwd"]
+        self._hip.gemm, self._hip.attn_fwd, self._hip.gemm_grouped = self._orig["gemm"], self._orig["attn_fwd"], self._orig["gemm_grouped"]
 
     def clear(self):
         self.records = {}
@@ -164,11 +172,13 @@ def main():
     model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval()
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     m = args.members_per_gpu
-    member_ids = [rank * m + i for i in range(m)]
+    from ladcast_amd.pipelines.distributed import shard_members
+
+    member_ids = shard_members(m * world, rank, world)  # rank r owns members {k : k mod world == r}
     R, lead = args.return_seq_len, args.lead_steps
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).to(dev)  # IC latent, resident in HBM
     targs = {"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5}
-    gathered = [torch.empty(m, 84, 1 + lead, 15, 30, device=dev) for _ in range(world)] if world > 1 else None
+    from ladcast_amd.pipelines.distributed import gather_members
 
     def step():
         out = roll_out_serial(
@@ -177,7 +187,7 @@ def main():
             known_latents_override=ic, member_ids=member_ids,
         )
         if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
-            dist.all_gather(gathered, out[0].to(dev))
+            out = gather_members(out.to(dev), m * world, member_dim=1)
         return out
 
     def fence():
@@ -211,18 +221,21 @@ def main():
         value = total_members * lead * args.steps / elapsed
         ks = timer.summary()
         roof = None
-        if "gemm_nt_f32_kernel" in ks:
-            k = ks["gemm_nt_f32_kernel"]
+        dom = "gemm_streamk_kernel" if "gemm_streamk_kernel" in ks else "gemm_nt_f32_kernel"
+        if dom in ks:
+            k = ks[dom]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("gemm_nt_f32_kernel", {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = dict(bound="mfma", kernel="gemm_nt_f32_kernel", achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel=dom, achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
-                        flops_per_launch=k["work_per_launch"])
+                        flops_per_launch=k["work_per_launch"],
+                        note="one launch = one grouped stream-K GEMM call (main kernel + its fix-up kernel); achieved = 2*M*N*K summed over the "
+                             "call's problems / HIP-event time of the call, averaged over all calls of the timed region")
         line = {
             "metric": "ensemble-member-steps/sec", "value": round(value, 4), "unit": "member-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
