@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = DPM-Solver++(2M), N forwards")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="token-stream GEMM arithmetic: exact fp32 MFMA, or split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +171,7 @@ def main():
 
     cfg = CONFIGS[args.model]
     torch.manual_seed(1234)
-    model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval()
+    model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval().set_gemm_precision(args.precision)
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     m = args.members_per_gpu
     from ladcast_amd.pipelines.distributed import shard_members

@@ -84,6 +84,15 @@ long long ldc_gemm_grouped_workspace_bytes(void);
 int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                      void* stream);
 
+/* Split-bf16 ("bf16x3") form of ldc_gemm_grouped: same problems / epilogue / scheduling, but every
+ * problem's W points to weights pre-split by ldc_pack_weight_bf16x2 ([N][K/8][hi x8 | lo x8] bf16,
+ * N*K*4 bytes; d.ldw is ignored, K % 8 == 0) and the contraction is Ah.Wh + Ah.Wl + Al.Wh on the bf16
+ * matrix cores with fp32 accumulation (hi = bf16(x), lo = bf16(x - hi); activations are split on
+ * load).  Error vs exact fp32: ~4e-6 rel-L2 per model forward. */
+int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                            void* stream);
+int ldc_pack_weight_bf16x2(const float* W, void* out, int N, int K, int ldw, void* stream);
+
 /* Small-M linear (M = rows <= 64): y[r] = act_out(W . act_in(x[r % x_rows]) + bias)
  *                                           + add[r % add_rows]
  * HBM-bound weight streaming; replaces the timestep / text / AdaLN projection

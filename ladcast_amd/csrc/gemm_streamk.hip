@@ -199,6 +199,212 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(SKArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: the same contraction on the 16x faster bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16) with fp32-grade error compensation.  Each fp32 operand is written as
+// hi + lo with hi = bf16(x), lo = bf16(x - hi) (24 -> 16 significant bits kept), and
+//     A.W^T  ~=  Ah.Wh^T + Ah.Wl^T + Al.Wh^T          (fp32 accumulation inside the MFMA)
+// dropping only the lo*lo term (~2^-18 relative per product).  Measured on this model: 4e-6 rel-L2
+// per forward, 2e-6 over a 20-step Heun chunk vs exact fp32 (tools/split_precision_study.py),
+// against a 1e-4 budget; a plain bf16 GEMM is 2e-3.
+// Weights are pre-split once (ldc_pack_weight_bf16x2: [N][K/8][hi x8 | lo x8], 4 bytes/element like
+// fp32); activations are split in the loader on their way to LDS (v_cvt_pk_bf16_f32).
+// LDS row = [hi 64 B | lo 64 B | pad 16 B] (pitch 36 dwords: conflict-free b128 reads and writes).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PITCH_B = 144;                     // bytes per LDS row
+constexpr int STAGE_BYTES_B = (BM + BN) * PITCH_B;  // 36 KiB per stage
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> one dword of two bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) + the fp32 residuals
+__device__ __forceinline__ unsigned split_pair(float a, float b, float& ra, float& rb) {
+  bf16x2 v;
+  v.x = static_cast<__bf16>(a);
+  v.y = static_cast<__bf16>(b);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  ra = a - __uint_as_float(u << 16);
+  rb = b - __uint_as_float(u & 0xffff0000u);
+  return u;
+}
+__device__ __forceinline__ unsigned pack_pair(float a, float b) {
+  bf16x2 v;
+  v.x = static_cast<__bf16>(a);
+  v.y = static_cast<__bf16>(b);
+  return __builtin_bit_cast(unsigned, v);
+}
+// 8 fp32 -> hi (8 bf16 = 16 B) and lo = bf16(x - hi) (16 B)
+__device__ __forceinline__ void split8(const float4 p, const float4 q, uint4& h, uint4& l) {
+  float r0, r1, r2, r3, r4, r5, r6, r7;
+  h.x = split_pair(p.x, p.y, r0, r1);
+  h.y = split_pair(p.z, p.w, r2, r3);
+  h.z = split_pair(q.x, q.y, r4, r5);
+  h.w = split_pair(q.z, q.w, r6, r7);
+  l.x = pack_pair(r0, r1);
+  l.y = pack_pair(r2, r3);
+  l.z = pack_pair(r4, r5);
+  l.w = pack_pair(r6, r7);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_streamk_bf16x3_kernel(SKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = blockIdx.x;
+  const long long u_begin = range_start(g, a.U, a.G);
+  const long long u_end = range_start(g + 1, a.U, a.G);
+  const int frag_row = lane & 31;
+  const int frag_h = lane >> 5;
+
+  long long u = u_begin;
+  while (u < u_end) {
+    const int pi = find_problem_by_unit(a, u);
+    const DevProblem& P = a.pr[pi];
+    const long long local = u - P.unit0;
+    const int tile = static_cast<int>(local / P.kt);
+    const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
+    const long long left = u_end - u;
+    const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
+    const int bn = tile % P.tn;
+    const int bmb = tile / P.tn;
+    const int bm = bmb % P.tm;
+    const int b = bmb / P.tm;
+
+    const int M = P.d.M, N = P.d.N, K = P.d.K;
+    const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
+    const uint4* __restrict__ Wp = reinterpret_cast<const uint4*>(P.W);  // [N][K/8][2] x 16 B
+    const int lda = P.d.lda;
+    const int kchunks = K >> 3;
+
+    // staging: chunk c = tid + 256*i (i = 0,1): row = c>>2, 8-wide k chunk kc = c&3.
+    // Out-of-range chunks load from a valid clamped address and are zeroed by a select (no branches,
+    // so the staging registers stay in VGPRs).
+    const int srow0 = tid >> 2, srow1 = srow0 + 64, skc = tid & 3;
+    const bool am0 = bm * BM + srow0 < M, am1 = bm * BM + srow1 < M;
+    const bool wn0 = bn * BN + srow0 < N, wn1 = bn * BN + srow1 < N;
+    const float* a_src0 = A + static_cast<long long>(am0 ? bm * BM + srow0 : 0) * lda + skc * 8;
+    const float* a_src1 = A + static_cast<long long>(am1 ? bm * BM + srow1 : 0) * lda + skc * 8;
+    const uint4* w_src0 = Wp + (static_cast<long long>(wn0 ? bn * BN + srow0 : 0) * kchunks + skc) * 2;
+    const uint4* w_src1 = Wp + (static_cast<long long>(wn1 ? bn * BN + srow1 : 0) * kchunks + skc) * 2;
+    float4 ra00, ra01, ra10, ra11;
+    uint4 rw00, rw01, rw10, rw11;
+    auto gload = [&](int kt) {
+      const bool kin = kt * BK + skc * 8 < K;
+      const int ko = kin ? kt * BK : 0;  // element offset along K (clamped when the chunk is past K)
+      const float4* pa0 = reinterpret_cast<const float4*>(a_src0 + ko);
+      const float4* pa1 = reinterpret_cast<const float4*>(a_src1 + ko);
+      const uint4* pw0 = w_src0 + (ko >> 3) * 2;
+      const uint4* pw1 = w_src1 + (ko >> 3) * 2;
+      ra00 = pa0[0];
+      ra01 = pa0[1];
+      ra10 = pa1[0];
+      ra11 = pa1[1];
+      rw00 = pw0[0];
+      rw01 = pw0[1];
+      rw10 = pw1[0];
+      rw11 = pw1[1];
+      // zero out-of-range chunks with component-wise masks (a whole-vector select is lowered through scratch)
+      const unsigned m0a = (kin && am0) ? 0xffffffffu : 0u, m1a = (kin && am1) ? 0xffffffffu : 0u;
+      const unsigned m0w = (kin && wn0) ? 0xffffffffu : 0u, m1w = (kin && wn1) ? 0xffffffffu : 0u;
+#define LDC_MASKF4(v, m)                                 \
+  v.x = __uint_as_float(__float_as_uint(v.x) & (m));     \
+  v.y = __uint_as_float(__float_as_uint(v.y) & (m));     \
+  v.z = __uint_as_float(__float_as_uint(v.z) & (m));     \
+  v.w = __uint_as_float(__float_as_uint(v.w) & (m));
+#define LDC_MASKU4(v, m) \
+  v.x &= (m);            \
+  v.y &= (m);            \
+  v.z &= (m);            \
+  v.w &= (m);
+      LDC_MASKF4(ra00, m0a) LDC_MASKF4(ra01, m0a) LDC_MASKF4(ra10, m1a) LDC_MASKF4(ra11, m1a)
+      LDC_MASKU4(rw00, m0w) LDC_MASKU4(rw01, m0w) LDC_MASKU4(rw10, m1w) LDC_MASKU4(rw11, m1w)
+    };
+    auto sstore = [&](int stage) {
+      unsigned char* As = smem_b + stage * STAGE_BYTES_B;
+      unsigned char* Bs = As + BM * PITCH_B;
+      uint4 h, l;
+      split8(ra00, ra01, h, l);
+      *reinterpret_cast<uint4*>(As + srow0 * PITCH_B + skc * 16) = h;
+      *reinterpret_cast<uint4*>(As + srow0 * PITCH_B + 64 + skc * 16) = l;
+      split8(ra10, ra11, h, l);
+      *reinterpret_cast<uint4*>(As + srow1 * PITCH_B + skc * 16) = h;
+      *reinterpret_cast<uint4*>(As + srow1 * PITCH_B + 64 + skc * 16) = l;
+      *reinterpret_cast<uint4*>(Bs + srow0 * PITCH_B + skc * 16) = rw00;
+      *reinterpret_cast<uint4*>(Bs + srow0 * PITCH_B + 64 + skc * 16) = rw01;
+      *reinterpret_cast<uint4*>(Bs + srow1 * PITCH_B + skc * 16) = rw10;
+      *reinterpret_cast<uint4*>(Bs + srow1 * PITCH_B + 64 + skc * 16) = rw11;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(k0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = k0; kt < k1; ++kt) {
+      const int st = (kt - k0) & 1;
+      if (kt + 1 < k1) gload(kt + 1);
+      const unsigned char* As = smem_b + st * STAGE_BYTES_B;
+      const unsigned char* Bs = As + BM * PITCH_B;
+      const unsigned char* a_base = As + (wm * 64 + frag_row) * PITCH_B + frag_h * 16;
+      const unsigned char* b_base = Bs + (wn * 64 + frag_row) * PITCH_B + frag_h * 16;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {  // two 16-deep MFMA steps per 32-deep k-tile
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a_base + s2 * 32);
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a_base + 64 + s2 * 32);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a_base + 32 * PITCH_B + s2 * 32);
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a_base + 32 * PITCH_B + 64 + s2 * 32);
+        const bf16x8 wh0 = *reinterpret_cast<const bf16x8*>(b_base + s2 * 32);
+        const bf16x8 wl0 = *reinterpret_cast<const bf16x8*>(b_base + 64 + s2 * 32);
+        const bf16x8 wh1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * PITCH_B + s2 * 32);
+        const bf16x8 wl1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * PITCH_B + 64 + s2 * 32);
+#define LDC_MFMA3(ACC, AH, AL, WH, WL)                                        \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, WH, ACC, 0, 0, 0);        \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, WL, ACC, 0, 0, 0);        \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, WH, ACC, 0, 0, 0);
+        LDC_MFMA3(acc[0][0], ah0, al0, wh0, wl0)
+        LDC_MFMA3(acc[0][1], ah0, al0, wh1, wl1)
+        LDC_MFMA3(acc[1][0], ah1, al1, wh0, wl0)
+        LDC_MFMA3(acc[1][1], ah1, al1, wh1, wl1)
+      }
+      if (kt + 1 < k1) sstore(st ^ 1);
+      __syncthreads();
+    }
+
+    if (k0 == 0 && k1 == P.kt) {
+      tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
+    } else {
+      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    u += k1 - k0;
+  }
+}
+
+// W [N][K] fp32 (row stride ldw) -> packed split [N][K/8][hi x8 | lo x8] bf16
+__global__ __launch_bounds__(256) void pack_weight_bf16x2_kernel(const float* __restrict__ W, uint4* __restrict__ out,
+                                                                 int N, int K, int ldw) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const int kchunks = K >> 3;
+  if (idx >= static_cast<long long>(N) * kchunks) return;
+  const int n = static_cast<int>(idx / kchunks), kc = static_cast<int>(idx - static_cast<long long>(n) * kchunks);
+  const float4* src = reinterpret_cast<const float4*>(W + static_cast<long long>(n) * ldw + kc * 8);
+  uint4 h, l;
+  split8(src[0], src[1], h, l);
+  out[idx * 2] = h;
+  out[idx * 2 + 1] = l;
+}
+
 // one workgroup per output tile; tiles that one range covered completely were finished above
 __global__ __launch_bounds__(256) void gemm_streamk_fixup_kernel(SKArgs a) {
   const long long t = blockIdx.x;
@@ -253,8 +459,8 @@ extern "C" long long ldc_gemm_grouped_workspace_bytes(void) {
   return 2LL * 512 * SLOT_FLOATS * static_cast<long long>(sizeof(float));
 }
 
-extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
-                                void* stream) {
+static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                             void* stream, bool split_bf16) {
   LDC_CHECK_PTR(problems);
   if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
   SKArgs a{};
@@ -269,7 +475,8 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
     LDC_CHECK_ALIGN16(q.A);
     LDC_CHECK_ALIGN16(q.W);
-    if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3) || (d.a_bs & 3)) return LDC_ERR_ALIGN;
+    if ((d.K & 3) || (d.lda & 3) || (d.a_bs & 3)) return LDC_ERR_ALIGN;
+    if (split_bf16 ? (d.K & 7) != 0 : (d.ldw & 3) != 0) return LDC_ERR_ALIGN;
     if (d.act < LDC_ACT_NONE || d.act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
     DevProblem& P = a.pr[i];
     P.A = q.A;
@@ -303,18 +510,44 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
   a.U = U;
   a.tiles = tiles;
   a.ws = static_cast<float*>(workspace);
-  const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
+  const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(2 * STAGE_FLOATS * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_bf16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES_B);
     attr_set = true;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gemm_streamk_kernel, dim3(a.G), dim3(256), lds, s, a);
+  if (split_bf16) hipLaunchKernelGGL(gemm_streamk_bf16x3_kernel, dim3(a.G), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(gemm_streamk_kernel, dim3(a.G), dim3(256), lds, s, a);
   int st = ldc_launch_status();
   if (st != LDC_OK) return st;
   // some tile is split whenever the ranges are not tile-aligned; the fix-up exits at once for whole tiles
   hipLaunchKernelGGL(gemm_streamk_fixup_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, a);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                                void* stream) {
+  return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace,
+                                       long long workspace_bytes, void* stream) {
+  return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int ldc_pack_weight_bf16x2(const float* W, void* out, int N, int K, int ldw, void* stream) {
+  LDC_CHECK_PTR(W);
+  LDC_CHECK_PTR(out);
+  if (N <= 0 || K <= 0) return LDC_ERR_ARG;
+  if ((K & 7) || (ldw & 3)) return LDC_ERR_ALIGN;
+  LDC_CHECK_ALIGN16(W);
+  LDC_CHECK_ALIGN16(out);
+  const long long total = static_cast<long long>(N) * (K >> 3);
+  hipLaunchKernelGGL(pack_weight_bf16x2_kernel, dim3(ldc_cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     W, static_cast<uint4*>(out), N, K, ldw);
   return ldc_launch_status();
 }

@@ -52,6 +52,8 @@ def _load():
         "ldc_sizeof_gemm_problem": (I, []),
         "ldc_gemm_grouped_workspace_bytes": (L, []),
         "ldc_gemm_grouped": (I, [POINTER(GemmProblem), I, P, L, P]),
+        "ldc_gemm_grouped_bf16x3": (I, [POINTER(GemmProblem), I, P, L, P]),
+        "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
@@ -143,19 +145,31 @@ def gemm_problem(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_b
     return GemmProblem(pv(A), pv(W), pv(bias), pv(gate), pv(R), pv(C), d), (A, W, C, bias, gate, R)
 
 
-def gemm_grouped(problems):
-    """Up to MAX_GROUPED independent GEMMs in one persistent stream-K launch (+ fix-up launch)."""
+def gemm_grouped(problems, split_bf16=False):
+    """Up to MAX_GROUPED independent GEMMs in one persistent stream-K launch (+ fix-up launch).
+    split_bf16: every problem's W is a `pack_weight_bf16x2` buffer and the bf16x3 kernel is used."""
     n = len(problems)
     if not 1 <= n <= MAX_GROUPED:
         raise ValueError(f"gemm_grouped takes 1..{MAX_GROUPED} problems")
     arr = (GemmProblem * n)(*[p[0] for p in problems])
     ws = _grouped_workspace(problems[0][1][2].device)
-    _check(lib.ldc_gemm_grouped(arr, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped")
+    fn = lib.ldc_gemm_grouped_bf16x3 if split_bf16 else lib.ldc_gemm_grouped
+    _check(fn(arr, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped" + ("_bf16x3" if split_bf16 else ""))
 
 
-def gemm_sk(A, W, C, **kw):
+def gemm_sk(A, W, C, split_bf16=False, **kw):
     """single GEMM through the stream-K scheduler"""
-    gemm_grouped([gemm_problem(A, W, C, **kw)])
+    gemm_grouped([gemm_problem(A, W, C, **kw)], split_bf16=split_bf16)
+
+
+def pack_weight_bf16x2(W):
+    """fp32 [N, K] (K % 8 == 0) -> packed split-bf16 weight buffer (int32 view, N*K elements = same bytes)"""
+    _dev(W)
+    W = W.contiguous()
+    N, K = W.shape
+    out = torch.empty(N * K, device=W.device, dtype=torch.int32)
+    _check(lib.ldc_pack_weight_bf16x2(_p(W), _p(out), N, K, K, _stream()), "ldc_pack_weight_bf16x2")
+    return out
 
 
 def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE):

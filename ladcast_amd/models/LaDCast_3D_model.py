@@ -250,6 +250,18 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._ws = {}
         self._rope = {}
         self._te_cache = None
+        self.gemm_precision = "fp32"
+
+    def set_gemm_precision(self, mode: str):
+        """"fp32": exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  "bf16x3": split-bf16 error-compensated
+        contraction on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate), ~4e-6 rel-L2 per
+        forward vs fp32 -- see DESIGN.md section 4.  Token-stream GEMMs only; everything else stays fp32."""
+        if mode not in ("fp32", "bf16x3"):
+            raise ValueError("gemm precision must be 'fp32' or 'bf16x3'")
+        if mode != self.gemm_precision:
+            self.gemm_precision = mode
+            self._plan = None
+        return self
 
     # -- diffusers-style processor surface (models/LaDCast_3D_model.py:763-827) --------------
     @property
@@ -309,6 +321,22 @@ class LaDCastTransformer3DModel(ModelMixin):
         d = self.inner_dim
         plan.wx = self.x_embedder.proj.weight.reshape(d, -1).contiguous()
         plan.wc = self.context_embedder.proj.weight.reshape(d, -1).contiguous()
+        # split-bf16 mode: every token-stream GEMM weight gets a pre-split [N][K/8][hi|lo] copy (same bytes as fp32)
+        plan.split = self.gemm_precision == "bf16x3"
+        plan.packed = {}
+        if plan.split:
+            ws = [e.wqkv for e in plan.attn.values()] + [e.wqkv_c for e in plan.attn.values() if hasattr(e, "wqkv_c")]
+            ws.append(self.context_refiner.proj_in.weight)
+            ws.append(self.proj_out.weight)
+            for blk in self.context_refiner.token_refiner.refiner_blocks:
+                ws += [blk.ff.net[0].proj.weight, blk.ff.net[2].weight]
+            for blk in self.transformer_blocks:
+                ws += [blk.attn.to_out[0].weight, blk.attn.to_add_out.weight, blk.ff.net[0].proj.weight, blk.ff.net[2].weight,
+                       blk.ff_context.net[0].proj.weight, blk.ff_context.net[2].weight]
+            for blk in self.single_transformer_blocks:
+                ws += [blk.proj_mlp.weight, blk.proj_out.weight]
+            for w in ws:
+                plan.packed[id(w)] = hip.pack_weight_bf16x2(w)
         self._plan = plan
 
     # -- cached tables -----------------------------------------------------------------------
@@ -414,12 +442,23 @@ class LaDCastTransformer3DModel(ModelMixin):
         nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
 
         # 1. patch embeds (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
-        G = hip.gemm_problem
+        split = plan.split
+        packed = plan.packed
+
+        def G(A, W, C, **kw):  # weight in the format of the active precision mode
+            return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
+
+        def run(problems):
+            hip.gemm_grouped(problems, split_bf16=split)
+
+        def run1(A, W, C, **kw):
+            hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
+
         hip.chan_to_token(hidden_states, ws.xtok, B=B, C=C_in, N=Nx, ldo=C_in)
         hip.chan_to_token(conditioning_tensors, ws.ctok, B=B, C=Cc, N=Nc, ldo=Cc)
-        hip.gemm_grouped([
-            G(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias),
-            G(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
+        hip.gemm_grouped([  # K = 84: fp32 path in both modes (tiny, K not a multiple of 8)
+            hip.gemm_problem(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias),
+            hip.gemm_problem(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
         ])
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
@@ -427,11 +466,11 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.timestep_embedding(timestep, ws.tsin, Bt)
         hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
         self._combined_embed(ref.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb_r)
-        hip.gemm_sk(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
+        run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps)
-            hip.gemm_sk(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            run1(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
             self._attention(ws, B, Nc, Nx, ws.qkv, ws.att[:, Nx:], D, SD)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
@@ -439,8 +478,8 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
-            hip.gemm_sk(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
-            hip.gemm_sk(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
+            run1(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
+            run1(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
                         gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD)
 
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
@@ -460,7 +499,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.linear_small(ws.temb, blk.norm1_context.linear.weight, mc, rows=B, N=6 * D, K=D, bias=blk.norm1_context.linear.bias, act_in=hip.ACT_SILU)
             hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=6 * D, mode=0, eps=1e-6)
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=6 * D, mode=0, eps=1e-6)
-            hip.gemm_grouped([
+            run([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c),
             ])
@@ -468,7 +507,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)
             self._attention(ws, B, S, 0, ws.qkv, ws.att, D, SD)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
-            hip.gemm_grouped([
+            run([
                 G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=6 * D, R=h_x, ldr=D, r_bs=SD),
                 G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=6 * D, R=h_c, ldr=D, r_bs=SD),
             ])
@@ -482,8 +521,8 @@ class LaDCastTransformer3DModel(ModelMixin):
                 up.append(G(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH))
                 down.append(G(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
                               gate=mod[:, 5 * D :], gate_bs=6 * D, R=hs, ldr=D, r_bs=SD))
-            hip.gemm_grouped(up)
-            hip.gemm_grouped(down)
+            run(up)
+            run(down)
 
         # 5. single-stream blocks, models/LaDCast_3D_model.py:426-468
         for blk in self.single_transformer_blocks:
@@ -493,20 +532,20 @@ class LaDCastTransformer3DModel(ModelMixin):
             W5 = D + F
             hip.linear_small(ws.temb, blk.norm.linear.weight, mod, rows=B, N=3 * D, K=D, bias=blk.norm.linear.bias, act_in=hip.ACT_SILU)
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=3 * D, mode=0, eps=1e-6)
-            hip.gemm_grouped([
+            run([
                 G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
             ])
             self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
             self._attention(ws, B, S, 0, ws.qkv, ws.cat, W5, S * W5)
-            hip.gemm_sk(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
+            run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=3 * D, R=ws.h, ldr=D, r_bs=SD)
 
         # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
         hip.linear_small(ws.temb, self.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=self.norm_out.linear.bias, act_in=hip.ACT_SILU)
         hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=ws.mod_a, shift=ws.mod_a[:, D:], mod_bs=2 * D, mode=0, eps=1e-7)
-        hip.gemm_sk(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
+        run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
 

@@ -87,6 +87,46 @@ def test_tiny_sampler_chunk_matches_oracle(tiny_pair, sampler_type):
     assert rel_l2(part.cpu(), got[2:3].cpu()) < 1e-5
 
 
+def test_bf16x3_mode_stays_inside_the_parity_budget(tiny_pair):
+    """split-bf16 GEMM mode: per-forward and per-chunk rel-L2 vs the fp32 CPU oracle.  Budget: 1e-4 (north star);
+    measured on CPU emulation: 4e-6 / 2e-6 (tools/split_precision_study.py)."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o, g = tiny_pair
+    g.set_gemm_precision("bf16x3")
+    try:
+        x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+        known, ts = synth_known(1), torch.tensor([2018010100])
+        with torch.no_grad():
+            want = o(x, torch.tensor([0.3]), known.expand(2, -1, -1, -1, -1), time_elapsed=ts).sample
+        got = g(x.cuda(), torch.tensor([0.3]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
+        e_fwd = rel_l2(got.cpu(), want)
+        assert e_fwd < 3e-5, e_fwd
+        opipe = OP.AutoRegressive2DPipeline(o, OracleScheduler())
+        want = OP.ensemble_AR_sampler(opipe, 2, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm")
+        gpipe = AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())
+        got = ensemble_AR_sampler(gpipe, 2, 4, 20, known_latents=known.cuda(), timestamps=ts.cuda(), sampler_type="edm", device="cuda")
+        e_chunk = rel_l2(got.cpu(), want)
+        print(f"bf16x3: forward rel-L2 {e_fwd:.2e}, 20-step Heun chunk rel-L2 {e_chunk:.2e}")
+        assert e_chunk < TOL, e_chunk
+    finally:
+        g.set_gemm_precision("fp32")
+
+
+def test_full_375m_forward_bf16x3():
+    o = make_ar(dict(CONFIG_375M))
+    g = to_hip(o, dict(CONFIG_375M)).set_gemm_precision("bf16x3")
+    x = torch.randn(1, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+    known, ts = synth_known(1), torch.tensor([2018010100])
+    with torch.no_grad():
+        want = o(x, torch.tensor([0.3]), known, time_elapsed=ts).sample
+    got = g(x.cuda(), torch.tensor([0.3]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
+    e = rel_l2(got.cpu(), want)
+    print(f"375M bf16x3 forward rel-L2 {e:.2e}")
+    assert e < 3e-5, e
+
+
 def test_scheduler_indexing_is_bit_exact():
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 

@@ -101,6 +101,46 @@ def test_gemm_streamk_grouped_with_epilogues(hip):
     assert torch.equal(c1, c2)
 
 
+def _bf16_split(x):
+    hi = x.bfloat16().float()
+    lo = (x - hi).bfloat16().float()
+    return hi.double(), lo.double()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(128, 128, 32, 1), (2250, 1536, 1536, 1), (450, 84, 1536, 2), (37, 200, 264, 3), (2250, 1536, 7680, 1), (1, 5, 8, 1)])
+def test_gemm_bf16x3(hip, M, N, K, batch):
+    """split-bf16 GEMM: (a) equals its own definition Ah.Wh + Ah.Wl + Al.Wh almost exactly (only fp32 accumulation
+    order differs), (b) is within 1e-5 rel-L2 of the exact product (vs 2e-3 for plain bf16)."""
+    A, W, b = rnd(batch, M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    Wp = hip.pack_weight_bf16x2(dev(W))
+    C = torch.full((batch, M, N), float("nan"), device="cuda")
+    hip.gemm_sk(dev(A), Wp, C, split_bf16=True, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b))
+    ah, al = _bf16_split(A)
+    wh, wl = _bf16_split(W)
+    defn = ah @ wh.T + ah @ wl.T + al @ wh.T + b.double()
+    exact = A.double() @ W.double().T + b.double()
+    assert torch.isfinite(C).all()
+    assert rel(C, defn) < 1e-6
+    assert rel(C, exact) < 1e-5
+
+
+def test_gemm_bf16x3_grouped_epilogue(hip):
+    specs = [(1800, 1536, 1536, 2, 2), (450, 1536, 1536, 2, 1), (300, 264, 136, 1, 0)]
+    probs, checks = [], []
+    for i, (M, N, K, B, act) in enumerate(specs):
+        A, W, b = rnd(B, M, K, seed=10 + i), rnd(N, K, seed=20 + i) / math.sqrt(K), rnd(N, seed=30 + i)
+        gate, res = rnd(B, N, seed=40 + i), rnd(B, M, N, seed=50 + i)
+        Cd = dev(res.clone())
+        probs.append(hip.gemm_problem(dev(A), hip.pack_weight_bf16x2(dev(W)), Cd, M=M, N=N, K=K, batch=B, a_bs=M * K, c_bs=M * N, bias=dev(b),
+                                      gate=dev(gate), gate_bs=N, R=Cd, ldr=N, r_bs=M * N, act=act))
+        v = A.double() @ W.double().T + b.double()
+        v = [v, F.silu(v), F.gelu(v, approximate="tanh")][act]
+        checks.append((Cd, res.double() + v * gate[:, None, :].double()))
+    hip.gemm_grouped(probs, split_bf16=True)
+    for Cd, want in checks:
+        assert rel(Cd, want) < 1e-5
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a = torch.zeros(8, 6, device="cuda")
     with pytest.raises(RuntimeError):

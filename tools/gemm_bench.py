@@ -17,7 +17,9 @@ for (M,N,K) in shapes:
     A = torch.randn(M,K,device="cuda"); W = torch.randn(N,K,device="cuda"); C = torch.empty(M,N,device="cuda")
     ms = time_it(lambda: hip.gemm(A,W,C,M=M,N=N,K=K))
     ms2 = time_it(lambda: hip.gemm_sk(A,W,C,M=M,N=N,K=K))
-    print(f"gemm M={M:6d} N={N:5d} K={K:5d}: tile-per-WG {ms*1e3:9.1f} us {2*M*N*K/ms/1e9:7.1f} TF/s | stream-K {ms2*1e3:9.1f} us {2*M*N*K/ms2/1e9:7.1f} TF/s  tiles={((M+127)//128)*((N+127)//128)}")
+    Wp = hip.pack_weight_bf16x2(W)
+    ms3 = time_it(lambda: hip.gemm_sk(A,Wp,C,split_bf16=True,M=M,N=N,K=K))
+    print(f"gemm M={M:6d} N={N:5d} K={K:5d}: tile-per-WG {ms*1e3:8.1f} us {2*M*N*K/ms/1e9:6.1f} TF/s | stream-K fp32 {ms2*1e3:8.1f} us {2*M*N*K/ms2/1e9:6.1f} TF/s | stream-K bf16x3 {ms3*1e3:8.1f} us {2*M*N*K/ms3/1e9:6.1f} TF/s  tiles={((M+127)//128)*((N+127)//128)}")
 for (B,S,H) in [(1,2250,12),(1,450,12),(2,2250,12),(8,2250,12),(1,2250,16)]:
     D=H*128
     qkv = torch.randn(B,S,3*D,device="cuda"); O = torch.empty(B,S,D,device="cuda")
