@@ -141,6 +141,32 @@ def test_gemm_bf16x3_grouped_epilogue(hip):
         assert rel(Cd, want) < 1e-5
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_streamk_handoff_stress(hip, split):
+    """In-launch owner/piece hand-off under changing data: back-to-back calls on shapes whose ranges split almost every
+    tile, with NEW inputs each time (so a stale slab or a lost arrival would show as a mismatch), checking every word,
+    interleaved with a different-shaped call that re-uses the same workspace slots.  The status word must stay 0."""
+    shapes = [(2250, 1536, 1536), (450, 1536, 6144), (1800, 4608, 1536), (2250, 1536, 7680)]
+    Ws = {}
+    for (M, N, K) in shapes:
+        W = rnd(N, K, seed=K + N) / math.sqrt(K)
+        Ws[(M, N, K)] = (W, hip.pack_weight_bf16x2(dev(W)) if split else dev(W))
+    tol = 1e-5 if split else 2e-6
+    for it in range(12):
+        M, N, K = shapes[it % len(shapes)]
+        W, Wd = Ws[(M, N, K)]
+        A = rnd(M, K, seed=100 + it)
+        C = torch.full((M, N), float("nan"), device="cuda")
+        hip.gemm_sk(dev(A), Wd, C, split_bf16=split, M=M, N=N, K=K)
+        got = C.cpu().double()
+        want = A.double() @ W.double().T
+        assert torch.isfinite(got).all(), it
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < 50 * tol, (it, err)  # every word, max-norm
+        assert rel(C, want) < tol, it
+    assert hip.gemm_grouped_status() == 0
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a = torch.zeros(8, 6, device="cuda")
     with pytest.raises(RuntimeError):
