@@ -64,15 +64,11 @@ int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const f
 
 /* Same contraction for up to LDC_GEMM_MAX_PROBLEMS independent problems in ONE persistent launch
  * with stream-K scheduling (work = (tile, 32-deep k-step) units cut into equal contiguous ranges,
- * 2 co-resident workgroups per CU; tiles whose K range is split are finished in-launch by their owner
- * workgroup).  Built for the small grids of the AR transformer (e.g. the pred- and cond-stream
- * projections of a dual block, models/LaDCast_3D_model.py:92-94,175-177,558-563).
- * `workspace`: caller-owned device scratch of at least ldc_gemm_grouped_workspace_bytes() bytes,
- * 16-byte aligned, initialised ONCE with ldc_gemm_grouped_workspace_init and then reused by every call
- * on the same stream (one workspace per stream; its first 4 KiB hold arrival counters that each call
- * leaves zeroed, word 512 is a sticky status: non-zero = a bounded wait timed out).
- * C of one problem must not overlap A/R of another problem of the same call.  The kernel assumes
- * it has the device to itself (all its workgroups co-resident). */
+ * 2 workgroups per CU) plus a fix-up launch for the tiles whose K range was split.  Built for the
+ * small grids of the AR transformer (e.g. the pred- and cond-stream projections of a dual block,
+ * models/LaDCast_3D_model.py:92-94,175-177,558-563).  `workspace` is caller-owned device scratch of
+ * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned); contents are undefined after
+ * the call.  C of one problem must not overlap A/R of another problem of the same call. */
 #define LDC_GEMM_MAX_PROBLEMS 4
 typedef struct ldc_gemm_problem {
   const float* A;
@@ -85,7 +81,6 @@ typedef struct ldc_gemm_problem {
 } ldc_gemm_problem;
 int ldc_sizeof_gemm_problem(void);
 long long ldc_gemm_grouped_workspace_bytes(void);
-int ldc_gemm_grouped_workspace_init(void* workspace, long long workspace_bytes, void* stream);
 int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                      void* stream);
 

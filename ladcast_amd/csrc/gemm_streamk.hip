@@ -9,18 +9,11 @@
 // equal contiguous ranges, G = 2 workgroups per CU, so every CU gets the same number of MFMAs and
 // two waves per SIMD cover each other's staging stalls.
 //
-// A workgroup whose range covers a tile's full K applies the epilogue directly.  A split tile is
-// finished by its OWNER = the workgroup holding the tile's first k-step (always that workgroup's last
-// segment): every other piece (always the first segment of a later workgroup, so it is computed
-// at once and depends on nothing) stores its raw accumulators to a workspace slot and arrives on
-// the owner's counter; the owner keeps its own accumulators in registers, waits for the arrivals,
-// adds the slots in workgroup order and runs the epilogue.  Hand-off = the placement-independent
-// agent-scope release/acquire recipe of cdna_hip_programming.md Guideline 16 (plain slab stores ->
-// every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 release fence + asm vmcnt(0) + relaxed atomic
-// add; owner: relaxed poll -> acquire fence -> vmcnt(0) -> barrier -> plain loads).  All G <= 2/CU
-// workgroups are co-resident (grid sized from the occupancy query) and a piece never waits, so
-// there are no wait chains; the spin is bounded and reports through a status word.  The schedule
-// is a pure function of (U, G): results are deterministic.
+// A workgroup whose range covers a tile's full K applies the epilogue directly.  Otherwise it
+// stores its raw accumulators to a caller-provided workspace slot (<= 2 slots per workgroup) and
+// a second tiny kernel -- after a plain kernel boundary, so no in-launch inter-workgroup
+// hand-off is needed -- sums the slots of each split tile in fixed order and runs the same
+// epilogue.  Both kernels derive the schedule from (U, G) alone; results are deterministic.
 #include <math.h>
 
 #include "common.h"
@@ -52,12 +45,8 @@ struct SKArgs {
   int G;
   long long U;
   long long tiles;
-  float* ws;        // G slots of SLOT_FLOATS
-  unsigned* ctrl;   // [0..511] arrival counters (indexed by owner workgroup), [512] status word
+  float* ws;
 };
-
-constexpr int CTRL_BYTES = 4096;
-constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ long long range_start(long long g, long long U, int G) { return (g * U) / G; }
 
@@ -97,73 +86,6 @@ __device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u
   for (int k = 1; k < MAXP; ++k)
     if (k < a.np && u >= a.pr[k].unit0) pi = k;
   return pi;
-}
-
-// workgroup whose range holds global unit f
-__device__ __forceinline__ long long owner_of_unit(long long f, long long U, int G) {
-  long long g0 = (f * G) / U;
-  while (g0 + 1 < G && range_start(g0 + 1, U, G) <= f) ++g0;
-  while (g0 > 0 && range_start(g0, U, G) > f) --g0;
-  return g0;
-}
-
-// Finish one segment [k0, k1) of a tile: direct epilogue, publish a piece, or (owner) gather + epilogue.
-__device__ __forceinline__ void finish_segment(const SKArgs& a, const DevProblem& P, int g, int tile, int k0, int k1, int b,
-                                               int bm, int bn, f32x16 (&acc)[2][2], int wave, int wm, int wn, int lane) {
-  if (k0 == 0 && k1 == P.kt) {
-    tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
-    return;
-  }
-  const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;  // tile's first global unit
-  if (k0 > 0) {
-    // a piece: raw accumulators, lane-contiguous: slot[(wave*4 + i*2 + j)*16 + r][lane]
-    float* slot = a.ws + static_cast<long long>(g) * SLOT_FLOATS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)  // write-through (sc1) stores: no L2 write-back fence needed (Guideline 16, R1)
-          __hip_atomic_store(slot + ((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores ...
-    __syncthreads();                                    // ... before ONE lane signals for all of them
-    if (threadIdx.x == 0) {
-      const long long owner = owner_of_unit(f, a.U, a.G);
-      __hip_atomic_fetch_add(a.ctrl + owner, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  // owner: k0 == 0, k1 < kt.  Pieces come from workgroups g+1 .. g_last (each its first segment).
-  const long long l = f + P.kt;
-  int g_last = g;
-  while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
-  const unsigned pieces = static_cast<unsigned>(g_last - g);
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(a.ctrl + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pieces) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > SPIN_LIMIT) {
-        __hip_atomic_store(a.ctrl + 512, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // report, do not hang
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  for (int gp = g + 1; gp <= g_last; ++gp) {
-    const float* slot = a.ws + static_cast<long long>(gp) * SLOT_FLOATS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
-        if (j == 1) __builtin_amdgcn_sched_barrier(0);  // at most 32 slab loads in flight (register pressure)
-      }
-  }
-  tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
-  if (threadIdx.x == 0) __hip_atomic_store(a.ctrl + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(SKArgs a) {
@@ -263,7 +185,18 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(SKArgs a) {
       __syncthreads();
     }
 
-    finish_segment(a, P, g, tile, k0, k1, b, bm, bn, acc, wave, wm, wn, lane);
+    if (k0 == 0 && k1 == P.kt) {
+      tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
+    } else {
+      // raw accumulators, lane-contiguous: slot[(wave*4 + i*2 + j)*16 + r][lane]
+      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
     u += k1 - k0;
   }
 }
@@ -445,7 +378,17 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_bf16x3_kernel(SKArgs a) {
       __syncthreads();
     }
 
-    finish_segment(a, P, g, tile, k0, k1, b, bm, bn, acc, wave, wm, wn, lane);
+    if (k0 == 0 && k1 == P.kt) {
+      tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
+    } else {
+      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
     u += k1 - k0;
   }
 }
@@ -464,31 +407,58 @@ __global__ __launch_bounds__(256) void pack_weight_bf16x2_kernel(const float* __
   out[idx * 2 + 1] = l;
 }
 
+// one workgroup per output tile; tiles that one range covered completely were finished above
+__global__ __launch_bounds__(256) void gemm_streamk_fixup_kernel(SKArgs a) {
+  const long long t = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < MAXP; ++k)
+    if (k < a.np && t >= a.pr[k].tile0) pi = k;
+  const DevProblem& P = a.pr[pi];
+  const int tile = static_cast<int>(t - P.tile0);
+  const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;  // tile's first unit
+  const long long l = f + P.kt;
+  long long g0 = (f * a.G) / a.U;
+  while (g0 + 1 < a.G && range_start(g0 + 1, a.U, a.G) <= f) ++g0;
+  while (g0 > 0 && range_start(g0, a.U, a.G) > f) --g0;
+  if (range_start(g0 + 1, a.U, a.G) >= l) return;  // a single range holds the whole tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (long long g = g0; g < a.G; ++g) {
+    const long long s = range_start(g, a.U, a.G), e = range_start(g + 1, a.U, a.G);
+    if (s >= l) break;
+    const long long ob = s > f ? s : f, oe = e < l ? e : l;
+    if (oe <= ob) continue;
+    const float* slot = a.ws + (2 * g + (ob > f ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
+  }
+  const int bn = tile % P.tn;
+  const int bmb = tile / P.tn;
+  tile_epilogue(P, bmb / P.tm, bmb % P.tm, bn, acc, wm, wn, lane);
+}
+
 }  // namespace
 
 extern "C" int ldc_sizeof_gemm_problem(void) { return static_cast<int>(sizeof(ldc_gemm_problem)); }
 
 extern "C" long long ldc_gemm_grouped_workspace_bytes(void) {
-  // control block + 1 slot per workgroup, 2 workgroups per CU on a 256-CU MI355X
-  return CTRL_BYTES + 512LL * SLOT_FLOATS * static_cast<long long>(sizeof(float));
-}
-
-extern "C" int ldc_gemm_grouped_workspace_init(void* workspace, long long workspace_bytes, void* stream) {
-  LDC_CHECK_PTR(workspace);
-  if (workspace_bytes < CTRL_BYTES) return LDC_ERR_ARG;
-  hipError_t e = hipMemsetAsync(workspace, 0, CTRL_BYTES, static_cast<hipStream_t>(stream));
-  return e == hipSuccess ? LDC_OK : -(1000 + static_cast<int>(e));
-}
-
-// resident workgroups the device admits for the kernel (co-residency is what makes the owner wait safe)
-template <typename K>
-static int resident_workgroups(K kernel, size_t lds) {
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) return 0;
-  if (per_cu > 2) per_cu = 2;
-  return cus * per_cu;
+  // 2 slots per workgroup, 2 workgroups per CU on a 256-CU MI355X
+  return 2LL * 512 * SLOT_FLOATS * static_cast<long long>(sizeof(float));
 }
 
 static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
@@ -529,21 +499,7 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
   }
   if (tiles > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
-  const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
-  static int resident[2] = {0, 0};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(2 * STAGE_FLOATS * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_bf16x3_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES_B);
-    resident[0] = resident_workgroups(gemm_streamk_kernel, 2 * STAGE_FLOATS * sizeof(float));
-    resident[1] = resident_workgroups(gemm_streamk_bf16x3_kernel, 2 * STAGE_BYTES_B);
-    attr_set = true;
-  }
-  long long G = resident[split_bf16 ? 1 : 0];
-  if (G < 1) return LDC_ERR_UNSUPPORTED;
-  if (G > 512) G = 512;
+  long long G = 512;
   {
     // Balance k-steps per workgroup against slabs per split tile: time ~ (U/G) t_unit + (kt G/U) t_slab is
     // smallest at U/G = sqrt(kt t_slab / t_unit); t_slab / t_unit ~ 2 (fp32 units) or ~ 7 (bf16x3 units).
@@ -554,20 +510,33 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
     if (gmax < G) G = gmax;
   }
   if (U < G) G = U;
-  if (workspace == nullptr || workspace_bytes < CTRL_BYTES + slot_bytes) return LDC_ERR_ARG;
-  {
-    const long long fit = (workspace_bytes - CTRL_BYTES) / slot_bytes;  // one slot per workgroup
+  if (workspace == nullptr || workspace_bytes < 2 * G * slot_bytes) {
+    // not enough scratch for 2 slots per workgroup: shrink the grid to what fits (>= 1 tile-complete fallback)
+    const long long fit = workspace ? workspace_bytes / (2 * slot_bytes) : 0;
+    if (fit < 1) return LDC_ERR_ARG;
     if (fit < G) G = fit;
   }
   LDC_CHECK_ALIGN16(workspace);
   a.G = static_cast<int>(G);
   a.U = U;
   a.tiles = tiles;
-  a.ctrl = static_cast<unsigned*>(workspace);
-  a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + CTRL_BYTES);
+  a.ws = static_cast<float*>(workspace);
+  const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(2 * STAGE_FLOATS * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_bf16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES_B);
+    attr_set = true;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (split_bf16) hipLaunchKernelGGL(gemm_streamk_bf16x3_kernel, dim3(a.G), dim3(256), lds, s, a);
   else hipLaunchKernelGGL(gemm_streamk_kernel, dim3(a.G), dim3(256), lds, s, a);
+  int st = ldc_launch_status();
+  if (st != LDC_OK) return st;
+  // some tile is split whenever the ranges are not tile-aligned; the fix-up exits at once for whole tiles
+  hipLaunchKernelGGL(gemm_streamk_fixup_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, a);
   return ldc_launch_status();
 }
 

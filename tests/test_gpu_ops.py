@@ -143,9 +143,9 @@ def test_gemm_bf16x3_grouped_epilogue(hip):
 
 @pytest.mark.parametrize("split", [False, True])
 def test_streamk_handoff_stress(hip, split):
-    """In-launch owner/piece hand-off under changing data: back-to-back calls on shapes whose ranges split almost every
-    tile, with NEW inputs each time (so a stale slab or a lost arrival would show as a mismatch), checking every word,
-    interleaved with a different-shaped call that re-uses the same workspace slots.  The status word must stay 0."""
+    """Split-tile slabs under changing data: back-to-back calls on shapes whose ranges split almost every tile, with NEW
+    inputs each time (a stale slab would show as a mismatch), checking every word, interleaved with different-shaped
+    calls that re-use the same workspace slots."""
     shapes = [(2250, 1536, 1536), (450, 1536, 6144), (1800, 4608, 1536), (2250, 1536, 7680)]
     Ws = {}
     for (M, N, K) in shapes:
@@ -164,7 +164,6 @@ def test_streamk_handoff_stress(hip, split):
         err = (got - want).abs().max().item() / want.abs().max().item()
         assert err < 50 * tol, (it, err)  # every word, max-norm
         assert rel(C, want) < tol, it
-    assert hip.gemm_grouped_status() == 0
 
 
 def test_gemm_rejects_bad_arguments(hip):
