@@ -67,8 +67,10 @@ int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const f
  * 2 workgroups per CU) plus a fix-up launch for the tiles whose K range was split.  Built for the
  * small grids of the AR transformer (e.g. the pred- and cond-stream projections of a dual block,
  * models/LaDCast_3D_model.py:92-94,175-177,558-563).  `workspace` is caller-owned device scratch of
- * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned); contents are undefined after
- * the call.  C of one problem must not overlap A/R of another problem of the same call. */
+ * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned), initialised ONCE with
+ * ldc_gemm_grouped_workspace_init (zeroes the tile-arrival counters in its first MiB; every call
+ * leaves them zero) and then reused by the calls of ONE stream.  C of one problem must not overlap
+ * A/R of another problem of the same call. */
 #define LDC_GEMM_MAX_PROBLEMS 4
 typedef struct ldc_gemm_problem {
   const float* A;
@@ -81,6 +83,7 @@ typedef struct ldc_gemm_problem {
 } ldc_gemm_problem;
 int ldc_sizeof_gemm_problem(void);
 long long ldc_gemm_grouped_workspace_bytes(void);
+int ldc_gemm_grouped_workspace_init(void* workspace, long long workspace_bytes, void* stream);
 int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                      void* stream);
 

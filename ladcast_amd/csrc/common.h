@@ -5,6 +5,9 @@
 
 #include "../../include/ladcast_hip.h"
 
+// stream-K workspace layout: [counter block (zeroed once, every call leaves it zero)][partial-sum slabs]
+#define LDC_GEMM_COUNTER_BYTES (1 << 20)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

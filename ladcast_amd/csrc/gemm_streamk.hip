@@ -15,6 +15,8 @@
 // hand-off is needed -- sums the slots of each split tile in fixed order and runs the same
 // epilogue.  Both kernels derive the schedule from (U, G) alone; results are deterministic.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -457,8 +459,15 @@ __global__ __launch_bounds__(256) void gemm_streamk_fixup_kernel(SKArgs a) {
 extern "C" int ldc_sizeof_gemm_problem(void) { return static_cast<int>(sizeof(ldc_gemm_problem)); }
 
 extern "C" long long ldc_gemm_grouped_workspace_bytes(void) {
-  // 2 slots per workgroup, 2 workgroups per CU on a 256-CU MI355X
-  return 2LL * 512 * SLOT_FLOATS * static_cast<long long>(sizeof(float));
+  // counter block + 2 slabs per workgroup, 2 workgroups per CU on a 256-CU MI355X
+  return LDC_GEMM_COUNTER_BYTES + 2LL * 512 * SLOT_FLOATS * static_cast<long long>(sizeof(float));
+}
+
+extern "C" int ldc_gemm_grouped_workspace_init(void* workspace, long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(workspace);
+  if (workspace_bytes < LDC_GEMM_COUNTER_BYTES) return LDC_ERR_ARG;
+  hipError_t e = hipMemsetAsync(workspace, 0, LDC_GEMM_COUNTER_BYTES, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? LDC_OK : -(1000 + static_cast<int>(e));
 }
 
 static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
@@ -510,17 +519,16 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
     if (gmax < G) G = gmax;
   }
   if (U < G) G = U;
-  if (workspace == nullptr || workspace_bytes < 2 * G * slot_bytes) {
-    // not enough scratch for 2 slots per workgroup: shrink the grid to what fits (>= 1 tile-complete fallback)
-    const long long fit = workspace ? workspace_bytes / (2 * slot_bytes) : 0;
-    if (fit < 1) return LDC_ERR_ARG;
-    if (fit < G) G = fit;
+  if (workspace == nullptr || workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2 * slot_bytes) return LDC_ERR_ARG;
+  {
+    const long long fit = (workspace_bytes - LDC_GEMM_COUNTER_BYTES) / (2 * slot_bytes);
+    if (fit < G) G = fit;  // not enough scratch for 2 slabs per workgroup: shrink the grid to what fits
   }
   LDC_CHECK_ALIGN16(workspace);
   a.G = static_cast<int>(G);
   a.U = U;
   a.tiles = tiles;
-  a.ws = static_cast<float*>(workspace);
+  a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -545,8 +553,21 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, false);
 }
 
+int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                                void* stream);  // gemm_bf16x3_dma.hip
+
 extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace,
                                        long long workspace_bytes, void* stream) {
+  // LDS-DMA ring kernel (256x128 tile) when every K is a multiple of 32, else the register-staged kernel.
+  // LDC_BF16X3_KERNEL=regstage forces the latter (A/B measurements).
+  static const bool force_v1 = [] {
+    const char* e = getenv("LDC_BF16X3_KERNEL");
+    return e != nullptr && strcmp(e, "regstage") == 0;
+  }();
+  if (!force_v1) {
+    const int st = ldc_gemm_grouped_bf16x3_dma(problems, n, workspace, workspace_bytes, stream);
+    if (st != LDC_ERR_UNSUPPORTED) return st;
+  }
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, true);
 }
 

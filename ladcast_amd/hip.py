@@ -51,6 +51,7 @@ def _load():
         "ldc_gemm_bias_act": (I, [P, P, P, P, P, P, POINTER(GemmDesc), P]),
         "ldc_sizeof_gemm_problem": (I, []),
         "ldc_gemm_grouped_workspace_bytes": (L, []),
+        "ldc_gemm_grouped_workspace_init": (I, [P, L, P]),
         "ldc_gemm_grouped": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_gemm_grouped_bf16x3": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
@@ -130,8 +131,11 @@ _grouped_ws = {}
 
 def _grouped_workspace(device):
     key = str(device)
+    key = (key, torch.cuda.current_stream(device).cuda_stream)  # one workspace per (device, stream)
     if key not in _grouped_ws:
-        _grouped_ws[key] = torch.empty(lib.ldc_gemm_grouped_workspace_bytes() // 4, device=device, dtype=torch.float32)
+        ws = torch.empty(lib.ldc_gemm_grouped_workspace_bytes() // 4, device=device, dtype=torch.float32)
+        _check(lib.ldc_gemm_grouped_workspace_init(c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped_workspace_init")
+        _grouped_ws[key] = ws
     return _grouped_ws[key]
 
 

@@ -166,6 +166,23 @@ def test_streamk_handoff_stress(hip, split):
         assert rel(C, want) < tol, it
 
 
+def test_gemm_bf16x3_inlaunch_reduction_is_deterministic_and_rearmed(hip):
+    """The last-arriver reduction re-reads every slab in fixed order: repeated launches are bitwise identical, and the
+    arrival counters are back to zero after every call (checked through the workspace)."""
+    M, N, K = 2250, 1536, 7680
+    A, W = dev(rnd(M, K, seed=1)), rnd(N, K, seed=2) / math.sqrt(K)
+    Wp = hip.pack_weight_bf16x2(dev(W))
+    outs = []
+    for _ in range(4):
+        C = torch.empty(M, N, device="cuda")
+        hip.gemm_sk(A, Wp, C, split_bf16=True, M=M, N=N, K=K)
+        outs.append(C)
+    for c in outs[1:]:
+        assert torch.equal(outs[0], c)
+    ws = hip._grouped_workspace(A.device)
+    assert int(ws.view(torch.int32)[: (1 << 20) // 4].abs().sum().item()) == 0
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a = torch.zeros(8, 6, device="cuda")
     with pytest.raises(RuntimeError):
