@@ -90,7 +90,8 @@ class KernelTimer:
             s.record()
             timer._orig["attn_fwd"](Q, K, V, O, **kw)
             e.record()
-            timer.records.setdefault("attn_fwd_f32_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
+            name = "attn_fwd_bf16x3_kernel" if kw.get("split_bf16") else "attn_fwd_f32_kernel"
+            timer.records.setdefault(name, []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
         hip.gemm, hip.attn_fwd, hip.gemm_grouped = gemm, attn_fwd, gemm_grouped
 
@@ -143,7 +144,8 @@ def main():
     ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = DPM-Solver++(2M), N forwards")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per model forward instead of launching from Python (same speed on this host)")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="token-stream GEMM arithmetic: exact fp32 MFMA, or split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate)")
     args = ap.parse_args()
 
@@ -172,6 +174,7 @@ def main():
     cfg = CONFIGS[args.model]
     torch.manual_seed(1234)
     model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval().set_gemm_precision(args.precision)
+    model.enable_hip_graph(args.graph)
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     m = args.members_per_gpu
     from ladcast_amd.pipelines.distributed import shard_members

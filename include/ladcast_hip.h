@@ -117,6 +117,11 @@ int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bi
 int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
                  int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
 
+/* Same contract on the bf16 matrix cores with split-bf16 operands (Q.K^T and P.V each evaluated as
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation; error ~1e-6 rel-L2 vs ldc_attn_fwd). */
+int ldc_attn_fwd_bf16x3(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
+                        int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
+
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),
  * for token rows [row0, row0+rows) of every batch of a fused QKV buffer.

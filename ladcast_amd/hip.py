@@ -57,6 +57,7 @@ def _load():
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
+        "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
@@ -182,9 +183,10 @@ def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_r
                                 rows, N, K, act_in, act_out, _stream()), "ldc_linear_small")
 
 
-def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs):
+def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False):
     _dev(Q, K, V, O)
-    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd")
+    fn = lib.ldc_attn_fwd_bf16x3 if split_bf16 else lib.ldc_attn_fwd
+    _check(fn(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd" + ("_bf16x3" if split_bf16 else ""))
 
 
 def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, sin=None):

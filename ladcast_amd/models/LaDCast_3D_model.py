@@ -250,17 +250,31 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._ws = {}
         self._rope = {}
         self._te_cache = None
+        self._te_buf = {}
+        self._graphs = {}
+        self.use_hip_graph = False
         self.gemm_precision = "fp32"
+
+    def enable_hip_graph(self, flag: bool = True):
+        """Capture the ~110 kernel launches of one forward into a hipGraph per input shape and replay it
+        (the launches are otherwise host-bound: ~8 us of Python per launch against 5-15 us kernels).
+        Inputs are copied into static buffers; the returned sample is a fresh tensor."""
+        self.use_hip_graph = bool(flag)
+        if not flag:
+            self._graphs = {}
+        return self
 
     def set_gemm_precision(self, mode: str):
         """"fp32": exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  "bf16x3": split-bf16 error-compensated
         contraction on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate), ~4e-6 rel-L2 per
-        forward vs fp32 -- see DESIGN.md section 4.  Token-stream GEMMs only; everything else stays fp32."""
+        forward vs fp32 -- see DESIGN.md section 4.  Applies to the token-stream GEMMs and both attention
+        contractions; softmax, norms, RoPE, modulation vectors and the sampler state stay fp32 / fp64."""
         if mode not in ("fp32", "bf16x3"):
             raise ValueError("gemm precision must be 'fp32' or 'bf16x3'")
         if mode != self.gemm_precision:
             self.gemm_precision = mode
             self._plan = None
+            self._graphs = {}
         return self
 
     # -- diffusers-style processor surface (models/LaDCast_3D_model.py:763-827) --------------
@@ -292,10 +306,13 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._ws = {}
         self._rope = {}
         self._te_cache = None
+        self._te_buf = {}
+        self._graphs = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._plan = None
+        self._graphs = {}
         return super().load_state_dict(*a, **k)
 
     @staticmethod
@@ -363,8 +380,9 @@ class LaDCastTransformer3DModel(ModelMixin):
         n, d2 = len(stamps), 2 * self.inner_dim
         emb = get_year_sincos_embedding(stamps, 256).to(dev)
         te = self.time_elapsed_embed
-        mid = torch.empty(n, d2, device=dev, dtype=torch.float32)
-        out = torch.empty(n, d2, device=dev, dtype=torch.float32)
+        if n not in self._te_buf:  # persistent buffers: a captured graph keeps reading the same addresses
+            self._te_buf[n] = (torch.empty(n, d2, device=dev, dtype=torch.float32), torch.empty(n, d2, device=dev, dtype=torch.float32))
+        mid, out = self._te_buf[n]
         hip.linear_small(emb, te.linear_1.weight, mid, rows=n, N=d2, K=256, bias=te.linear_1.bias, act_out=hip.ACT_SILU)
         hip.linear_small(mid, te.linear_2.weight, out, rows=n, N=d2, K=d2, bias=te.linear_2.bias)
         self._te_cache = (key, out, time_elapsed)  # keep the tensor alive so data_ptr cannot be recycled
@@ -388,7 +406,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         q = qkv[:, row0:, 0:D]
         k = qkv[:, row0:, D : 2 * D]
         v = qkv[:, row0:, 2 * D : 3 * D]
-        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs)
+        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs,
+                     split_bf16=self.gemm_precision == "bf16x3")
 
     def _qk_norm_rope(self, ws, B, row0, rows, norm_q, norm_k, cos, sin):
         D, H = self.inner_dim, self.config.num_attention_heads
@@ -431,6 +450,52 @@ class LaDCastTransformer3DModel(ModelMixin):
         Bt = timestep.shape[0]
         if Bt not in (1, B):
             raise ValueError(f"timestep must have 1 or {B} entries, got {Bt}")
+        te = None
+        if time_elapsed is not None and self.time_elapsed_embed is not None:
+            te = self._time_elapsed_embedding(time_elapsed, dev)  # eager, cached per chunk; never inside a capture
+            if te.shape[0] not in (1, B):
+                raise ValueError("time_elapsed must have 1 or batch entries")
+
+        if self.use_hip_graph:
+            gkey = (B, Bt, C_in, R, T_in, Hh, Ww, None if te is None else (te.data_ptr(), te.shape[0]))
+            ent = self._graphs.get(gkey)
+            if ent is None:
+                sx, st, sk = torch.empty_like(hidden_states), torch.empty_like(timestep), torch.empty_like(conditioning_tensors)
+                sx.copy_(hidden_states)
+                st.copy_(timestep)
+                sk.copy_(conditioning_tensors)
+                self._forward_device(sx, st, sk, te)  # warm-up on the side stream: workspaces, kernel attributes
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    sout = self._forward_device(sx, st, sk, te)
+                ent = (graph, sx, st, sk, sout)
+                self._graphs[gkey] = ent
+            graph, sx, st, sk, sout = ent
+            sx.copy_(hidden_states)
+            st.copy_(timestep)
+            sk.copy_(conditioning_tensors)
+            graph.replay()
+            out = sout.clone()
+        else:
+            out = self._forward_device(hidden_states, timestep, conditioning_tensors, te)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+    def _forward_device(self, hidden_states, timestep, conditioning_tensors, te):
+        """Kernel launches only (no host sync, no shape-dependent Python state): capturable into a hipGraph."""
+        plan = self._plan
+        dev = self.device
+        cfg = self.config
+        D, H = self.inner_dim, cfg.num_attention_heads
+        B, C_in, R, Hh, Ww = hidden_states.shape
+        T_in = conditioning_tensors.shape[2]
+        Cc = conditioning_tensors.shape[1]
+        Nx, Nc = R * Hh * Ww, T_in * Hh * Ww
+        S = Nx + Nc
+        C_out = cfg.out_channels or cfg.in_channels
+        Bt = timestep.shape[0]
 
         key = (B, Bt, Nx, Nc)
         if key not in self._ws:
@@ -485,10 +550,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
         hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
         self._combined_embed(self.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb)
-        if time_elapsed is not None and self.time_elapsed_embed is not None:
-            te = self._time_elapsed_embedding(time_elapsed, dev)
-            if te.shape[0] not in (1, B):
-                raise ValueError("time_elapsed must have 1 or batch entries")
+        if te is not None:
             hip.temb_modulate(ws.temb, te, B=B, D=D, te_rows=te.shape[0])
 
         # 4. dual-stream blocks, models/LaDCast_3D_model.py:514-566
@@ -548,7 +610,4 @@ class LaDCastTransformer3DModel(ModelMixin):
         run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
-
-        if not return_dict:
-            return (out,)
-        return SimpleNamespace(sample=out)
+        return out

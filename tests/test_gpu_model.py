@@ -47,6 +47,24 @@ def test_tiny_forward_matches_oracle(tiny_pair, B, R, Bt):
     assert torch.equal(got, got2)  # deterministic, workspace reuse is clean
 
 
+def test_hip_graph_replay_is_bitwise_equal_to_eager(tiny_pair):
+    """hipGraph mode: one captured graph per input shape, replayed with new inputs (timestep, state, timestamp)."""
+    _, g = tiny_pair
+    known = synth_known(2).cuda()
+    outs = {}
+    for mode in (False, True):
+        g.enable_hip_graph(mode)
+        res = []
+        for i, (t, stamp) in enumerate([(0.3, 2018010100), (-0.7, 2018010100), (1.05, 2019063012)]):
+            x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(10 + i)).cuda()
+            res.append(g(x, torch.tensor([t]).cuda(), known, time_elapsed=torch.tensor([stamp]).cuda()).sample.clone())
+        outs[mode] = res
+    g.enable_hip_graph(False)
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[True][0], outs[True][1])
+
+
 def test_tiny_forward_matches_golden_pin(tiny_pair, golden_dir):
     """The committed pin (made by the oracle in the build container) must also be hit by the HIP path."""
     _, g = tiny_pair

@@ -206,6 +206,35 @@ def test_attention(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
 
 
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1)])
+def test_attention_bf16x3(hip, B, S, H):
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 4.0  # logits with std ~4: a sharp softmax, so errors in S are not washed out
+    d_qkv = dev(qkv)
+    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D,
+                 ldo=D + 64, o_bs=S * (D + 64), split_bf16=True)
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(out[:, :, :D]).all()
+    assert rel(out[:, :, :D], want) < 2e-5
+    assert torch.isnan(out[:, :, D:]).all()
+
+
+def test_attention_bf16x3_rescale_branch(hip):
+    S = 200
+    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
+    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0
+    d_qkv = dev(qkv)
+    out = torch.empty(1, S, 128, device="cuda")
+    hip.attn_fwd(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], out, B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, ldo=128, o_bs=S * 128,
+                 split_bf16=True)
+    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
+    assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
+
+
 def test_attention_online_softmax_rescale_branch(hip):
     """Force the running max to jump at a late key tile (a spiked key row) and force early tiles to be
     negligible: exercises the O/l rescale path and the skip-rescale fast path (guide rule 26)."""

@@ -37,6 +37,21 @@ def linear_split(x, w, b=None):
         y = y + b
     return y
 
+_orig_sdpa = F.scaled_dot_product_attention
+ATT = {"split": False}
+
+def sdpa_split(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False):
+    if not ATT["split"]:
+        return _orig_sdpa(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal)
+    qs = q * (q.shape[-1] ** -0.5)
+    qh, ql = split(qs); kh, kl = split(k); vh, vl = split(v)
+    s_ = qh @ kh.transpose(-1, -2) + qh @ kl.transpose(-1, -2) + ql @ kh.transpose(-1, -2)
+    pu = torch.exp(s_ - s_.amax(dim=-1, keepdim=True))
+    ph, pl = split(pu)
+    o = ph @ vh + ph @ vl + pl @ vh
+    return o / pu.sum(dim=-1, keepdim=True)
+
+F.scaled_dot_product_attention = sdpa_split
 F.linear = linear_split
 torch.nn.functional.linear = linear_split
 
@@ -45,17 +60,18 @@ def run(cfg, steps, members=1, R=4):
     known, ts = synth_known(1), torch.tensor([2018010100])
     x = torch.randn(members, 84, R, 15, 30, generator=torch.Generator().manual_seed(3))
     res = {}
-    for terms in (0, 3, 6, 1):
-        MODE["terms"] = terms
+    for terms in (0, 3, 6, 1, 33):
+        MODE["terms"] = 3 if terms == 33 else terms
+        ATT["split"] = terms == 33
         with torch.no_grad():
             t0 = time.time()
             f = m(x, torch.tensor([0.3]), known.expand(members, -1, -1, -1, -1), time_elapsed=ts).sample
             pipe = OP.AutoRegressive2DPipeline(m, EDMDPMSolverMultistepScheduler())
             s = OP.ensemble_AR_sampler(pipe, members, R, steps, known_latents=known, timestamps=ts, sampler_type="edm") if steps else None
             res[terms] = (f, s, time.time() - t0)
-    for terms in (3, 6, 1):
+    for terms in (3, 33, 6, 1):
         f, s, dt = res[terms]
-        msg = f"terms={terms}: forward rel-L2 {rel_l2(f, res[0][0]):.3e}"
+        msg = f"terms={terms}{' (GEMM+attention split)' if terms == 33 else ''}: forward rel-L2 {rel_l2(f, res[0][0]):.3e}"
         if s is not None:
             msg += f" | {steps}-step Heun chunk rel-L2 {rel_l2(s, res[0][1]):.3e}"
         print(msg, f"({dt:.0f}s)", flush=True)
