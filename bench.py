@@ -40,6 +40,7 @@ CONFIGS = {
 CONFIGS["1.6B"] = dict(CONFIGS["375M"], num_attention_heads=16, num_layers=5, num_single_layers=10, num_refiner_layers=3)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is never used)
 
 
 def model_flops_per_forward(cfg, R, T_in=1, hw=450):
@@ -70,10 +71,10 @@ class KernelTimer:
         self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped}
         timer = self
 
-        def gemm_grouped(problems):
+        def gemm_grouped(problems, split_bf16=False):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            timer._orig["gemm_grouped"](problems)
+            timer._orig["gemm_grouped"](problems, split_bf16=split_bf16)
             e.record()
             work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
             timer.records.setdefault("gemm_streamk_kernel", []).append((s, e, work))
@@ -226,38 +227,51 @@ def main():
         value = total_members * lead * args.steps / elapsed
         ks = timer.summary()
         roof = None
+        split = args.precision == "bf16x3"
         dom = "gemm_streamk_kernel" if "gemm_streamk_kernel" in ks else "gemm_nt_f32_kernel"
         if dom in ks:
             k = ks[dom]
+            kname = "gemm_bf16x3_dma_kernel" if split else dom
+            peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = dict(bound="mfma", kernel=dom, achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
+            roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s",
+                        frac=round(k["tflops"] / peak, 4), traffic=traffic, launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
                         flops_per_launch=k["work_per_launch"],
-                        note="one launch = one grouped stream-K GEMM call (main kernel + its fix-up kernel); achieved = 2*M*N*K summed over the "
-                             "call's problems / HIP-event time of the call, averaged over all calls of the timed region")
+                        note="one launch = one grouped stream-K GEMM call; achieved = ALGORITHMIC 2*M*N*K summed over the call's problems / "
+                             "HIP-event time of the call, averaged over the timed region."
+                             + (" Split-bf16: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi), so its "
+                                "ceiling against this peak is 1/3; frac_of_attainable = achieved / (peak/3)." if split else ""))
+            if split:
+                roof["frac_of_attainable"] = round(3 * k["tflops"] / peak, 4)
+                roof["traffic_note"] = ("fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/pmc_summary.json, "
+                                        "2*FETCH+WRITE KiB); served mostly by the 256 MiB Infinity Cache: panels are re-read per XCD")
         line = {
             "metric": "ensemble-member-steps/sec", "value": round(value, 4), "unit": "member-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3(split-fp32 operands, f32 accumulate; softmax/norms f32, sampler state f64)" if args.precision == "bf16x3" else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": f"cfg2: {args.model} AR transformer, {m} member/GPU, {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
-                            f"{lead} lead step(s) = {chunks} chunk(s) of return_seq_len {R}, latent 84x15x30, fp32 weights random-init seed 1234",
+                            f"{lead} lead step(s) = {chunks} chunk(s) of return_seq_len {R}, latent 84x15x30, fp32 weights random-init seed 1234, arithmetic {args.precision}",
                 "sampler": args.sampler, "members_per_gpu": m, "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
                 "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
             },
             "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
             "roofline": roof,
         }
-        if "attn_fwd_f32_kernel" in ks:
-            k = ks["attn_fwd_f32_kernel"]
-            line["attention_kernel"] = dict(achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                                            launches=k["launches"], avg_launch_us=round(k["avg_us"], 2))
+        for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS), ("attn_fwd_bf16x3_kernel", PEAK_BF16_MFMA_TFLOPS)):
+            if an in ks:
+                k = ks[an]
+                line["attention_kernel"] = dict(kernel=an, achieved=round(k["tflops"], 2), peak=apeak, unit="TFLOP/s", frac=round(k["tflops"] / apeak, 4),
+                                                launches=k["launches"], avg_launch_us=round(k["avg_us"], 2))
+                if an.endswith("bf16x3_kernel"):
+                    line["attention_kernel"]["frac_of_attainable"] = round(3 * k["tflops"] / apeak, 4)
         if args.cpu_forwards > 0 and world == 1:
             cores = torch.get_num_threads()
             dt = cpu_baseline(args.model, R, args.cpu_forwards)
