@@ -158,7 +158,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.x;
+  // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // CONTIGUOUS run of unit ranges; with the row-tile-fastest tile order below, the ~G/8 workgroups of an XCD
+  // then walk the same few W column panels and A row panels in step and hit in that XCD's private L2
+  // (bijective for any G, cdna_hip_programming.md T1).  Measured before: 28 % L2 hit rate, ~15x over-fetch.
+  int g;
+  {
+    const int bid = blockIdx.x, G = a.G;
+    const int q = G >> 3, r = G & 7, xcd = bid & 7;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const long long u_begin = range_start(g, a.U, a.G);
   const long long u_end = range_start(g + 1, a.U, a.G);
   const int fr = lane & 31;
@@ -176,10 +185,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
     const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
     const long long left = u_end - u;
     const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
-    const int bn = tile % P.tn;
-    const int bmb = tile / P.tn;
-    const int bm = bmb % P.tm;
-    const int b = bmb / P.tm;
+    const int bm = tile % P.tm;  // row tile fastest: consecutive tiles share one W column panel
+    const int bnb = tile / P.tm;
+    const int bn = bnb % P.tn;
+    const int b = bnb / P.tn;
     const int M = P.d.M, N = P.d.N, K = P.d.K;
     const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
     const int lda = P.d.lda;
@@ -372,9 +381,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_fixup_kernel(SKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] += slot[((wave * 4 + j) * 16 + r) * 64 + lane];
   }
-  const int bn = tile % P.tn;
-  const int bmb = tile / P.tn;
-  tile_epilogue(P, bmb / P.tm, bmb % P.tm, bn, acc, wave, lane);
+  const int bm = tile % P.tm;
+  const int bnb = tile / P.tm;
+  tile_epilogue(P, bnb / P.tn, bm, bnb % P.tn, acc, wave, lane);
 }
 
 }  // namespace
@@ -418,14 +427,35 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
   }
   if (tiles > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
-  long long G = 256;  // one 8-wave workgroup per CU
+  // Grid size: at most one 8-wave workgroup per CU, and -- when every problem has the same k-depth -- a divisor of
+  // tiles * s for a small split factor s, so that every range starts on a (1/s)-tile boundary: all workgroups then
+  // walk K in phase and the panels shared inside an XCD are fetched once (otherwise plain equal ranges).
+  long long G = 256;
   {
-    // units per workgroup >= sqrt(kt * t_slab / t_unit), t_slab / t_unit ~ 8 for this tile
-    const double kt_avg = static_cast<double>(U) / static_cast<double>(tiles);
-    long long umin = static_cast<long long>(sqrt(kt_avg * 8.0) + 0.5);
-    if (umin < 1) umin = 1;
-    const long long gmax = U / umin > 0 ? U / umin : 1;
-    if (gmax < G) G = gmax;
+    bool same_kt = true;
+    for (int i = 1; i < n; ++i) same_kt = same_kt && (a.pr[i].kt == a.pr[0].kt);
+    long long best = 0;
+    if (same_kt) {
+      const int kt = a.pr[0].kt;
+      for (int sfac = 1; sfac <= 4; ++sfac) {
+        if (kt % sfac || kt / sfac < 8) continue;
+        const long long items = tiles * sfac;
+        long long gd = items < 256 ? items : 256;
+        while (gd > 1 && items % gd) --gd;
+        const long long score = gd * (34 - sfac);  // mild preference for fewer splits
+        if (score > best * (34 - 1) / 33 && gd > best) best = gd;
+      }
+    }
+    if (best >= 160) {
+      G = best;
+    } else {
+      // units per workgroup >= sqrt(kt * t_slab / t_unit), t_slab / t_unit ~ 8 for this tile
+      const double kt_avg = static_cast<double>(U) / static_cast<double>(tiles);
+      long long umin = static_cast<long long>(sqrt(kt_avg * 8.0) + 0.5);
+      if (umin < 1) umin = 1;
+      const long long gmax = U / umin > 0 ? U / umin : 1;
+      if (gmax < G) G = gmax;
+    }
   }
   if (U < G) G = U;
   if (workspace == nullptr) return LDC_ERR_ARG;
