@@ -4,7 +4,13 @@
 // Same interface, work split and online softmax as attn_f32.hip (which stays the exact-fp32 path);
 // the MFMA time per 32-key tile drops from 128 x 64 to 48 x 32 cycles per wave.
 //
-// Data flow per workgroup (4 waves x 32 queries, one (batch, head)):
+// Workgroup = 8 waves = 128 queries of one (batch, head): waves 0-3 sweep the first half of the keys, waves
+// 4-7 the second half for the SAME queries (two independent LDS rings), and the two partial results
+// (running max, sum, unnormalised O) are merged through LDS at the end.  At one member per GPU the grid
+// is only 18 x 12 = 216 workgroups for 256 CUs; the key split gives every SIMD two waves to interleave
+// (MFMA of one beside softmax / staging of the other) instead of one.
+//
+// Data flow per 4-wave group (4 waves x 32 queries):
 //   * Q: loaded once per wave, pre-scaled by log2(e)/sqrt(128), split, kept as 8 k16-step B fragments
 //     (hi and lo: 64 VGPRs);
 //   * K tile (32 keys x 128): split while staged, LDS row = key: [hi 256 B | lo 256 B | 16 B pad]
@@ -40,6 +46,7 @@ struct AttnArgs {
   int S, H, ld_qkv, ldo;
   long long qkv_bs, o_bs;
   float qscale;
+  int nq;  // query blocks per (batch, head)
 };
 
 __device__ __forceinline__ unsigned split_pair(float a, float b, float& ra, float& rb) {
@@ -71,16 +78,31 @@ __device__ __forceinline__ void split8(float x0, float x1, float x2, float x3, f
   l.w = pack_pair(r6, r7);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16x3_kernel(AttnArgs p) {
+template <int NGRP>
+__global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_bf16x3_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
+  const int grp = NGRP == 2 ? (threadIdx.x >> 8) : 0;  // key-range group 0 / 1
+  const int tid = threadIdx.x & 255;  // thread index inside the 4-wave group
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int l31 = lane & 31;
   const int S = p.S;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB + wave * 32;
+  // XCD-aware placement (speed only): the query blocks of one (batch, head) re-read the same K/V (2.3 MB at
+  // S = 2250), so lay the 1-D grid out as [batch][head][query block] and give each XCD a contiguous run of it
+  // (blocks are dealt round-robin over the 8 XCDs; bijective remap for any grid size).
+  int head, b, qblk;
+  {
+    const int nq = p.nq, T = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    qblk = lin % nq;
+    const int hb = lin / nq;
+    head = hb % p.H;
+    b = hb / p.H;
+  }
+  const int q0 = qblk * QB + wave * 32;
 
   const long long base = static_cast<long long>(b) * p.qkv_bs + static_cast<long long>(head) * HD;
   const float* __restrict__ Qg = p.Q + base;
@@ -137,8 +159,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16x3_kernel(AttnArgs p) {
       }
     }
   };
+  unsigned char* const ring = smem + grp * (2 * STAGE_BYTES);
   auto sstore = [&](int stage) {
-    unsigned char* Ks = smem + stage * STAGE_BYTES;
+    unsigned char* Ks = ring + stage * STAGE_BYTES;
     unsigned char* Vs = Ks + KT * KPITCH;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -167,13 +190,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16x3_kernel(AttnArgs p) {
   float l_run = 0.f;
 
   const int nt = (S + KT - 1) / KT;
-  gload(0);
-  sstore(0);
+  const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
+  const int t_begin = grp ? nhalf : 0;
+  const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
+  if (t_begin < t_end) {
+    gload(t_begin * KT);
+    sstore(0);
+  }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) gload((t + 1) * KT);
-    const unsigned char* Ks = smem + (t & 1) * STAGE_BYTES;
+  for (int it = 0; it < nhalf; ++it) {
+    const int t = t_begin + it;
+    const bool active = t < t_end;
+    if (active) {
+    if (t + 1 < t_end) gload((t + 1) * KT);
+    const unsigned char* Ks = ring + (it & 1) * STAGE_BYTES;
     const unsigned char* Vs = Ks + KT * KPITCH;
 
     // ---- S^T = K . Q^T  (24 MFMAs) ----------------------------------------------------------------
@@ -240,9 +271,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16x3_kernel(AttnArgs p) {
       }
     }
 
-    if (t + 1 < nt) sstore((t + 1) & 1);
+    if (t + 1 < t_end) sstore((it + 1) & 1);
+    }  // active
     __syncthreads();
   }
+
+  // ---- merge the two key halves: group 1 hands (m, l, O) to group 0 through LDS (the rings are idle) ----
+  if constexpr (NGRP == 2) {
+  float* xch = reinterpret_cast<float*>(smem) + (wave * 66) * 64 + lane;  // [wave][66][64 lanes]
+  if (grp == 1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = o[d][r];
+    xch[64 * 64] = m_run;
+    xch[65 * 64] = l_run;
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float m1 = xch[64 * 64], l1 = xch[65 * 64];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(d * 16 + r) * 64] * a1;
+  }
+  }  // NGRP == 2
 
   const int qrow = q0 + l31;
   if (qrow < S) {
@@ -272,16 +329,25 @@ extern "C" int ldc_attn_fwd_bf16x3(const float* Q, const float* K, const float* 
   LDC_CHECK_ALIGN16(V);
   LDC_CHECK_ALIGN16(O);
   if ((ld_qkv & 3) || (ldo & 3) || (qkv_bs & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
-  if (H > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   AttnArgs p{Q, K, V, O, S, H, ld_qkv, ldo, qkv_bs, o_bs, 0.08838834764831845f * 1.4426950408889634f};
-  dim3 grid(ldc_cdiv(S, QB), H, B);
-  const size_t lds = 2 * STAGE_BYTES;
+  p.nq = ldc_cdiv(S, QB);
+  dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bf16x3_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bf16x3_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bf16x3_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_fwd_bf16x3_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  // few workgroups (one member per GPU): split the keys over two 4-wave groups so every SIMD has two waves;
+  // enough workgroups: two 4-wave workgroups per CU do the same job without the merge
+  const long long nwg = static_cast<long long>(p.nq) * H * B;
+  if (nwg <= 256) {
+    hipLaunchKernelGGL(attn_fwd_bf16x3_kernel<2>, grid, dim3(512), 4 * STAGE_BYTES, static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_bf16x3_kernel<1>, grid, dim3(256), 2 * STAGE_BYTES, static_cast<hipStream_t>(stream), p);
+  }
   return ldc_launch_status();
 }

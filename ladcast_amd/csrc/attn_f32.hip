@@ -37,6 +37,7 @@ struct AttnArgs {
   int S, H, ld_qkv, ldo;
   long long qkv_bs, o_bs;
   float qscale;
+  int nq;  // query blocks per (batch, head)
 };
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
@@ -47,8 +48,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
   const int half = lane >> 5;
   const int l31 = lane & 31;
   const int S = p.S;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB + wave * 32;
+  // XCD-aware placement (speed only): the query blocks of one (batch, head) re-read the same K/V (2.3 MB at
+  // S = 2250), so lay the 1-D grid out as [batch][head][query block] and give each XCD a contiguous run of it
+  // (blocks are dealt round-robin over the 8 XCDs; bijective remap for any grid size).
+  int head, b, qblk;
+  {
+    const int nq = p.nq, T = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    qblk = lin % nq;
+    const int hb = lin / nq;
+    head = hb % p.H;
+    b = hb / p.H;
+  }
+  const int q0 = qblk * QB + wave * 32;
 
   const long long base = static_cast<long long>(b) * p.qkv_bs + static_cast<long long>(head) * HD;
   const float* __restrict__ Qg = p.Q + base;
@@ -209,10 +223,11 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
   LDC_CHECK_ALIGN16(V);
   LDC_CHECK_ALIGN16(O);
   if ((ld_qkv & 3) || (ldo & 3) || (qkv_bs & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
-  if (H > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   AttnArgs p{Q, K, V, O, S, H, ld_qkv, ldo, qkv_bs, o_bs,
              0.08838834764831845f * 1.4426950408889634f};  // 1/sqrt(128) * log2(e)
-  dim3 grid(ldc_cdiv(S, QB), H, B);
+  p.nq = ldc_cdiv(S, QB);
+  dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   const size_t lds = 2 * STAGE * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

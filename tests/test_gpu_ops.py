@@ -206,7 +206,7 @@ def test_attention(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
 
 
-@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1)])
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 2250, 16)])
 def test_attention_bf16x3(hip, B, S, H):
     D = H * 128
     qkv = rnd(B, S, 3 * D, seed=11)
