@@ -215,14 +215,17 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
       const int c = lp ^ ((r >> 1) & 7);
       w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + c * 16;
     }
-    auto issue = [&](int kt, int stage) {
+    // one DMA instruction i (0..3: A rows, 4..5: W rows) of k-step kt into `stage`
+    auto issue_one = [&](int kt, int stage, int i) {
       unsigned char* sA = smem + stage * STAGE_B;
       unsigned char* sW = sA + BM * ROW_B;
       const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
+      if (i < 4) dma16(a_src[i] + koff, sA + (wave + 8 * i) * 1024);
+      else dma16(w_src[i - 4] + koff, sW + (wave + 8 * (i - 4)) * 1024);
+    };
+    auto issue = [&](int kt, int stage) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dma16(a_src[i] + koff, sA + (wave + 8 * i) * 1024);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) dma16(w_src[i] + koff, sW + (wave + 8 * i) * 1024);
+      for (int i = 0; i < 6; ++i) issue_one(kt, stage, i);
     };
 
     f32x16 acc[4];
@@ -246,7 +249,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      if (kt + 2 < k1) issue(kt + 2, (kt + 2 - k0) % NSTAGE);
+      // the 6 DMA instructions of k-step kt+2 are spread between the MFMA groups below instead of issued as a
+      // burst behind the barrier (where both waves of a SIMD would stall the matrix pipe together)
+      const bool pre = kt + 2 < k1;
+      const int pst = (kt + 2 - k0) % NSTAGE;
       const unsigned aaddr = smem_lds + st * STAGE_B + a_row * ROW_B;
       const unsigned waddr = smem_lds + st * STAGE_B + BM * ROW_B + fr * ROW_B;
 #pragma unroll
@@ -276,8 +282,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WL), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WH), ACC, 0, 0, 0);
         LDC_MFMA3(acc[0], h0, l0)
+        if (pre) issue_one(kt + 2, pst, 3 * s2);
         LDC_MFMA3(acc[1], h1, l1)
+        if (pre) issue_one(kt + 2, pst, 3 * s2 + 1);
         LDC_MFMA3(acc[2], h2, l2)
+        if (pre) issue_one(kt + 2, pst, 3 * s2 + 2);
         LDC_MFMA3(acc[3], h3, l3)
       }
     }
