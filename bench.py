@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = DPM-Solver++(2M), N forwards")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; nccl (= RCCL over xGMI) is the real one, "
+                    "gloo only lets the N > 1 code path be dry-run on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-gpus", action="store_true", help="dry-run aid: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per model forward instead of launching from Python (same speed on this host)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="token-stream GEMM arithmetic: exact fp32 MFMA, or split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate)")
@@ -157,14 +160,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.share_gpus else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     import ladcast_amd.hip as hip
     from ladcast_amd.models import LaDCastTransformer3DModel
@@ -193,7 +200,7 @@ def main():
             known_latents_override=ic, member_ids=member_ids,
         )
         if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
-            out = gather_members(out.to(dev), m * world, member_dim=1)
+            out = gather_members(out.to(dev) if args.backend == "nccl" else out, m * world, member_dim=1)
         return out
 
     def fence():
@@ -215,7 +222,7 @@ def main():
     if not args.no_kernel_timers:
         timer.uninstall()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 

@@ -145,6 +145,25 @@ def test_full_375m_forward_bf16x3():
     assert e < 3e-5, e
 
 
+def test_full_1_6b_forward_matches_oracle_both_modes():
+    """BASELINE configs[3] model (1.6B: D = 2048, 16 heads, 3 + 5 + 10 blocks), one forward, both arithmetic modes."""
+    from oracle.ar_model import CONFIG_1_6B
+
+    o = make_ar(dict(CONFIG_1_6B))
+    g = to_hip(o, dict(CONFIG_1_6B))
+    x = torch.randn(1, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+    known, ts = synth_known(1), torch.tensor([2018010100])
+    with torch.no_grad():
+        want = o(x, torch.tensor([0.3]), known, time_elapsed=ts).sample
+    del o
+    for mode, tol in (("fp32", 2e-5), ("bf16x3", 3e-5)):
+        g.set_gemm_precision(mode)
+        got = g(x.cuda(), torch.tensor([0.3]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
+        e = rel_l2(got.cpu(), want)
+        print(f"1.6B {mode} forward rel-L2 {e:.2e}")
+        assert e < tol, (mode, e)
+
+
 def test_scheduler_indexing_is_bit_exact():
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 
@@ -200,3 +219,43 @@ def test_tiny_rollout_latent_mode_matches_oracle(tiny_pair):
     assert not torch.isnan(got).any()
     assert torch.equal(got[:, :, :, 0], want[:, :, :, 0])
     assert rel_l2(got, want) < TOL
+
+
+def test_end_to_end_rollout_with_dcae_matches_oracle():
+    """encode IC -> AR chunks -> decode (tiny DCAE + tiny AR), the decoded-field mode of roll_out_serial:
+    the whole product path on HIP vs the whole oracle path on CPU, same weights, same seeds."""
+    from datetime import datetime
+
+    from ladcast_amd.models import AutoencoderDC, LaDCastTransformer3DModel
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from oracle.dcae import CONFIG_DCAE_84
+    from tests.synth import make_dcae, synth_field
+
+    # latent grid must be 15x30 with 84 channels for the AR model: field 120x240, DCAE with small widths
+    # (widths must keep the reference's shortcut arithmetic integral: 4*c_i % c_{i+1} == 0 and c_last % 84 == 0)
+    ae_cfg = dict(CONFIG_DCAE_84, encoder_block_out_channels=(84, 84, 84, 168), decoder_block_out_channels=(84, 84, 84, 168),
+                  encoder_layers_per_block=(1, 1, 1, 1), decoder_layers_per_block=(1, 1, 1, 1))
+    oae = make_dcae(ae_cfg)
+    gae = AutoencoderDC.from_config(ae_cfg)
+    gae.load_state_dict(oae.state_dict(), strict=True)
+    gae = gae.cuda().eval()
+    cfg = tiny_ar_config(heads=2, layers=1, single=1, refiner=1)
+    oar = make_ar(cfg)
+    gar = to_hip(oar, cfg)
+    field = synth_field(84, 1, 120, 240)  # (C, T_in, H, W), already "normalised"
+    static = synth_field(1, 5, 120, 240, seed=1)[0]
+    g_ = torch.Generator().manual_seed(9)
+    mu, sd = torch.randn(84, generator=g_) * 0.2, torch.rand(84, generator=g_) + 0.5
+    targs = {"mean": mu.tolist(), "std": sd.tolist(), "target_std": 0.5}
+    fmu, fsd = torch.randn(84, generator=g_), torch.rand(84, generator=g_) + 0.5
+    t0 = [datetime(2018, 1, 1, 0)]
+    kw = dict(ensemble_size=2, num_inference_steps=2, return_seq_len=2, static_tensor4encdec=static, latent_transform_args=targs,
+              total_lead_time_hour=18, sampler_type="edm", return_latent=False, encdec_model_type="ae")
+    want = OP.roll_out_serial(lambda t: field, t0, OP.AutoRegressive2DPipeline(oar, OracleScheduler()), mean_tensor=fmu, std_tensor=fsd,
+                              encdec_model=oae, **kw)
+    got = roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()),
+                          normalization_param_dict={"mean": fmu, "std": fsd}, encdec_model=gae, **kw)
+    assert got.shape == want.shape == (1, 2, 84, 4, 120, 240)
+    assert torch.isnan(got[:, :, :, 0]).all() and torch.isnan(want[:, :, :, 0]).all()  # slot 0 = raw field, owned by the caller
+    assert rel_l2(got[:, :, :, 1:], want[:, :, :, 1:]) < TOL
