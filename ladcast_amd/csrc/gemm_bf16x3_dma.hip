@@ -272,8 +272,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
         LDC_DS_READ(l2, w1, 8192);
         LDC_DS_READ(h3, w0, 12288);
         LDC_DS_READ(l3, w1, 12288);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+        // counted waits (LDS returns in order): start multiplying as soon as the A fragment and the first W pair are
+        // back; the later W pairs land under the earlier MFMAs
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0));
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 ah, al;
         split8(make_float4(p.x, p.y, p.z, p.w), make_float4(q.x, q.y, q.z, q.w), ah, al);
@@ -281,13 +282,21 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, WH), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WL), ACC, 0, 0, 0);          \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WH), ACC, 0, 0, 0);
+        __builtin_amdgcn_s_setprio(1);
         LDC_MFMA3(acc[0], h0, l0)
         if (pre) issue_one(kt + 2, pst, 3 * s2);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h1), "+v"(l1));
+        __builtin_amdgcn_sched_barrier(0);
         LDC_MFMA3(acc[1], h1, l1)
         if (pre) issue_one(kt + 2, pst, 3 * s2 + 1);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h2), "+v"(l2));
+        __builtin_amdgcn_sched_barrier(0);
         LDC_MFMA3(acc[2], h2, l2)
         if (pre) issue_one(kt + 2, pst, 3 * s2 + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h3), "+v"(l3));
+        __builtin_amdgcn_sched_barrier(0);
         LDC_MFMA3(acc[3], h3, l3)
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     // all waves must be done reading the ring before the next segment's prologue overwrites stage 0/1
