@@ -135,27 +135,52 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_bf16x3
   const int vd = tid & 127, vg0 = tid >> 7;          // second item: group + 2
   float4 rk[2][2];
   float rv[2][8];
+  // per-thread source offsets (elements), fixed for the whole kernel: K rows kk0, kk0+16; V rows kappa(j) of the
+  // thread's two key groups.  Full tiles (all but the last) load unconditionally; only the last tile clamps and zeroes.
+  const int k_off0 = kk0 * ld + kc * 8, k_off1 = (kk0 + 16) * ld + kc * 8;
+  int v_off[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int vg = vg0 + 2 * i, tt = vg >> 1, hh = vg & 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v_off[i][j] = (16 * tt + 8 * (j >> 2) + 4 * hh + (j & 3)) * ld + vd;
+  }
   auto gload = [&](int key0) {
+    const float* Kt = Kg + static_cast<long long>(key0) * ld;
+    const float* Vt = Vg + static_cast<long long>(key0) * ld;
+    if (key0 + KT <= S) {  // wave-uniform: a full tile
+      const float4* s0 = reinterpret_cast<const float4*>(Kt + k_off0);
+      const float4* s1 = reinterpret_cast<const float4*>(Kt + k_off1);
+      rk[0][0] = s0[0];
+      rk[0][1] = s0[1];
+      rk[1][0] = s1[0];
+      rk[1][1] = s1[1];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = key0 + kk0 + 16 * i;
-      const bool ok = key < S;
-      const float4* src = reinterpret_cast<const float4*>(Kg + static_cast<long long>(ok ? key : 0) * ld + kc * 8);
-      float4 a = src[0], c = src[1];
-      const float m = ok ? 1.f : 0.f;
-      rk[i][0] = make_float4(a.x * m, a.y * m, a.z * m, a.w * m);
-      rk[i][1] = make_float4(c.x * m, c.y * m, c.z * m, c.w * m);
-    }
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int vg = vg0 + 2 * i;  // = 2 t + h
-      const int t = vg >> 1, h = vg & 1;
+        for (int j = 0; j < 8; ++j) rv[i][j] = Vt[v_off[i][j]];
+    } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = key0 + 16 * t + 8 * (j >> 2) + 4 * h + (j & 3);
+      for (int i = 0; i < 2; ++i) {
+        const int key = key0 + kk0 + 16 * i;
         const bool ok = key < S;
-        const float v = Vg[static_cast<long long>(ok ? key : 0) * ld + vd];
-        rv[i][j] = ok ? v : 0.f;
+        const float4* src = reinterpret_cast<const float4*>(Kg + static_cast<long long>(ok ? key : 0) * ld + kc * 8);
+        float4 a = src[0], c = src[1];
+        const float m = ok ? 1.f : 0.f;
+        rk[i][0] = make_float4(a.x * m, a.y * m, a.z * m, a.w * m);
+        rk[i][1] = make_float4(c.x * m, c.y * m, c.z * m, c.w * m);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int vg = vg0 + 2 * i;  // = 2 t + h
+        const int t = vg >> 1, h = vg & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = key0 + 16 * t + 8 * (j >> 2) + 4 * h + (j & 3);
+          const bool ok = key < S;
+          const float v = Vg[static_cast<long long>(ok ? key : 0) * ld + vd];
+          rv[i][j] = ok ? v : 0.f;
+        }
       }
     }
   };
