@@ -33,16 +33,18 @@
 // the fallback for grids with more tiles than counters.
 // Needs K % 32 == 0 (no K-edge zero fill through DMA); other shapes use the register-staged kernel.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 128, BK = 32;
+// Two instantiations: BM = 256 (8 waves, two per SIMD) for grids that fill the chip with whole tiles, and
+// BM = 128 (4 waves, one per SIMD: the rolling pipeline below keeps LDS and VALU work under the MFMAs of the
+// SAME wave) for small problems, where 256-row tiles leave CUs idle or force every tile to be split along K.
+constexpr int BN = 128, BK = 32;
 constexpr int ROW_B = 128;                       // bytes per LDS row (both operands)
-constexpr int STAGE_B = (BM + BN) * ROW_B;       // 48 KiB
 constexpr int NSTAGE = 3;
-constexpr int SLOT_FLOATS = BM * BN;
 constexpr int MAXP = LDC_GEMM_MAX_PROBLEMS;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -112,6 +114,7 @@ __device__ __forceinline__ void split8(const float4 p, const float4 q, bf16x8& h
 }
 
 // acc[j][r]: wave w owns rows [32w, 32w+32) of the tile and all 128 columns (4 MFMA column tiles)
+template <int BM>
 __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x16 (&acc)[4], int wave,
                                               int lane) {
   const int M = P.d.M, N = P.d.N;
@@ -153,9 +156,31 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_w
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
+// Diagnostic build only (-DLDC_GEMM_STAMPS): wall-clock stamps (100 MHz) per workgroup into the upper half of the
+// counter block, which nothing else reads; the product build contains no stamp.
+#ifdef LDC_GEMM_STAMPS
+#define LDC_STAMP(i)                                                                                        \
+  if (threadIdx.x == 0 && a.counters)                                                                       \
+    reinterpret_cast<unsigned long long*>(a.counters)[65536 + blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#define LDC_STAMP_CLK(i)                                                                                    \
+  if (threadIdx.x == 0 && a.counters)                                                                       \
+    reinterpret_cast<unsigned long long*>(a.counters)[65536 + blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define LDC_STAMP(i)
+#define LDC_STAMP_CLK(i)
+#endif
+
+template <int BM>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
+  constexpr int NW = BM / 32;                  // waves per workgroup, 8(M) x 1(N) or 4(M) x 1(N)
+  constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
+  constexpr int SLOT_FLOATS = BM * BN;
+  constexpr int NWI = 16 / NW;                 // W DMA instructions per wave and k-step (A: always 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
+  LDC_STAMP(0)
+  int seg_ = 0;
+  (void)seg_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
@@ -195,37 +220,64 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
     const long long w_row_bytes = static_cast<long long>(K) * 4;  // packed row: K/8 chunks x 32 B
 
     // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored)
-    // A instruction q (0..31) covers tile rows [8q, 8q+8); this wave issues q = wave + 8i, i = 0..3
-    // W instruction q (0..15) covers tile rows [8q, 8q+8); this wave issues q = wave + 8i, i = 0..1
+    // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8); this wave issues q = wave + NW i, i = 0..3
+    // W instruction q (0..15) covers tile rows [8q, 8q+8); this wave issues q = wave + NW i, i = 0..NWI-1
     const unsigned char* a_src[4];
-    const unsigned char* w_src[2];
+    const unsigned char* w_src[NWI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = 8 * (wave + 8 * i) + lr;
+      const int r = 8 * (wave + NW * i) + lr;
+#ifdef LDC_GEMM_DIAG_SAMEPANEL  // diagnostic build: every workgroup streams the same panels (operands stay in L2)
+      int gm = r;
+#else
       int gm = bm * BM + r;
+#endif
       gm = gm < M ? gm : M - 1;
       const int c = lp ^ ((r >> 1) & 7);
       a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + c * 16;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = 8 * (wave + 8 * i) + lr;
+    for (int i = 0; i < NWI; ++i) {
+      const int r = 8 * (wave + NW * i) + lr;
+#ifdef LDC_GEMM_DIAG_SAMEPANEL
+      int gn = r;
+#else
       int gn = bn * BN + r;
+#endif
       gn = gn < N ? gn : N - 1;
       const int c = lp ^ ((r >> 1) & 7);
       w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + c * 16;
     }
-    // one DMA instruction i (0..3: A rows, 4..5: W rows) of k-step kt into `stage`
+    // one DMA instruction i (0..3: A rows, 4..ND-1: W rows) of k-step kt into `stage`
+    constexpr int ND = 4 + NWI;    // DMA instructions per wave and k-step (6 / 8)
+    constexpr int NDH = ND / 2;    // issued per half-step
     auto issue_one = [&](int kt, int stage, int i) {
       unsigned char* sA = smem + stage * STAGE_B;
       unsigned char* sW = sA + BM * ROW_B;
       const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
-      if (i < 4) dma16(a_src[i] + koff, sA + (wave + 8 * i) * 1024);
-      else dma16(w_src[i - 4] + koff, sW + (wave + 8 * (i - 4)) * 1024);
+#ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
+      if (kt >= 0) return;
+#endif
+      if (i < 4) dma16(a_src[i] + koff, sA + (wave + NW * i) * 1024);
+      else dma16(w_src[i - 4] + koff, sW + (wave + NW * (i - 4)) * 1024);
     };
     auto issue = [&](int kt, int stage) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) issue_one(kt, stage, i);
+      for (int i = 0; i < ND; ++i) issue_one(kt, stage, i);
+    };
+    // the part of half `hf` (0 / 1) of a k-step's DMAs that goes behind MFMA group `slot` (0..2) of a half-step
+    auto issue_part = [&](int kt, int stage, int hf, int slot) {
+      const int base = hf * NDH;
+      if constexpr (NDH == 3) {
+        issue_one(kt, stage, base + slot);
+      } else {
+        if (slot == 0) {
+          issue_one(kt, stage, base);
+          issue_one(kt, stage, base + 1);
+        } else {
+          issue_one(kt, stage, base + slot + 1);
+        }
+      }
     };
 
     f32x16 acc[4];
@@ -234,76 +286,214 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // fragment read offsets (bytes) inside a stage: row * 128 + ((chunk ^ swz(row)) * 16)
-    const int a_row = wave * 32 + fr;
-    const int a_swz = (a_row >> 1) & 7;
-    const int w_swz = (fr >> 1) & 7;  // rows 32j + fr: (row >> 1) & 7 == (fr >> 1) & 7 ... + 16j & 7 = same
+    // ---- main loop: rolling software pipeline over HALF k-steps H = (kt, s2), hand-placed instruction stream ----
+    // Facts this is built on (MI355X_MICROARCH.md cycle constants; in-kernel clock stamps of the earlier versions):
+    //  * a v_mfma_f32_32x32x16_bf16 occupies the matrix pipe for 32 cycles but the SIMD's vector issue for only 8, so
+    //    ~24 cycles of other vector work (4-5 VALU, or 1-2 ds_read_b128) hide behind EVERY MFMA -- and only there:
+    //    the earlier "reads, wait, split, 12 MFMAs" half-step ran 2390 cycles per k-step against 1536 of MFMA, with
+    //    or without operand traffic (the no-DMA diagnostic build measured the same), because the fillers sat in
+    //    bursts between MFMA groups where both waves of a SIMD issued no MFMA;
+    //  * LDS reads return in order, so waits are counted: reads issued after the awaited ones stay in flight.
+    // Every fragment register is re-loaded for half-step H+1 right behind the last MFMA of H that reads it, the
+    // activation split of H+1 (24 VALU) is cut into 8 pieces of 3 placed one or two per MFMA gap, and the DMA
+    // instructions of later k-steps sit alone in a gap each:
+    //   M1 [pq'] M2 [l0'] M3 [h0' DMA] | M4 [s] M5 [l1' s] M6 [h1' DMA] | M7 [s s] M8 [l2' s] M9 [h2' DMA] |
+    //   M10 [s s] M11 [l3' s] M12 [h3']            (x' = LDS read of x for H+1, s = one split piece)
+    // H = (kt,1) starts with barrier(kt+1) = {lgkmcnt(0): this wave is done READING stage kt; vmcnt: its DMAs of
+    // k-step kt+1 landed; s_barrier}: behind it stage kt+1 may be read and stage kt may be overwritten (by the DMAs
+    // of k-step kt+3).  DMA schedule: k-step t's instructions are issued half in H = (t-3,1), half in H = (t-2,0).
+    const unsigned swz = (fr >> 1) & 7;  // (row >> 1) & 7 is the same for A rows 32*wave + fr and W rows 32*j + fr
+    const unsigned arow = smem_lds + (wave * 32 + fr) * ROW_B;
+    const unsigned wrow = smem_lds + BM * ROW_B + fr * ROW_B;
+    // byte offset of the two 16-byte chunks (2m, 2m+1), m = 2*s2 + fh, of this lane's 8-wide k slice
+    const unsigned c00 = ((2u * fh) ^ swz) << 4, c01 = c00 ^ 16u;            // s2 = 0
+    const unsigned c10 = ((2u * (2 + fh)) ^ swz) << 4, c11 = c10 ^ 16u;      // s2 = 1
 
+    f32x4v p, q;
+    i32x4v h0, l0, h1, l1, h2, l2, h3, l3;
+    i32x4v ahA, alA, ahB, alB;
+
+#define LDC_SB __builtin_amdgcn_sched_barrier(0)
+#define LDC_MFMA(ACC, X, Y)                                                                                 \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, X), __builtin_bit_cast(bf16x8, Y), ACC, 0, 0, 0); \
+  LDC_SB;
+    // split piece 1 of a pair (x0, x1): hi pair -> AH[i]; the two hi values as fp32 stay in t0, t1
+#define LDC_SPLIT_A(AH, I, X0, X1)                                                                          \
+  {                                                                                                         \
+    unsigned u_ = pack_pair(X0, X1);                                                                        \
+    asm volatile("" : "+v"(u_)); /* keep ONE cvt_pk: the compiler otherwise re-converts x0 alone */         \
+    AH[I] = static_cast<int>(u_);                                                                           \
+    t0 = __uint_as_float(u_ << 16);                                                                         \
+    t1 = __uint_as_float(u_ & 0xffff0000u);                                                                 \
+    asm volatile("" : "+v"(t0), "+v"(t1)); /* anchor: IR-level sinking would move the piece to its use */   \
+  }
+    // split piece 2: residuals -> lo pair -> AL[i]
+#define LDC_SPLIT_B(AL, I, X0, X1)                                                                          \
+  {                                                                                                         \
+    unsigned lo_ = pack_pair(X0 - t0, X1 - t1);                                                             \
+    asm volatile("" : "+v"(lo_));                                                                           \
+    AL[I] = static_cast<int>(lo_);                                                                          \
+  }
+#define LDC_READ_PQ(SB, C0, C1)                                                                             \
+  {                                                                                                         \
+    const unsigned a0_ = arow + (SB) + (C0), a1_ = arow + (SB) + (C1);                                      \
+    LDC_DS_READ(p, a0_, 0);                                                                                 \
+    LDC_DS_READ(q, a1_, 0);                                                                                 \
+  }
+    // one half-step: 12 MFMAs with A fragments (AH, AL); loads for H+1 from stage offset SBN with chunk offsets
+    // CN0/CN1; builds (AHN, ALN); DMA part (kt DK, stage DS, half DH) when DP
+#define LDC_HALF_STEP(AH, AL, AHN, ALN, SBN, CN0, CN1, W_H1, DP, DK, DS, DH)                                \
+  {                                                                                                         \
+    float t0, t1;                                                                                           \
+    const unsigned w0_ = wrow + (SBN) + (CN0), w1_ = wrow + (SBN) + (CN1);                                  \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[0], AL, h0)                                                                                \
+    LDC_READ_PQ(SBN, CN0, CN1)                                                                              \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[0], AH, l0)                                                                                \
+    LDC_DS_READ(l0, w1_, 0);                                                                                \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[0], AH, h0)                                                                                \
+    LDC_DS_READ(h0, w0_, 0);                                                                                \
+    if (DP) issue_part(DK, DS, DH, 0);                                                                      \
+    W_H1                                                                                                    \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[1], AL, h1)                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(p), "+v"(q), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));        \
+    LDC_SB;                                                                                                 \
+    LDC_SPLIT_A(AHN, 0, p.x, p.y)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[1], AH, l1)                                                                                \
+    LDC_DS_READ(l1, w1_, 4096);                                                                             \
+    LDC_SPLIT_B(ALN, 0, p.x, p.y)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[1], AH, h1)                                                                                \
+    LDC_DS_READ(h1, w0_, 4096);                                                                             \
+    if (DP) issue_part(DK, DS, DH, 1);                                                                      \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[2], AL, h2)                                                                                \
+    LDC_SPLIT_A(AHN, 1, p.z, p.w)                                                                           \
+    LDC_SPLIT_B(ALN, 1, p.z, p.w)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[2], AH, l2)                                                                                \
+    LDC_DS_READ(l2, w1_, 8192);                                                                             \
+    LDC_SPLIT_A(AHN, 2, q.x, q.y)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[2], AH, h2)                                                                                \
+    LDC_DS_READ(h2, w0_, 8192);                                                                             \
+    if (DP) issue_part(DK, DS, DH, 2);                                                                      \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[3], AL, h3)                                                                                \
+    LDC_SPLIT_B(ALN, 2, q.x, q.y)                                                                           \
+    LDC_SPLIT_A(AHN, 3, q.z, q.w)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[3], AH, l3)                                                                                \
+    LDC_DS_READ(l3, w1_, 12288);                                                                            \
+    LDC_SPLIT_B(ALN, 3, q.z, q.w)                                                                           \
+    LDC_SB;                                                                                                 \
+    LDC_MFMA(acc[3], AH, h3)                                                                                \
+    LDC_DS_READ(h3, w0_, 12288);                                                                            \
+    LDC_SB;                                                                                                 \
+  }
+
+    // prologue: k-steps k0 and k0+1 in flight, fragments of H = (k0,0) loaded and split
     issue(k0, 0);
-    if (k0 + 1 < k1) issue(k0 + 1, 1);
-    for (int kt = k0; kt < k1; ++kt) {
-      const int st = (kt - k0) % NSTAGE;
-      if (kt + 1 < k1) {
+    if (k0 + 1 < k1) {
+      issue(k0 + 1, 1);
+      if constexpr (ND == 6) {
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();
-      // the 6 DMA instructions of k-step kt+2 are spread between the MFMA groups below instead of issued as a
-      // burst behind the barrier (where both waves of a SIMD would stall the matrix pipe together)
-      const bool pre = kt + 2 < k1;
-      const int pst = (kt + 2 - k0) % NSTAGE;
-      const unsigned aaddr = smem_lds + st * STAGE_B + a_row * ROW_B;
-      const unsigned waddr = smem_lds + st * STAGE_B + BM * ROW_B + fr * ROW_B;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int m = 2 * s2 + fh;  // 8-wide k chunk of this lane half
-        const unsigned a0 = aaddr + (((2 * m) ^ a_swz) << 4), a1 = aaddr + (((2 * m + 1) ^ a_swz) << 4);
-        const unsigned w0 = waddr + (((2 * m) ^ w_swz) << 4), w1 = waddr + (((2 * m + 1) ^ w_swz) << 4);
-        f32x4v p, q;
-        i32x4v h0, l0, h1, l1, h2, l2, h3, l3;
-        LDC_DS_READ(p, a0, 0);
-        LDC_DS_READ(q, a1, 0);
-        LDC_DS_READ(h0, w0, 0);
-        LDC_DS_READ(l0, w1, 0);
-        LDC_DS_READ(h1, w0, 4096);
-        LDC_DS_READ(l1, w1, 4096);
-        LDC_DS_READ(h2, w0, 8192);
-        LDC_DS_READ(l2, w1, 8192);
-        LDC_DS_READ(h3, w0, 12288);
-        LDC_DS_READ(l3, w1, 12288);
-        // counted waits (LDS returns in order): start multiplying as soon as the A fragment and the first W pair are
-        // back; the later W pairs land under the earlier MFMAs
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0));
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 ah, al;
-        split8(make_float4(p.x, p.y, p.z, p.w), make_float4(q.x, q.y, q.z, q.w), ah, al);
-#define LDC_MFMA3(ACC, WH, WL)                                                                              \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, WH), ACC, 0, 0, 0);          \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WL), ACC, 0, 0, 0);          \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, WH), ACC, 0, 0, 0);
-        __builtin_amdgcn_s_setprio(1);
-        LDC_MFMA3(acc[0], h0, l0)
-        if (pre) issue_one(kt + 2, pst, 3 * s2);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h1), "+v"(l1));
-        __builtin_amdgcn_sched_barrier(0);
-        LDC_MFMA3(acc[1], h1, l1)
-        if (pre) issue_one(kt + 2, pst, 3 * s2 + 1);
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h2), "+v"(l2));
-        __builtin_amdgcn_sched_barrier(0);
-        LDC_MFMA3(acc[2], h2, l2)
-        if (pre) issue_one(kt + 2, pst, 3 * s2 + 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h3), "+v"(l3));
-        __builtin_amdgcn_sched_barrier(0);
-        LDC_MFMA3(acc[3], h3, l3)
-        __builtin_amdgcn_s_setprio(0);
-      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
+    LDC_STAMP(1 + 4 * seg_)
+    if (seg_ == 0) { LDC_STAMP_CLK(13) }
+    LDC_READ_PQ(0u, c00, c01)
+    {
+      const unsigned w0_ = wrow + c00, w1_ = wrow + c01;
+      LDC_DS_READ(l0, w1_, 0);
+      LDC_DS_READ(h0, w0_, 0);
+      LDC_DS_READ(l1, w1_, 4096);
+      LDC_DS_READ(h1, w0_, 4096);
+      LDC_DS_READ(l2, w1_, 8192);
+      LDC_DS_READ(h2, w0_, 8192);
+      LDC_DS_READ(l3, w1_, 12288);
+      LDC_DS_READ(h3, w0_, 12288);
+    }
+    if (k0 + 2 < k1) {
+#pragma unroll
+      for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+    LDC_SB;
+    {
+      float t0, t1;
+      LDC_SPLIT_A(ahA, 0, p.x, p.y)
+      LDC_SPLIT_B(alA, 0, p.x, p.y)
+      LDC_SPLIT_A(ahA, 1, p.z, p.w)
+      LDC_SPLIT_B(alA, 1, p.z, p.w)
+      LDC_SPLIT_A(ahA, 2, q.x, q.y)
+      LDC_SPLIT_B(alA, 2, q.x, q.y)
+      LDC_SPLIT_A(ahA, 3, q.z, q.w)
+      LDC_SPLIT_B(alA, 3, q.z, q.w)
+    }
+    LDC_SB;
+
+    unsigned sb = 0;          // LDS byte offset of stage kt
+    int st = 0;               // stage index of k-step kt
+    for (int kt = k0; kt < k1; ++kt) {
+      const int st1 = st == NSTAGE - 1 ? 0 : st + 1;   // stage of kt+1
+      const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1; // stage of kt+2 ( = stage of kt-1)
+      const unsigned sb1 = st1 * STAGE_B;
+      const bool dma2 = kt + 2 < k1;  // second half of k-step kt+2's DMAs
+      const bool dma3 = kt + 3 < k1;  // first half of k-step kt+3's DMAs (into stage st, free behind barrier(kt+1))
+      // ---------------- H = (kt, 0); H+1 = (kt, 1), same stage ----------------
+      // W fragments of H were issued in the previous half-step: [.. l0 h0 .. l1 h1 .. l2 h2 .. l3 h3]
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(h0), "+v"(l0));
+      LDC_HALF_STEP(ahA, alA, ahB, alB, sb, c10, c11,
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(h1), "+v"(l1));, dma2, kt + 2, st2, 1)
+      // ---------------- H = (kt, 1); H+1 = (kt+1, 0), next stage ----------------
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+      if (kt + 1 < k1) {
+        // k-step kt+1 landed: its DMAs precede all ND of k-step kt+2
+        if (dma2) {
+          if constexpr (ND == 6) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          }
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      // (in the last k-step the reads of H+1 fetch stale ring data that is never used; they only keep the loop
+      // body branch-free around registers that are in flight)
+      LDC_HALF_STEP(ahB, alB, ahA, alA, sb1, c00, c01, , dma3, kt + 3, st, 0)
+      st = st1;
+      sb = sb1;
+    }
+    // drain the (unused) reads of the last half-step before their registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+#undef LDC_READ_PQ
+#undef LDC_HALF_STEP
+#undef LDC_SPLIT_A
+#undef LDC_SPLIT_B
+#undef LDC_MFMA
+#undef LDC_SB
     // all waves must be done reading the ring before the next segment's prologue overwrites stage 0/1
     __builtin_amdgcn_s_barrier();
+    if (seg_ == 0) { LDC_STAMP_CLK(14) }
+    LDC_STAMP(2 + 4 * seg_)
 
     if (k0 == 0 && k1 == P.kt) {
-      tile_epilogue(P, b, bm, bn, acc, wave, lane);
+      tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
     } else {
       float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
       if (a.counters == nullptr) {
@@ -341,6 +531,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
           *flag = last;
         }
         __syncthreads();
+        LDC_STAMP(3 + 4 * seg_)
         const unsigned is_last = *flag;
         __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
         if (is_last) {
@@ -358,15 +549,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(SKArgs a) {
               if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
           }
-          tile_epilogue(P, b, bm, bn, acc, wave, lane);
+          tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
         }
       }
     }
     u += k1 - k0;
+    LDC_STAMP(4 + 4 * seg_)
+#ifdef LDC_GEMM_STAMPS
+    if (seg_ < 2) ++seg_;
+#endif
   }
+  LDC_STAMP(15)
 }
 
-__global__ __launch_bounds__(512) void gemm_bf16x3_dma_fixup_kernel(SKArgs a) {
+template <int BM>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_fixup_kernel(SKArgs a) {
+  constexpr int SLOT_FLOATS = BM * BN;
   const long long t = blockIdx.x;
   int pi = 0;
 #pragma unroll
@@ -401,16 +599,19 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_fixup_kernel(SKArgs a) {
   }
   const int bm = tile % P.tm;
   const int bnb = tile / P.tm;
-  tile_epilogue(P, bnb / P.tn, bm, bnb % P.tn, acc, wave, lane);
+  tile_epilogue<BM>(P, bnb / P.tn, bm, bnb % P.tn, acc, wave, lane);
 }
 
 }  // namespace
 
 // returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back)
-int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
-                                void* stream) {
-  LDC_CHECK_PTR(problems);
-  if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
+namespace {
+
+template <int BM>
+int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+  constexpr int SLOT_FLOATS = BM * BN;
+  constexpr int STAGE_B = (BM + BN) * ROW_B;
+  constexpr int CUS = 256;  // one workgroup per CU
   SKArgs a{};
   a.np = n;
   long long U = 0, tiles = 0;
@@ -448,7 +649,7 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
   // Grid size: at most one 8-wave workgroup per CU, and -- when every problem has the same k-depth -- a divisor of
   // tiles * s for a small split factor s, so that every range starts on a (1/s)-tile boundary: all workgroups then
   // walk K in phase and the panels shared inside an XCD are fetched once (otherwise plain equal ranges).
-  long long G = 256;
+  long long G = CUS;
   {
     bool same_kt = true;
     for (int i = 1; i < n; ++i) same_kt = same_kt && (a.pr[i].kt == a.pr[0].kt);
@@ -492,14 +693,35 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
   const size_t lds = NSTAGE * STAGE_B;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     attr_set = true;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gemm_bf16x3_dma_kernel, dim3(a.G), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<BM>, dim3(a.G), dim3(BM * 2), lds, s, a);
   int st = ldc_launch_status();
   if (st != LDC_OK || a.counters != nullptr) return st;
-  hipLaunchKernelGGL(gemm_bf16x3_dma_fixup_kernel, dim3(static_cast<unsigned>(tiles)), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(gemm_bf16x3_dma_fixup_kernel<BM>, dim3(static_cast<unsigned>(tiles)), dim3(BM * 2), 0, s, a);
   return ldc_launch_status();
+}
+
+}  // namespace
+
+int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                                void* stream) {
+  LDC_CHECK_PTR(problems);
+  if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
+  // Tile height: 256 rows when whole tiles fill the chip (two waves per SIMD, less operand traffic per FLOP);
+  // 128 rows when they do not -- half-height tiles then double the tile count, so fewer (or no) tiles are split
+  // along K and fewer rows are padding.  LDC_BF16X3_BM = 128 / 256 forces one (measurement aid).
+  long long tiles256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ldc_gemm_desc& d = problems[i].d;
+    if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return LDC_ERR_ARG;
+    tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
+  }
+  bool small = tiles256 <= 128;  // measured cross-over (tools/gemm_bench.py, both heights forced): about half the CUs
+  if (const char* e = getenv("LDC_BF16X3_BM")) small = (atoi(e) == 128);
+  return small ? launch_dma<128>(problems, n, workspace, workspace_bytes, stream)
+               : launch_dma<256>(problems, n, workspace, workspace_bytes, stream);
 }

@@ -15,7 +15,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libladcast_hip.so")
+# LDC_LIB_PATH: diagnostic builds only (e.g. the in-kernel stamp build made by `make stamps`)
+LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 
