@@ -106,24 +106,34 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(float* __restrict_
 
 // ---------------------------------------------------------------------------
 // mean over token rows: y[b][c] = mean_r x[b][r][c]
-// block = 64 columns x 4 row-groups; LDS combine of the 4 partial sums
+// block = 64 columns x 16 row-groups, 4 loads in flight per thread; LDS combine of the 16 partial sums
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows,
-                                                        int D, int ldx, long long x_bs) {
-  __shared__ float part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+__global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows,
+                                                         int D, int ldx, long long x_bs) {
+  __shared__ float part[16][64];
+  const int c = threadIdx.x & 63;
+  const int col = blockIdx.x * 64 + c;
   const int g = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  float s = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight per thread
   if (col < D) {
     const float* xb = x + b * x_bs + col;
-    for (int r = g; r < rows; r += 4) s += xb[static_cast<long long>(r) * ldx];
+    int r = g;
+    for (; r + 48 < rows; r += 64) {
+      s0 += xb[static_cast<long long>(r) * ldx];
+      s1 += xb[static_cast<long long>(r + 16) * ldx];
+      s2 += xb[static_cast<long long>(r + 32) * ldx];
+      s3 += xb[static_cast<long long>(r + 48) * ldx];
+    }
+    for (; r < rows; r += 16) s0 += xb[static_cast<long long>(r) * ldx];
   }
-  part[g][threadIdx.x & 63] = s;
+  part[g][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && col < D) {
-    const int c = threadIdx.x & 63;
-    y[static_cast<long long>(b) * D + col] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / static_cast<float>(rows);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][c];
+    y[static_cast<long long>(b) * D + col] = t / static_cast<float>(rows);
   }
 }
 
@@ -145,50 +155,84 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------
 // small-M linear: y[r][n] = act_out(sum_k W[n][k] act_in(x[r % x_rows][k]) + bias[n]) + add[r % add_rows][n]
-// one wave per output column n, 8 rows per pass; W streamed once from HBM (float4/lane).
+// HBM-bound weight streaming (the AdaLN modulation GEMVs: one row per member).  A workgroup stages act_in(x) for
+// its <= 8 rows in LDS once (K chunks of <= 2048), then each wave streams LS_CPW weight rows at a time: LS_CPW x
+// K/256 float4 loads in flight per lane, every W byte read once.
 // ---------------------------------------------------------------------------
 constexpr int LS_ROWS = 8;
+constexpr int LS_CPW_MAX = 4; // output columns per wave: 4 for wide outputs, 1 when that would leave CUs idle
+constexpr int LS_KC = 2048;   // K chunk staged in LDS (8 rows x 2048 x 4 B = 64 KiB)
 
+template <int LS_CPW>
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int x_rows,
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ add, int add_rows,
-                                                           float* __restrict__ y, int rows, int N, int K, int act_in,
+                                                           float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
                                                            int act_out) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [rows_here][kc]
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
   const int r_base = blockIdx.y * LS_ROWS;
-  if (n >= N) return;
-  const float* wr = W + static_cast<long long>(n) * K;
-  float acc[LS_ROWS];
+  const int rows_here = rows - r_base < LS_ROWS ? rows - r_base : LS_ROWS;
+  const int n0 = (blockIdx.x * 4 + wave) * LS_CPW;
+  const float* wr[LS_CPW];
 #pragma unroll
-  for (int i = 0; i < LS_ROWS; ++i) acc[i] = 0.f;
-  const int nv4 = K >> 2;
-  for (int c = lane; c < nv4; c += 64) {
-    const float4 w = reinterpret_cast<const float4*>(wr)[c];
+  for (int j = 0; j < LS_CPW; ++j) {
+    const int n = n0 + j < N ? n0 + j : N - 1;  // clamped: columns past N are computed and dropped
+    wr[j] = W + static_cast<long long>(n) * K;
+  }
+  float acc[LS_CPW][LS_ROWS];
 #pragma unroll
-    for (int i = 0; i < LS_ROWS; ++i) {
-      const int r = r_base + i;
-      if (r < rows) {
-        float4 xv = reinterpret_cast<const float4*>(x + static_cast<long long>(r % x_rows) * K)[c];
-        if (act_in != LDC_ACT_NONE) {
-          xv.x = ldc_apply_act(xv.x, act_in);
-          xv.y = ldc_apply_act(xv.y, act_in);
-          xv.z = ldc_apply_act(xv.z, act_in);
-          xv.w = ldc_apply_act(xv.w, act_in);
+  for (int j = 0; j < LS_CPW; ++j)
+#pragma unroll
+    for (int i = 0; i < LS_ROWS; ++i) acc[j][i] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += kc) {
+    const int kn = K - k0 < kc ? K - k0 : kc;  // multiple of 4
+    const int nv4 = kn >> 2;
+    if (k0) __syncthreads();
+    for (int idx = threadIdx.x; idx < rows_here * nv4; idx += 256) {
+      const int i = idx / nv4, c = idx - i * nv4;
+      float4 xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
+      if (act_in != LDC_ACT_NONE) {
+        xv.x = ldc_apply_act(xv.x, act_in);
+        xv.y = ldc_apply_act(xv.y, act_in);
+        xv.z = ldc_apply_act(xv.z, act_in);
+        xv.w = ldc_apply_act(xv.w, act_in);
+      }
+      reinterpret_cast<float4*>(xs + i * kc)[c] = xv;
+    }
+    __syncthreads();
+    if (n0 < N) {
+      for (int c = lane; c < nv4; c += 64) {
+        float4 w[LS_CPW];
+#pragma unroll
+        for (int j = 0; j < LS_CPW; ++j) w[j] = reinterpret_cast<const float4*>(wr[j] + k0)[c];
+#pragma unroll
+        for (int i = 0; i < LS_ROWS; ++i) {
+          if (i < rows_here) {
+            const float4 xv = reinterpret_cast<const float4*>(xs + i * kc)[c];
+#pragma unroll
+            for (int j = 0; j < LS_CPW; ++j) acc[j][i] += (w[j].x * xv.x + w[j].y * xv.y) + (w[j].z * xv.z + w[j].w * xv.w);
+          }
         }
-        acc[i] += (w.x * xv.x + w.y * xv.y) + (w.z * xv.z + w.w * xv.w);
       }
     }
   }
+  if (n0 >= N) return;
 #pragma unroll
-  for (int i = 0; i < LS_ROWS; ++i) {
-    const float s = wave_sum(acc[i]);
-    const int r = r_base + i;
-    if (lane == 0 && r < rows) {
-      float v = s + (bias ? bias[n] : 0.f);
-      v = ldc_apply_act(v, act_out);
-      if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
-      y[static_cast<long long>(r) * N + n] = v;
+  for (int j = 0; j < LS_CPW; ++j) {
+    const int n = n0 + j;
+#pragma unroll
+    for (int i = 0; i < LS_ROWS; ++i) {
+      const float sum = wave_sum(acc[j][i]);
+      const int r = r_base + i;
+      if (lane == 0 && i < rows_here && n < N) {
+        float v = sum + (bias ? bias[n] : 0.f);
+        v = ldc_apply_act(v, act_out);
+        if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
+        y[static_cast<long long>(r) * N + n] = v;
+      }
     }
   }
 }
@@ -236,7 +280,7 @@ extern "C" int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, i
   LDC_CHECK_PTR(y);
   if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
   dim3 grid(ldc_cdiv(D, 64), B);
-  hipLaunchKernelGGL(mean_rows_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx, x_bs);
+  hipLaunchKernelGGL(mean_rows_kernel, grid, dim3(1024), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx, x_bs);
   return ldc_launch_status();
 }
 
@@ -267,8 +311,26 @@ extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, cons
   if (K & 3) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(W);
-  dim3 grid(ldc_cdiv(N, 4), ldc_cdiv(rows, LS_ROWS));
-  hipLaunchKernelGGL(linear_small_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add,
-                     add_rows, y, rows, N, K, act_in, act_out);
+  const int kc = K < LS_KC ? K : LS_KC;
+  const int rows_max = rows < LS_ROWS ? rows : LS_ROWS;
+  const size_t lds = static_cast<size_t>(rows_max) * kc * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_kernel<LS_CPW_MAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
+    attr_set = true;
+  }
+  const int row_groups = ldc_cdiv(rows, LS_ROWS);
+  if (static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
+    dim3 grid(ldc_cdiv(N, 4 * LS_CPW_MAX), row_groups);
+    hipLaunchKernelGGL(linear_small_kernel<LS_CPW_MAX>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W,
+                       bias, add, add_rows, y, rows, N, K, kc, act_in, act_out);
+  } else {
+    dim3 grid(ldc_cdiv(N, 4), row_groups);
+    hipLaunchKernelGGL(linear_small_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add,
+                       add_rows, y, rows, N, K, kc, act_in, act_out);
+  }
   return ldc_launch_status();
 }

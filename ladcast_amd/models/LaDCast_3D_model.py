@@ -162,8 +162,9 @@ class _DualBlockP(nn.Module):
 class _Workspace:
     """Device scratch for one (B, Nx, Nc) problem; allocated once, reused by every forward."""
 
-    def __init__(self, dev, B, Bt, Nx, Nc, D, C_in, C_out):
+    def __init__(self, dev, B, Bt, Nx, Nc, D, C_in, C_out, n_mod):
         f = dict(device=dev, dtype=torch.float32)
+        self.mods = torch.empty(B, n_mod, **f)  # every temb-driven AdaLN modulation vector of one forward
         S = Nx + Nc
         self.h = torch.empty(B, S, D, **f)
         self.nh = torch.empty(B, S, D, **f)
@@ -338,6 +339,22 @@ class LaDCastTransformer3DModel(ModelMixin):
         d = self.inner_dim
         plan.wx = self.x_embedder.proj.weight.reshape(d, -1).contiguous()
         plan.wc = self.context_embedder.proj.weight.reshape(d, -1).contiguous()
+        # split-bf16 mode: the patch embeds run on the bf16x3 kernel with K zero-padded to a multiple of 32
+        plan.kx_pad = -(-plan.wx.shape[1] // 32) * 32
+        plan.kc_pad = -(-plan.wc.shape[1] // 32) * 32
+        # Every AdaLN modulation driven by the conditioning embedding (dual blocks: 6D per stream, single blocks: 3D,
+        # output head: 2D) is one [sum N, D] matrix: one HBM-bound GEMV launch per forward instead of one per block.
+        mods = []
+        for blk in self.transformer_blocks:
+            mods += [blk.norm1.linear, blk.norm1_context.linear]
+        mods += [blk.norm.linear for blk in self.single_transformer_blocks]
+        mods.append(self.norm_out.linear)
+        plan.mod_w = torch.cat([m.weight for m in mods], dim=0).contiguous()
+        plan.mod_b = torch.cat([m.bias for m in mods], dim=0).contiguous()
+        plan.mod_off, off = {}, 0
+        for m in mods:
+            plan.mod_off[id(m)] = off
+            off += m.weight.shape[0]
         # split-bf16 mode: every token-stream GEMM weight gets a pre-split [N][K/8][hi|lo] copy (same bytes as fp32)
         plan.split = self.gemm_precision == "bf16x3"
         plan.packed = {}
@@ -354,6 +371,10 @@ class LaDCastTransformer3DModel(ModelMixin):
                 ws += [blk.proj_mlp.weight, blk.proj_out.weight]
             for w in ws:
                 plan.packed[id(w)] = hip.pack_weight_bf16x2(w)
+            for w, kp in ((plan.wx, plan.kx_pad), (plan.wc, plan.kc_pad)):
+                wp = torch.zeros(w.shape[0], kp, device=w.device, dtype=w.dtype)
+                wp[:, : w.shape[1]] = w
+                plan.packed[id(w)] = hip.pack_weight_bf16x2(wp)
         self._plan = plan
 
     # -- cached tables -----------------------------------------------------------------------
@@ -499,7 +520,7 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         key = (B, Bt, Nx, Nc)
         if key not in self._ws:
-            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(C_in, Cc), C_out)
+            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(plan.kx_pad, plan.kc_pad), C_out, plan.mod_w.shape[0])
         ws = self._ws[key]
         pc, ps, cc, cs = self._rope_tables(R, T_in, Hh, Ww, dev)
         SD = S * D
@@ -519,12 +540,21 @@ class LaDCastTransformer3DModel(ModelMixin):
         def run1(A, W, C, **kw):
             hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
 
-        hip.chan_to_token(hidden_states, ws.xtok, B=B, C=C_in, N=Nx, ldo=C_in)
-        hip.chan_to_token(conditioning_tensors, ws.ctok, B=B, C=Cc, N=Nc, ldo=Cc)
-        hip.gemm_grouped([  # K = 84: fp32 path in both modes (tiny, K not a multiple of 8)
-            hip.gemm_problem(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias),
-            hip.gemm_problem(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
-        ])
+        if split:
+            KX, KC = plan.kx_pad, plan.kc_pad
+            xtok, ctok = ws.xtok.view(-1)[: B * Nx * KX].view(B, Nx, KX), ws.ctok.view(-1)[: B * Nc * KC].view(B, Nc, KC)
+            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX)
+            hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC)
+            run([
+                G(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias),
+                G(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
+            ])
+        else:
+            hip.chan_to_token(hidden_states, ws.xtok.view(-1)[: B * Nx * C_in].view(B, Nx, C_in), B=B, C=C_in, N=Nx, ldo=C_in)
+            hip.chan_to_token(conditioning_tensors, ws.ctok.view(-1)[: B * Nc * Cc].view(B, Nc, Cc), B=B, C=Cc, N=Nc, ldo=Cc)
+            # K = 84: exact-fp32 tile-per-workgroup kernel (3 k-steps: nothing for stream-K to balance)
+            hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
+            hip.gemm(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias)
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
@@ -552,15 +582,19 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._combined_embed(self.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb)
         if te is not None:
             hip.temb_modulate(ws.temb, te, B=B, D=D, te_rows=te.shape[0])
+        NM = plan.mod_w.shape[0]
+        hip.linear_small(ws.temb, plan.mod_w, ws.mods, rows=B, N=NM, K=D, bias=plan.mod_b, act_in=hip.ACT_SILU)
+
+        def mod_of(linear, width):
+            o = plan.mod_off[id(linear)]
+            return ws.mods[:, o : o + width]
 
         # 4. dual-stream blocks, models/LaDCast_3D_model.py:514-566
         for blk in self.transformer_blocks:
             pa = plan.attn[id(blk.attn)]
-            mx, mc = ws.mod_a, ws.mod_b
-            hip.linear_small(ws.temb, blk.norm1.linear.weight, mx, rows=B, N=6 * D, K=D, bias=blk.norm1.linear.bias, act_in=hip.ACT_SILU)
-            hip.linear_small(ws.temb, blk.norm1_context.linear.weight, mc, rows=B, N=6 * D, K=D, bias=blk.norm1_context.linear.bias, act_in=hip.ACT_SILU)
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=6 * D, mode=0, eps=1e-6)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=6 * D, mode=0, eps=1e-6)
+            mx, mc = mod_of(blk.norm1.linear, 6 * D), mod_of(blk.norm1_context.linear, 6 * D)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=NM, mode=0, eps=1e-6)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=NM, mode=0, eps=1e-6)
             run([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c),
@@ -570,11 +604,11 @@ class LaDCastTransformer3DModel(ModelMixin):
             self._attention(ws, B, S, 0, ws.qkv, ws.att, D, SD)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
             run([
-                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=6 * D, R=h_x, ldr=D, r_bs=SD),
-                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=6 * D, R=h_c, ldr=D, r_bs=SD),
+                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD),
+                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD),
             ])
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=6 * D, mode=0, eps=1e-7)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7)
             up, down = [], []
             for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
                 f0, f2 = ff.net[0].proj, ff.net[2]
@@ -582,18 +616,17 @@ class LaDCastTransformer3DModel(ModelMixin):
                 hid = ws.cat.view(-1)[off * B * F :]  # [B, rows, F] slab inside the concat scratch
                 up.append(G(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH))
                 down.append(G(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
-                              gate=mod[:, 5 * D :], gate_bs=6 * D, R=hs, ldr=D, r_bs=SD))
+                              gate=mod[:, 5 * D :], gate_bs=NM, R=hs, ldr=D, r_bs=SD))
             run(up)
             run(down)
 
         # 5. single-stream blocks, models/LaDCast_3D_model.py:426-468
         for blk in self.single_transformer_blocks:
             pa = plan.attn[id(blk.attn)]
-            mod = ws.mod_a
+            mod = mod_of(blk.norm.linear, 3 * D)
             F = blk.proj_mlp.weight.shape[0]
             W5 = D + F
-            hip.linear_small(ws.temb, blk.norm.linear.weight, mod, rows=B, N=3 * D, K=D, bias=blk.norm.linear.bias, act_in=hip.ACT_SILU)
-            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=3 * D, mode=0, eps=1e-6)
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6)
             run([
                 G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
@@ -602,11 +635,11 @@ class LaDCastTransformer3DModel(ModelMixin):
             self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
             self._attention(ws, B, S, 0, ws.qkv, ws.cat, W5, S * W5)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
-                        gate=mod[:, 2 * D :], gate_bs=3 * D, R=ws.h, ldr=D, r_bs=SD)
+                        gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD)
 
         # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
-        hip.linear_small(ws.temb, self.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=self.norm_out.linear.bias, act_in=hip.ACT_SILU)
-        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=ws.mod_a, shift=ws.mod_a[:, D:], mod_bs=2 * D, mode=0, eps=1e-7)
+        mo = mod_of(self.norm_out.linear, 2 * D)
+        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mo, shift=mo[:, D:], mod_bs=NM, mode=0, eps=1e-7)
         run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)

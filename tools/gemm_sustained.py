@@ -1,0 +1,36 @@
+"""bf16x3 GEMM per-shape time under SUSTAINED load (the chip lowers its clock after ~1 s of MFMA-dense work; a
+20-iteration burst after idle reads 15-25 % optimistic -- the model runs in the settled state).
+usage: python tools/gemm_sustained.py [--grouped] ; LDC_BF16X3_BM=128/256 forces a tile height"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ladcast_amd.hip as hip
+
+# the 375M model's launches at one member: (list of (M, N, K)) per grouped call
+calls = {
+    "refiner qkv": [(450, 4608, 1536)], "refiner ff up": [(450, 6144, 1536)], "refiner ff down": [(450, 1536, 6144)],
+    "refiner proj_in": [(450, 1536, 1536)],
+    "dual qkv": [(1800, 4608, 1536), (450, 4608, 1536)], "dual out": [(1800, 1536, 1536), (450, 1536, 1536)],
+    "dual ff up": [(1800, 6144, 1536), (450, 6144, 1536)], "dual ff down": [(1800, 1536, 6144), (450, 1536, 6144)],
+    "single qkv+mlp": [(2250, 6144, 1536), (2250, 4608, 1536)], "single out": [(2250, 1536, 7680)],
+    "4096^3": [(4096, 4096, 4096)],
+}
+warm_s = float(os.environ.get("WARM_S", "1.5"))
+for name, probs in calls.items():
+    ps = []
+    flops = 0
+    for (M, N, K) in probs:
+        A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); C = torch.empty(M, N, device="cuda")
+        ps.append(hip.gemm_problem(A, hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K))
+        flops += 2 * M * N * K
+    fn = lambda: hip.gemm_grouped(ps, split_bf16=True)
+    t_end = time.time() + warm_s
+    while time.time() < t_end:
+        for _ in range(50): fn()
+        torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(200): fn()
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / 200
+    print(f"{name:16s} {us:8.1f} us  {flops / us / 1e6:6.1f} TF/s")
