@@ -122,6 +122,24 @@ int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B
 int ldc_attn_fwd_bf16x3(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
                         int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
 
+/* Split-bf16 attention in two steps, for callers that also need the q/k RMSNorm + rotary embedding:
+ *   ldc_attn_pack_bf16x3     reads Q, K, V (same views as ldc_attn_fwd), applies to q and k the per-head
+ *                            RMSNorm(128, eps, weight) and the adjacent-pair rotary embedding of ldc_qk_rmsnorm_rope
+ *                            (token rows [0, split_row) use wq0/wk0/cos0/sin0, rows [split_row, S) use
+ *                            wq1/wk1/cos1/sin1 with table row = row - split_row; NULL weights = no norm,
+ *                            NULL tables = no RoPE), splits every operand into bf16 hi + lo ONCE and writes
+ *                            them as ready-made LDS tile images into `packed` (ldc_attn_packed_bytes bytes);
+ *   ldc_attn_fwd_packed_bf16x3  the attention itself on those images (tiles brought in by LDS-DMA).
+ * Together they replace attn.norm_q/norm_k/norm_added_q/norm_added_k + apply_rotary_emb +
+ * F.scaled_dot_product_attention, models/LaDCast_3D_model.py:103-169,183-203.  Q, K, V are not modified. */
+long long ldc_attn_packed_bytes(int B, int S, int H);
+int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, int S, int H, int ld_qkv,
+                         long long qkv_bs, int split_row, const float* wq0, const float* wk0,
+                         const float* cos0, const float* sin0, const float* wq1, const float* wk1,
+                         const float* cos1, const float* sin1, float eps, void* packed, void* stream);
+int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
+                               void* stream);
+
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),
  * for token rows [row0, row0+rows) of every batch of a fused QKV buffer.

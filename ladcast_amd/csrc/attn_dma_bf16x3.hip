@@ -1,0 +1,573 @@
+// Split-bf16 ("bf16x3") attention, second generation: operands are split ONCE per attention call by a pack
+// kernel (which also applies the per-head q/k RMSNorm and the rotary embedding), and the attention kernel brings
+// whole pre-arranged K / V^T tiles into LDS by LDS-DMA (global_load_lds_dwordx4).
+//
+// Why: in attn_bf16x3.hip every query block re-reads raw fp32 K and V and re-splits them (S/128 = 18 times per
+// head at S = 2250): per 32-key tile and wave that is ~112 VALU instructions, 20 global loads (16 of them dword
+// gathers for the V transpose) and 8 LDS stores next to 48 MFMAs -- the kernel measured 11 VALU instructions per
+// MFMA and 28 % MFMA busy.  Here a tile costs 8 DMA instructions per wave and no VALU; what is left beside the
+// MFMAs is the softmax and the split of P.
+//
+// Packed operand buffer (ldc_attn_packed_bytes), nt = ceil(S / 32) key tiles, Sp = 32 nt:
+//   Qp [B][H][Sp]  512 B per query: [hi: 16 chunks x 16 B | lo: 16 chunks], chunk = 8 consecutive head-dim values,
+//                  pre-scaled by log2(e) / sqrt(128);
+//   Kp [B][H][nt]  16 KiB per tile = the LDS image: 32 rows (keys) x 512 B, chunk c (0..15 hi, 16..31 lo) of row r at
+//                  slot (c & 16) | ((c & 15) ^ (r & 15))   (conflict-free ds_read_b128 of one chunk column over 32 rows);
+//   Vp [B][H][nt]  16 KiB per tile = the LDS image of V^T: 128 rows (head-dim d) x 128 B = [hi 4 chunks | lo 4 chunks],
+//                  chunk 2t+h holds keys 16t + 8(j>>2) + 4h + (j&3), j = 0..7 (the order in which a 32x32 accumulator's
+//                  registers hold keys, so P needs no shuffle), chunk c of row d at slot c ^ ((d >> 1) & 7).
+//   Rows / keys past S are zero.
+// Attention workgroup = 8 waves = 128 queries of one (batch, head); waves 0-3 sweep the first half of the key
+// tiles, waves 4-7 the second half (two independent 2-stage rings of 32 KiB stages), merged through LDS at the end
+// (as attn_bf16x3.hip).  Per iteration: vmcnt(0) + barrier (tile t landed, everyone is done with tile t-1) ->
+// issue the DMA of tile t+1 -> S^T = K.Q^T (24 MFMAs) -> online softmax -> O^T += V^T.P^T (24 MFMAs).
+// Fragment reads are untracked inline-asm ds_read_b128 with counted lgkmcnt waits (a compiler-visible LDS read would
+// make hipcc drain vmcnt(0), i.e. wait for the next tile's DMA, in front of it), four fragment pairs in flight.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int QB = 128;
+constexpr int KT = 32;
+constexpr int TILE_B = 16384;            // one K tile image = one V^T tile image
+constexpr int STAGE_B = 2 * TILE_B;      // K | V^T
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned split_pair(float a, float b, float& ra, float& rb) {
+  bf16x2 v;
+  v.x = static_cast<__bf16>(a);
+  v.y = static_cast<__bf16>(b);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  ra = a - __uint_as_float(u << 16);
+  rb = b - __uint_as_float(u & 0xffff0000u);
+  return u;
+}
+__device__ __forceinline__ unsigned pack_pair(float a, float b) {
+  bf16x2 v;
+  v.x = static_cast<__bf16>(a);
+  v.y = static_cast<__bf16>(b);
+  return __builtin_bit_cast(unsigned, v);
+}
+// 8 fp32 -> hi / lo packed bf16 (16 B each)
+__device__ __forceinline__ void split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7,
+                                       uint4& h, uint4& l) {
+  float r0, r1, r2, r3, r4, r5, r6, r7;
+  h.x = split_pair(x0, x1, r0, r1);
+  h.y = split_pair(x2, x3, r2, r3);
+  h.z = split_pair(x4, x5, r4, r5);
+  h.w = split_pair(x6, x7, r6, r7);
+  l.x = pack_pair(r0, r1);
+  l.y = pack_pair(r2, r3);
+  l.z = pack_pair(r4, r5);
+  l.w = pack_pair(r6, r7);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pack: [RMSNorm(128) * weight -> adjacent-pair RoPE] on q and k (same operation order as qk_rmsnorm_rope_kernel),
+// split, and lay out as above.  One workgroup per (32-row tile, head, batch).
+// ------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+  const float* Q;
+  const float* K;
+  const float* V;
+  int S, H, ld;
+  long long bs;
+  int split_row;  // rows [0, split_row): segment 0, rows [split_row, S): segment 1
+  const float* wq[2];
+  const float* wk[2];
+  const float* cs[2];
+  const float* sn[2];
+  float eps, qscale;
+  unsigned char* Qp;
+  unsigned char* Kp;
+  unsigned char* Vp;
+  int nt;
+};
+
+__device__ __forceinline__ void norm_rope16(float (&x)[16], const float* __restrict__ w, const float* __restrict__ cs,
+                                            const float* __restrict__ sn, int trow, int d0, float eps) {
+  if (w) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) ss += x[i] * x[i] + x[i + 1] * x[i + 1];
+    // the 8 threads of a row are 8 consecutive lanes
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = x[i] * r * w[d0 + i];
+  }
+  if (cs) {
+    const float* c = cs + static_cast<long long>(trow) * 128 + d0;
+    const float* s = sn + static_cast<long long>(trow) * 128 + d0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const float ox = x[i] * c[i] + (-x[i + 1]) * s[i];
+      const float oy = x[i + 1] * c[i + 1] + x[i] * s[i + 1];
+      x[i] = ox;
+      x[i + 1] = oy;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
+  // the two tile images are assembled in LDS and leave as linear 1 KiB-per-wave-instruction copies
+  __shared__ __attribute__((aligned(16))) float vs[KT][HD + 4];
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[TILE_B];
+  __shared__ __attribute__((aligned(16))) unsigned char vimg[TILE_B];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int r = tid >> 3, sg = tid & 7;
+  const int row = t * KT + r;
+  const bool ok = row < p.S;
+  const int seg = row < p.split_row ? 0 : 1;
+  const int trow = ok ? (seg ? row - p.split_row : row) : 0;  // rows past S: any valid table row (their output is zeroed)
+  const long long src = static_cast<long long>(b) * p.bs + static_cast<long long>(ok ? row : 0) * p.ld + head * HD + 16 * sg;
+  const long long bh = static_cast<long long>(b) * p.H + head;
+
+  // every load of the thread is issued before the first use
+  float xq[16], xk[16];
+  float4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = reinterpret_cast<const float4*>(p.Q + src)[i];
+    xq[4 * i] = a.x; xq[4 * i + 1] = a.y; xq[4 * i + 2] = a.z; xq[4 * i + 3] = a.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = reinterpret_cast<const float4*>(p.K + src)[i];
+    xk[4 * i] = a.x; xk[4 * i + 1] = a.y; xk[4 * i + 2] = a.z; xk[4 * i + 3] = a.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xv[i] = reinterpret_cast<const float4*>(p.V + src)[i];
+
+  // ---- v: raw tile to LDS for the transpose ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 a = xv[i];
+    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&vs[r][16 * sg + 4 * i]) = a;
+  }
+  // ---- q: rows are contiguous 512 B in Qp ----
+  norm_rope16(xq, p.wq[seg], p.cs[seg], p.sn[seg], trow, 16 * sg, p.eps);
+  {
+    const float sc = ok ? p.qscale : 0.f;
+    unsigned char* dst = p.Qp + (bh * (static_cast<long long>(p.nt) * KT) + row) * 512;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      uint4 h, l;
+      split8(xq[8 * e] * sc, xq[8 * e + 1] * sc, xq[8 * e + 2] * sc, xq[8 * e + 3] * sc, xq[8 * e + 4] * sc,
+             xq[8 * e + 5] * sc, xq[8 * e + 6] * sc, xq[8 * e + 7] * sc, h, l);
+      *reinterpret_cast<uint4*>(dst + (2 * sg + e) * 16) = h;
+      *reinterpret_cast<uint4*>(dst + 256 + (2 * sg + e) * 16) = l;
+    }
+  }
+  // ---- k -> LDS image ----
+  norm_rope16(xk, p.wk[seg], p.cs[seg], p.sn[seg], trow, 16 * sg, p.eps);
+  {
+    const float m = ok ? 1.f : 0.f;
+    unsigned char* dst = kimg + r * 512;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      uint4 h, l;
+      split8(xk[8 * e] * m, xk[8 * e + 1] * m, xk[8 * e + 2] * m, xk[8 * e + 3] * m, xk[8 * e + 4] * m, xk[8 * e + 5] * m,
+             xk[8 * e + 6] * m, xk[8 * e + 7] * m, h, l);
+      const int slot = (2 * sg + e) ^ (r & 15);
+      *reinterpret_cast<uint4*>(dst + slot * 16) = h;
+      *reinterpret_cast<uint4*>(dst + 256 + slot * 16) = l;
+    }
+  }
+  __syncthreads();
+  // ---- v^T -> LDS image ----
+  {
+    const int d = tid & 127, g = tid >> 7;
+    unsigned char* dst = vimg + d * 128;
+    const int sw = (d >> 1) & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int vg = g + 2 * i, tt = vg >> 1, hh = vg & 1;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = vs[16 * tt + 8 * (j >> 2) + 4 * hh + (j & 3)][d];
+      uint4 h, l;
+      split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], h, l);
+      *reinterpret_cast<uint4*>(dst + ((vg) ^ sw) * 16) = h;
+      *reinterpret_cast<uint4*>(dst + ((4 + vg) ^ sw) * 16) = l;
+    }
+  }
+  __syncthreads();
+  {
+    uint4* kd = reinterpret_cast<uint4*>(p.Kp + (bh * p.nt + t) * TILE_B);
+    uint4* vd = reinterpret_cast<uint4*>(p.Vp + (bh * p.nt + t) * TILE_B);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kd[tid + 256 * i] = reinterpret_cast<const uint4*>(kimg)[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vd[tid + 256 * i] = reinterpret_cast<const uint4*>(vimg)[tid + 256 * i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention on packed operands
+// ------------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const unsigned char* Qp;
+  const unsigned char* Kp;
+  const unsigned char* Vp;
+  float* O;
+  int S, H, ldo;
+  long long o_bs;
+  int nq, nt;
+};
+
+#define LDC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<unsigned long long>(p));
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int NGRP>
+__global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int grp = NGRP == 2 ? (threadIdx.x >> 8) : 0;  // key-range group 0 / 1
+  const int tid = threadIdx.x & 255;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int S = p.S;
+  int head, b, qblk;
+  {  // XCD-aware placement as attn_bf16x3.hip: contiguous runs of [batch][head][query block] per XCD
+    const int nq = p.nq, T = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    qblk = lin % nq;
+    const int hb = lin / nq;
+    head = hb % p.H;
+    b = hb / p.H;
+  }
+  const int q0 = qblk * QB + wave * 32;
+  const long long bh = static_cast<long long>(b) * p.H + head;
+  const int nt = p.nt;
+
+  // Q fragments: step s, element j <-> d = 16 s + 8 half + j = chunk 2 s + half
+  bf16x8 qh[8], ql[8];
+  {
+    int qrow = q0 + l31;
+    qrow = qrow < nt * KT ? qrow : nt * KT - 1;  // rows in [S, Sp) are zero in Qp; rows past Sp only exist in the last block
+    const unsigned char* qp = p.Qp + (bh * (static_cast<long long>(nt) * KT) + qrow) * 512 + 16 * half;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qh[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
+      ql[s] = *reinterpret_cast<const bf16x8*>(qp + 256 + 32 * s);
+    }
+  }
+
+  unsigned char* const ring = smem + grp * (2 * STAGE_B);
+  const unsigned ring_lds = lds_addr(ring);
+  const unsigned char* const Kt0 = p.Kp + bh * nt * TILE_B;
+  const unsigned char* const Vt0 = p.Vp + bh * nt * TILE_B;
+  // one tile = 16 K pieces + 16 V pieces of 1 KiB; wave w of the group issues pieces w, w+4, w+8, w+12 of each
+  auto issue_tile = [&](int t, int stage) {
+    const unsigned char* ks = Kt0 + static_cast<long long>(t) * TILE_B + lane * 16;
+    const unsigned char* vsrc = Vt0 + static_cast<long long>(t) * TILE_B + lane * 16;
+    unsigned char* dst = ring + stage * STAGE_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave + 4 * j;
+      dma16(ks + i * 1024, dst + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave + 4 * j;
+      dma16(vsrc + i * 1024, dst + TILE_B + i * 1024);
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -1.0e30f;
+  float l_run = 0.f;
+
+  const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
+  const int t_begin = grp ? nhalf : 0;
+  const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
+  if (t_begin < t_end) issue_tile(t_begin, 0);
+
+  // per-lane fragment addressing inside a stage
+  const unsigned kx = l31 & 15, vx = (l31 >> 1) & 7;
+  const unsigned k_row = l31 * 512;   // + ((2 st + half) ^ kx) * 16 (+ 256 for lo)
+  const unsigned v_row = TILE_B + l31 * 128;  // + 32 dd * 128 + ((2 tt + half) ^ vx) * 16 (lo: ^ 64)
+
+  for (int it = 0; it < nhalf; ++it) {
+    const int t = t_begin + it;
+    const bool active = t < t_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+      if (t + 1 < t_end) issue_tile(t + 1, (it + 1) & 1);
+      const unsigned sbase = ring_lds + (it & 1) * STAGE_B;
+      const unsigned ka = sbase + k_row;
+      const unsigned va = sbase + v_row;
+
+      // four fragment pairs in flight: K steps 0..7, then V pairs (tt, dd) 0..7 reuse the same registers
+      i32x4v fh0, fl0, fh1, fl1, fh2, fl2, fh3, fl3;
+#define LDC_RD_K(FH, FL, ST)                                                     \
+  {                                                                              \
+    const unsigned a_ = ka + (((2 * (ST) + half) ^ kx) << 4);                    \
+    LDC_DS_READ(FH, a_, 0);                                                      \
+    LDC_DS_READ(FL, a_, 256);                                                    \
+  }
+#define LDC_RD_V(FH, FL, J) /* pair J = 4 tt + dd */                             \
+  {                                                                              \
+    const unsigned a_ = va + ((J) & 3) * 4096 + (((2 * ((J) >> 2) + half) ^ vx) << 4); \
+    const unsigned b_ = a_ ^ 64u;                                                \
+    LDC_DS_READ(FH, a_, 0);                                                      \
+    LDC_DS_READ(FL, b_, 0);                                                      \
+  }
+#define LDC_W6(FH, FL) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(FH), "+v"(FL))
+#define LDC_WN(N, FH, FL) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FH), "+v"(FL))
+      LDC_RD_K(fh0, fl0, 0)
+      LDC_RD_K(fh1, fl1, 1)
+      LDC_RD_K(fh2, fl2, 2)
+      LDC_RD_K(fh3, fl3, 3)
+
+      // ---- S^T = K . Q^T  (24 MFMAs) ----
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#define LDC_QK(FH, FL, ST)                                                                                  \
+  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), qh[ST], s, 0, 0, 0);          \
+  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ql[ST], s, 0, 0, 0);          \
+  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], s, 0, 0, 0);
+      LDC_W6(fh0, fl0);
+      LDC_QK(fh0, fl0, 0)
+      LDC_RD_K(fh0, fl0, 4)
+      LDC_W6(fh1, fl1);
+      LDC_QK(fh1, fl1, 1)
+      LDC_RD_K(fh1, fl1, 5)
+      LDC_W6(fh2, fl2);
+      LDC_QK(fh2, fl2, 2)
+      LDC_RD_K(fh2, fl2, 6)
+      LDC_W6(fh3, fl3);
+      LDC_QK(fh3, fl3, 3)
+      LDC_RD_K(fh3, fl3, 7)
+      LDC_W6(fh0, fl0);
+      LDC_QK(fh0, fl0, 4)
+      LDC_RD_V(fh0, fl0, 0)
+      LDC_W6(fh1, fl1);
+      LDC_QK(fh1, fl1, 5)
+      LDC_RD_V(fh1, fl1, 1)
+      LDC_W6(fh2, fl2);
+      LDC_QK(fh2, fl2, 6)
+      LDC_RD_V(fh2, fl2, 2)
+      LDC_W6(fh3, fl3);
+      LDC_QK(fh3, fl3, 7)
+      LDC_RD_V(fh3, fl3, 3)
+
+      // ---- online softmax over the key axis (registers + the other lane half) ----
+      const int key_base = t * KT + 4 * half;
+      if (t == nt - 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + (r & 3) + 8 * (r >> 2);
+          if (key >= S) s[r] = -1.0e30f;
+        }
+      }
+      float m_t = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m_t = fmaxf(m_t, s[r]);
+      m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+      const float m_new = fmaxf(m_run, m_t);
+      const float alpha = exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = exp2f(s[r] - m_new);
+        rs += s[r];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
+
+      // ---- O^T += V^T . P^T  (24 MFMAs); P split on the fly ----
+      bf16x8 ph, pl;
+      {
+        uint4 h4, l4;
+        split8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], h4, l4);
+        ph = __builtin_bit_cast(bf16x8, h4);
+        pl = __builtin_bit_cast(bf16x8, l4);
+      }
+#define LDC_PV(FH, FL, DD)                                                                                  \
+  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), ph, o[DD], 0, 0, 0);      \
+  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), pl, o[DD], 0, 0, 0);      \
+  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ph, o[DD], 0, 0, 0);
+      LDC_W6(fh0, fl0);
+      LDC_PV(fh0, fl0, 0)
+      LDC_RD_V(fh0, fl0, 4)
+      LDC_W6(fh1, fl1);
+      LDC_PV(fh1, fl1, 1)
+      LDC_RD_V(fh1, fl1, 5)
+      LDC_W6(fh2, fl2);
+      LDC_PV(fh2, fl2, 2)
+      LDC_RD_V(fh2, fl2, 6)
+      LDC_W6(fh3, fl3);
+      LDC_PV(fh3, fl3, 3)
+      LDC_RD_V(fh3, fl3, 7)
+      {
+        uint4 h4, l4;
+        split8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], h4, l4);
+        ph = __builtin_bit_cast(bf16x8, h4);
+        pl = __builtin_bit_cast(bf16x8, l4);
+      }
+      LDC_W6(fh0, fl0);
+      LDC_PV(fh0, fl0, 0)
+      LDC_WN(4, fh1, fl1);
+      LDC_PV(fh1, fl1, 1)
+      LDC_WN(2, fh2, fl2);
+      LDC_PV(fh2, fl2, 2)
+      LDC_WN(0, fh3, fl3);
+      LDC_PV(fh3, fl3, 3)
+#undef LDC_RD_K
+#undef LDC_RD_V
+#undef LDC_W6
+#undef LDC_WN
+#undef LDC_QK
+#undef LDC_PV
+    }  // active
+  }
+  __syncthreads();  // everyone is done reading the rings
+
+  // ---- merge the two key halves: group 1 hands (m, l, O) to group 0 through LDS ----
+  if constexpr (NGRP == 2) {
+    float* xch = reinterpret_cast<float*>(smem) + (wave * 66) * 64 + lane;  // [wave][66][64 lanes]
+    if (grp == 1) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = o[d][r];
+      xch[64 * 64] = m_run;
+      xch[65 * 64] = l_run;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    {
+      const float m1 = xch[64 * 64], l1 = xch[65 * 64];
+      const float m = fmaxf(m_run, m1);
+      const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
+      l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(d * 16 + r) * 64] * a1;
+    }
+  }
+
+  const int qrow = q0 + l31;
+  if (qrow < S) {
+    const float inv = 1.0f / l_run;
+    float* op = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD + 4 * half;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" long long ldc_attn_packed_bytes(int B, int S, int H) {
+  if (B <= 0 || S <= 0 || H <= 0) return 0;
+  return 3LL * B * H * ldc_cdiv(S, KT) * TILE_B;
+}
+
+extern "C" int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, int S, int H, int ld_qkv,
+                                    long long qkv_bs, int split_row, const float* wq0, const float* wk0, const float* cos0,
+                                    const float* sin0, const float* wq1, const float* wk1, const float* cos1,
+                                    const float* sin1, float eps, void* packed, void* stream) {
+  LDC_CHECK_PTR(Q);
+  LDC_CHECK_PTR(K);
+  LDC_CHECK_PTR(V);
+  LDC_CHECK_PTR(packed);
+  if (B <= 0 || S <= 0 || H <= 0 || split_row < 0) return LDC_ERR_ARG;
+  if ((wq0 == nullptr) != (wk0 == nullptr) || (wq1 == nullptr) != (wk1 == nullptr)) return LDC_ERR_ARG;
+  if ((cos0 == nullptr) != (sin0 == nullptr) || (cos1 == nullptr) != (sin1 == nullptr)) return LDC_ERR_ARG;
+  LDC_CHECK_ALIGN16(Q);
+  LDC_CHECK_ALIGN16(K);
+  LDC_CHECK_ALIGN16(V);
+  LDC_CHECK_ALIGN16(packed);
+  if ((ld_qkv & 3) || (qkv_bs & 3)) return LDC_ERR_ALIGN;
+  if (H > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  PackArgs p{};
+  p.Q = Q; p.K = K; p.V = V;
+  p.S = S; p.H = H; p.ld = ld_qkv; p.bs = qkv_bs;
+  p.split_row = split_row > S ? S : split_row;
+  p.wq[0] = wq0; p.wk[0] = wk0; p.cs[0] = cos0; p.sn[0] = sin0;
+  p.wq[1] = wq1; p.wk[1] = wk1; p.cs[1] = cos1; p.sn[1] = sin1;
+  p.eps = eps;
+  p.qscale = 0.08838834764831845f * 1.4426950408889634f;
+  p.nt = ldc_cdiv(S, KT);
+  const long long plane = static_cast<long long>(B) * H * p.nt * TILE_B;
+  p.Qp = static_cast<unsigned char*>(packed);
+  p.Kp = p.Qp + plane;
+  p.Vp = p.Kp + plane;
+  hipLaunchKernelGGL(attn_pack_kernel, dim3(p.nt, H, B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
+                                          void* stream) {
+  LDC_CHECK_PTR(packed);
+  LDC_CHECK_PTR(O);
+  if (B <= 0 || S <= 0 || H <= 0) return LDC_ERR_ARG;
+  LDC_CHECK_ALIGN16(packed);
+  LDC_CHECK_ALIGN16(O);
+  if ((ldo & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
+  if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  AttnArgs p{};
+  p.nt = ldc_cdiv(S, KT);
+  const long long plane = static_cast<long long>(B) * H * p.nt * TILE_B;
+  p.Qp = static_cast<const unsigned char*>(packed);
+  p.Kp = p.Qp + plane;
+  p.Vp = p.Kp + plane;
+  p.O = O;
+  p.S = S; p.H = H; p.ldo = ldo; p.o_bs = o_bs;
+  p.nq = ldc_cdiv(S, QB);
+  dim3 grid(static_cast<unsigned>(p.nq) * H * B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_B);
+    attr_set = true;
+  }
+  const long long nwg = static_cast<long long>(p.nq) * H * B;
+  if (nwg <= 256) {
+    hipLaunchKernelGGL(attn_fwd_packed_kernel<2>, grid, dim3(512), 4 * STAGE_B, static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_packed_kernel<1>, grid, dim3(256), 2 * STAGE_B, static_cast<hipStream_t>(stream), p);
+  }
+  return ldc_launch_status();
+}

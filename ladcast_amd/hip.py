@@ -60,6 +60,9 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
+        "ldc_attn_packed_bytes": (L, [I, I, I]),
+        "ldc_attn_pack_bf16x3": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P, P]),
+        "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, P]),
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
@@ -188,6 +191,25 @@ def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False
     _dev(Q, K, V, O)
     fn = lib.ldc_attn_fwd_bf16x3 if split_bf16 else lib.ldc_attn_fwd
     _check(fn(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd" + ("_bf16x3" if split_bf16 else ""))
+
+
+def attn_packed_bytes(B, S, H):
+    return int(lib.ldc_attn_packed_bytes(B, S, H))
+
+
+def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None, None, None, None), seg1=(None, None, None, None),
+              eps=1e-6):
+    """seg = (wq, wk, cos, sin) for token rows [0, split_row) / [split_row, S); None entries = no norm / no RoPE"""
+    _dev(Q, K, V, packed, *seg0, *seg1)
+    if packed.numel() * packed.element_size() < attn_packed_bytes(B, S, H):
+        raise ValueError("packed buffer smaller than ldc_attn_packed_bytes")
+    _check(lib.ldc_attn_pack_bf16x3(_p(Q), _p(K), _p(V), B, S, H, ld_qkv, qkv_bs, split_row, *[_p(t) for t in seg0],
+                                    *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
+
+
+def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs):
+    _dev(packed, O)
+    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, _stream()), "ldc_attn_fwd_packed_bf16x3")
 
 
 def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, sin=None):

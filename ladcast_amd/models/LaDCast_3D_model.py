@@ -165,6 +165,7 @@ class _Workspace:
     def __init__(self, dev, B, Bt, Nx, Nc, D, C_in, C_out, n_mod):
         f = dict(device=dev, dtype=torch.float32)
         self.mods = torch.empty(B, n_mod, **f)  # every temb-driven AdaLN modulation vector of one forward
+        self.apack = None  # split-bf16 attention operands (ldc_attn_packed_bytes), allocated on first use
         S = Nx + Nc
         self.h = torch.empty(B, S, D, **f)
         self.nh = torch.empty(B, S, D, **f)
@@ -419,24 +420,36 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=pooled_dim, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
         hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
 
-    def _attention(self, ws, B, S, row0, q_ld_buf, out, ldo, o_bs):
-        """attention over token rows [row0, row0+S) of the fused qkv buffer -> out"""
+    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c):
+        """q/k RMSNorm + RoPE per segment, then attention over token rows [row0, row0 + Sx + Sc) of the fused qkv
+        buffer -> out.  seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the next Sc rows seg_c.
+        fp32 mode: ldc_qk_rmsnorm_rope in place + ldc_attn_fwd; split-bf16 mode: ldc_attn_pack_bf16x3 (norm, RoPE
+        and the hi/lo split in one pass, qkv left untouched) + ldc_attn_fwd_packed_bf16x3."""
         D, H = self.inner_dim, self.config.num_attention_heads
-        qkv = q_ld_buf
+        qkv = ws.qkv
         full = qkv.shape[1]
+        S = Sx + Sc
         q = qkv[:, row0:, 0:D]
         k = qkv[:, row0:, D : 2 * D]
         v = qkv[:, row0:, 2 * D : 3 * D]
-        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs,
-                     split_bf16=self.gemm_precision == "bf16x3")
-
-    def _qk_norm_rope(self, ws, B, row0, rows, norm_q, norm_k, cos, sin):
-        D, H = self.inner_dim, self.config.num_attention_heads
-        full = ws.qkv.shape[1]
-        hip.qk_rmsnorm_rope(
-            ws.qkv[:, :, 0:D], ws.qkv[:, :, D : 2 * D], B=B, row0=row0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
-            wq=norm_q.weight, wk=norm_k.weight, eps=norm_q.eps, cos=cos, sin=sin,
-        )
+        segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
+        if self.gemm_precision == "bf16x3":
+            if ws.apack is None:
+                ws.apack = torch.empty(hip.attn_packed_bytes(B, full, H) // 4, device=qkv.device, dtype=torch.float32)
+            if any(sg_[1][0].eps != segs[0][1][0].eps or sg_[1][1].eps != segs[0][1][0].eps for sg_ in segs):
+                raise NotImplementedError("ldc_attn_pack_bf16x3 takes one RMSNorm eps for q and k of both segments")
+            sg = [(n.weight, m.weight, c, s_) for (_, (n, m, c, s_)) in segs]
+            sg.append((None, None, None, None))
+            hip.attn_pack(q, k, v, ws.apack, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, split_row=segs[0][0],
+                          seg0=sg[0], seg1=sg[1], eps=segs[0][1][0].eps)
+            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs)
+            return
+        r0 = row0
+        for rows, (nq, nk, c, s_) in segs:
+            hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
+                                wq=nq.weight, wk=nk.weight, eps=nq.eps, cos=c, sin=s_)
+            r0 += rows
+        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, split_bf16=False)
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -566,8 +579,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps)
             run1(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
-            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
-            self._attention(ws, B, Nc, Nx, ws.qkv, ws.att[:, Nx:], D, SD)
+            self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             hip.gate_residual(h_c, ws.att[:, Nx:], ws.mod_a, h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D)
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps)
@@ -599,9 +611,8 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c),
             ])
-            self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
-            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)
-            self._attention(ws, B, S, 0, ws.qkv, ws.att, D, SD)
+            self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
+                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None))
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
             run([
                 G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD),
@@ -631,9 +642,8 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
             ])
-            self._qk_norm_rope(ws, B, 0, Nx, blk.attn.norm_q, blk.attn.norm_k, pc, ps)
-            self._qk_norm_rope(ws, B, Nx, Nc, blk.attn.norm_q, blk.attn.norm_k, cc, cs)
-            self._attention(ws, B, S, 0, ws.qkv, ws.cat, W5, S * W5)
+            self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
+                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs))
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD)
 

@@ -222,6 +222,80 @@ def test_attention_bf16x3(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()
 
 
+def _packed(hip, B, S, H):
+    return torch.empty(hip.attn_packed_bytes(B, S, H) // 4, device="cuda", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 2250, 16), (1, 97, 2)])
+def test_attention_packed_bf16x3(hip, B, S, H):
+    """pack (no norm / RoPE) + LDS-DMA attention == sdpa on the raw operands; Q, K, V are left untouched"""
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 4.0
+    d_qkv = dev(qkv)
+    pk = _packed(hip, B, S, H)
+    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_pack(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, split_row=S)
+    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64))
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(out[:, :, :D]).all()
+    assert rel(out[:, :, :D], want) < 2e-5
+    assert torch.isnan(out[:, :, D:]).all()
+    assert torch.equal(d_qkv.cpu(), qkv)
+
+
+@pytest.mark.parametrize("Nx,Nc,rope1", [(37, 11, False), (1800, 450, True), (64, 0, False), (40, 57, True)])
+def test_attention_packed_norm_rope_two_segments(hip, Nx, Nc, rope1):
+    """the pack kernel's q/k RMSNorm + RoPE per row segment, against the oracle layers + sdpa (same maths as
+    ldc_qk_rmsnorm_rope + ldc_attn_fwd; reference models/LaDCast_3D_model.py:103-203)"""
+    B, H = 2 if Nx < 100 else 1, 3
+    D, S = H * 128, Nx + Nc
+    qkv = rnd(B, S + 5, 3 * D, seed=1)  # 5 extra token rows in the buffer: batch stride != S * ld
+    wq0, wk0, wq1, wk1 = [1 + 0.1 * rnd(128, seed=s_) for s_ in (2, 3, 4, 5)]
+    cos0, sin0 = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
+    cos1, sin1 = L.get_1d_rotary_pos_embed(128, torch.arange(max(Nc, 1)).float() * 0.11 - 3.0, 256.0)
+    d = dev(qkv)
+    pk = _packed(hip, B, S, H)
+    out = torch.empty(B, S, D, device="cuda")
+    seg1 = (dev(wq1), dev(wk1), dev(cos1) if rope1 else None, dev(sin1) if rope1 else None)
+    hip.attn_pack(d[:, :, :D], d[:, :, D : 2 * D], d[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=(S + 5) * 3 * D, split_row=Nx,
+                  seg0=(dev(wq0), dev(wk0), dev(cos0), dev(sin0)), seg1=seg1, eps=1e-7)
+    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D, o_bs=S * D)
+    norms = []
+    for w in (wq0, wk0, wq1, wk1):
+        n = L.RMSNorm(128, 1e-7)
+        n.weight.data = w
+        norms.append(n)
+    with torch.no_grad():
+        x = qkv[:, :S].double()
+        qk = []
+        for j in range(2):
+            t = x[:, :, j * D : (j + 1) * D].reshape(B, S, H, 128).transpose(1, 2).float()
+            a = L.apply_rotary_emb(norms[j](t[:, :, :Nx]), (cos0, sin0))
+            b = norms[2 + j](t[:, :, Nx:])
+            if rope1 and Nc:
+                b = L.apply_rotary_emb(b, (cos1, sin1))
+            qk.append(torch.cat([a, b], dim=2).double())
+        v = x[:, :, 2 * D :].reshape(B, S, H, 128).transpose(1, 2)
+        want = F.scaled_dot_product_attention(qk[0], qk[1], v).transpose(1, 2).reshape(B, S, D)
+    assert rel(out, want) < 2e-5
+
+
+def test_attention_packed_rescale_branch(hip):
+    S = 200
+    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
+    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0
+    d_qkv = dev(qkv)
+    pk = _packed(hip, 1, S, 1)
+    out = torch.empty(1, S, 128, device="cuda")
+    hip.attn_pack(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], pk, B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, split_row=S)
+    hip.attn_fwd_packed(pk, out, B=1, S=S, H=1, ldo=128, o_bs=S * 128)
+    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
+    assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
+
+
 def test_attention_bf16x3_rescale_branch(hip):
     S = 200
     qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
