@@ -11,11 +11,12 @@
 // Packed operand buffer (ldc_attn_packed_bytes), nt = ceil(S / 32) key tiles, Sp = 32 nt:
 //   Qp [B][H][Sp]  512 B per query: [hi: 16 chunks x 16 B | lo: 16 chunks], chunk = 8 consecutive head-dim values,
 //                  pre-scaled by log2(e) / sqrt(128);
-//   Kp [B][H][nt]  16 KiB per tile = the LDS image: 32 rows (keys) x 512 B, chunk c (0..15 hi, 16..31 lo) of row r at
-//                  slot (c & 16) | ((c & 15) ^ (r & 15))   (conflict-free ds_read_b128 of one chunk column over 32 rows);
-//   Vp [B][H][nt]  16 KiB per tile = the LDS image of V^T: 128 rows (head-dim d) x 128 B = [hi 4 chunks | lo 4 chunks],
+//   Kp [B][H][nt]  17 KiB per tile = the LDS image: 32 rows (keys) x 528 B = [hi 256 B | lo 256 B | 16 B pad] (pitch
+//                  132 dwords: conflict-free ds_read_b128 of one chunk column over 32 rows, and every fragment address
+//                  is lane base + immediate), padded to 17 DMA pieces of 1 KiB;
+//   Vp [B][H][nt]  18 KiB per tile = the LDS image of V^T: 128 rows (head-dim d) x 144 B = [hi 64 B | lo 64 B | 16 B pad],
 //                  chunk 2t+h holds keys 16t + 8(j>>2) + 4h + (j&3), j = 0..7 (the order in which a 32x32 accumulator's
-//                  registers hold keys, so P needs no shuffle), chunk c of row d at slot c ^ ((d >> 1) & 7).
+//                  registers hold keys, so P needs no shuffle) = 18 DMA pieces.
 //   Rows / keys past S are zero.
 // Attention workgroup = 8 waves = 128 queries of one (batch, head); waves 0-3 sweep the first half of the key
 // tiles, waves 4-7 the second half (two independent 2-stage rings of 32 KiB stages), merged through LDS at the end
@@ -30,8 +31,11 @@ namespace {
 constexpr int HD = 128;
 constexpr int QB = 128;
 constexpr int KT = 32;
-constexpr int TILE_B = 16384;            // one K tile image = one V^T tile image
-constexpr int STAGE_B = 2 * TILE_B;      // K | V^T
+constexpr int QTILE_B = 16384;           // 32 queries x 512 B
+constexpr int KPITCH = 528, KIMG_B = KT * KPITCH;      // 16896 B of image ...
+constexpr int KTILE_B = 17 * 1024;                     // ... in 17 DMA pieces
+constexpr int VPITCH = 144, VTILE_B = HD * VPITCH;     // 18432 B = 18 DMA pieces
+constexpr int GROUP_LDS = 2 * KTILE_B + 2 * VTILE_B;   // per key-range group: 2-stage K ring + 2-stage V^T ring = 70 KiB
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -118,8 +122,8 @@ __device__ __forceinline__ void norm_rope16(float (&x)[16], const float* __restr
 __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
   // the two tile images are assembled in LDS and leave as linear 1 KiB-per-wave-instruction copies
   __shared__ __attribute__((aligned(16))) float vs[KT][HD + 4];
-  __shared__ __attribute__((aligned(16))) unsigned char kimg[TILE_B];
-  __shared__ __attribute__((aligned(16))) unsigned char vimg[TILE_B];
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[KIMG_B];
+  __shared__ __attribute__((aligned(16))) unsigned char vimg[VTILE_B];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int r = tid >> 3, sg = tid & 7;
@@ -171,23 +175,23 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
   norm_rope16(xk, p.wk[seg], p.cs[seg], p.sn[seg], trow, 16 * sg, p.eps);
   {
     const float m = ok ? 1.f : 0.f;
-    unsigned char* dst = kimg + r * 512;
+    unsigned char* dst = kimg + r * KPITCH;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       uint4 h, l;
       split8(xk[8 * e] * m, xk[8 * e + 1] * m, xk[8 * e + 2] * m, xk[8 * e + 3] * m, xk[8 * e + 4] * m, xk[8 * e + 5] * m,
              xk[8 * e + 6] * m, xk[8 * e + 7] * m, h, l);
-      const int slot = (2 * sg + e) ^ (r & 15);
-      *reinterpret_cast<uint4*>(dst + slot * 16) = h;
-      *reinterpret_cast<uint4*>(dst + 256 + slot * 16) = l;
+      *reinterpret_cast<uint4*>(dst + (2 * sg + e) * 16) = h;
+      *reinterpret_cast<uint4*>(dst + 256 + (2 * sg + e) * 16) = l;
     }
+    if (sg == 0) *reinterpret_cast<uint4*>(dst + 512) = make_uint4(0u, 0u, 0u, 0u);  // pad
   }
   __syncthreads();
   // ---- v^T -> LDS image ----
   {
     const int d = tid & 127, g = tid >> 7;
-    unsigned char* dst = vimg + d * 128;
-    const int sw = (d >> 1) & 7;
+    unsigned char* dst = vimg + d * VPITCH;
+    if (g == 0) *reinterpret_cast<uint4*>(dst + 128) = make_uint4(0u, 0u, 0u, 0u);  // pad
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int vg = g + 2 * i, tt = vg >> 1, hh = vg & 1;
@@ -196,18 +200,16 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackArgs p) {
       for (int j = 0; j < 8; ++j) v[j] = vs[16 * tt + 8 * (j >> 2) + 4 * hh + (j & 3)][d];
       uint4 h, l;
       split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], h, l);
-      *reinterpret_cast<uint4*>(dst + ((vg) ^ sw) * 16) = h;
-      *reinterpret_cast<uint4*>(dst + ((4 + vg) ^ sw) * 16) = l;
+      *reinterpret_cast<uint4*>(dst + vg * 16) = h;
+      *reinterpret_cast<uint4*>(dst + 64 + vg * 16) = l;
     }
   }
   __syncthreads();
   {
-    uint4* kd = reinterpret_cast<uint4*>(p.Kp + (bh * p.nt + t) * TILE_B);
-    uint4* vd = reinterpret_cast<uint4*>(p.Vp + (bh * p.nt + t) * TILE_B);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kd[tid + 256 * i] = reinterpret_cast<const uint4*>(kimg)[tid + 256 * i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vd[tid + 256 * i] = reinterpret_cast<const uint4*>(vimg)[tid + 256 * i];
+    uint4* kd = reinterpret_cast<uint4*>(p.Kp + (bh * p.nt + t) * KTILE_B);
+    uint4* vd = reinterpret_cast<uint4*>(p.Vp + (bh * p.nt + t) * VTILE_B);
+    for (int i = tid; i < KIMG_B / 16; i += 256) kd[i] = reinterpret_cast<const uint4*>(kimg)[i];  // the piece padding past
+    for (int i = tid; i < VTILE_B / 16; i += 256) vd[i] = reinterpret_cast<const uint4*>(vimg)[i];  // the image is never read
   }
 }
 
@@ -234,10 +236,50 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_w
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// combine with the other 32-lane half (v_permlane32_swap: no LDS crossbar op, so no lgkmcnt(0) drain of the
+// fragment reads in flight)
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_add(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+#define LDC_SB __builtin_amdgcn_sched_barrier(0)
+// fragment addresses are lane base + immediate: K step st at 32 st (+256 for lo); V pair J = 4 tt + dd at
+// 32 dd rows x 144 B + 32 tt (+64 for lo)
+#define LDC_DS_READ_I(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LDC_RD_K(FH, FL, ST)                                                     \
+  {                                                                              \
+    LDC_DS_READ_I(FH, ka, 32 * (ST));                                            \
+    LDC_DS_READ_I(FL, ka, 32 * (ST) + 256);                                      \
+  }
+#define LDC_RD_V(FH, FL, J)                                                      \
+  {                                                                              \
+    LDC_DS_READ_I(FH, va, ((J) & 3) * (32 * VPITCH) + 32 * ((J) >> 2));          \
+    LDC_DS_READ_I(FL, va, ((J) & 3) * (32 * VPITCH) + 32 * ((J) >> 2) + 64);     \
+  }
+#define LDC_W6(FH, FL) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(FH), "+v"(FL))
+#define LDC_WN(N, FH, FL) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FH), "+v"(FL))
+// one pair of probabilities -> hi / lo bf16 pair I of the P fragment (6 VALU, anchored where it is written)
+#define LDC_SPLIT_PAIR(PH, PL, I, A, B)                                          \
+  {                                                                              \
+    unsigned u_ = pack_pair(A, B);                                               \
+    asm volatile("" : "+v"(u_));                                                 \
+    PH[I] = static_cast<int>(u_);                                                \
+    const float t0_ = __uint_as_float(u_ << 16), t1_ = __uint_as_float(u_ & 0xffff0000u); \
+    unsigned l_ = pack_pair((A) - t0_, (B) - t1_);                               \
+    asm volatile("" : "+v"(l_));                                                 \
+    PL[I] = static_cast<int>(l_);                                                \
+  }
+
 template <int NGRP>
 __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int grp = NGRP == 2 ? (threadIdx.x >> 8) : 0;  // key-range group 0 / 1
+  const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;  // key-range group 0 / 1 (wave-uniform)
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,7 +301,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
   const long long bh = static_cast<long long>(b) * p.H + head;
   const int nt = p.nt;
 
-  // Q fragments: step s, element j <-> d = 16 s + 8 half + j = chunk 2 s + half
+  // Q fragments: step s, element j <-> d = 16 s + 8 half + j = chunk 2 s + half  
   bf16x8 qh[8], ql[8];
   {
     int qrow = q0 + l31;
@@ -272,25 +314,26 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
     }
   }
 
-  unsigned char* const ring = smem + grp * (2 * STAGE_B);
+  // per group: K ring (2 x 16 KiB) then V^T ring (2 x 16 KiB); tile t_begin + j lives in stage j & 1 of each
+  unsigned char* const ring = smem + grp * GROUP_LDS;
   const unsigned ring_lds = lds_addr(ring);
-  const unsigned char* const Kt0 = p.Kp + bh * nt * TILE_B;
-  const unsigned char* const Vt0 = p.Vp + bh * nt * TILE_B;
-  // one tile = 16 K pieces + 16 V pieces of 1 KiB; wave w of the group issues pieces w, w+4, w+8, w+12 of each
-  auto issue_tile = [&](int t, int stage) {
-    const unsigned char* ks = Kt0 + static_cast<long long>(t) * TILE_B + lane * 16;
-    const unsigned char* vsrc = Vt0 + static_cast<long long>(t) * TILE_B + lane * 16;
-    unsigned char* dst = ring + stage * STAGE_B;
+  const unsigned char* const Kt0 = p.Kp + bh * nt * KTILE_B;  // wave-uniform bases; the lane adds 16 * lane
+  const unsigned char* const Vt0 = p.Vp + bh * nt * VTILE_B;
+  const unsigned lane_off = lane * 16;
+  // K tile = 17 pieces of 1 KiB, V^T tile = 18; wave w of the group issues pieces w, w+4, ... (wave-uniform counts)
+  auto issue_k = [&](int t, int stage) {
+    const unsigned char* src = Kt0 + static_cast<long long>(t) * KTILE_B + wave * 1024;
+    unsigned char* dst = ring + stage * KTILE_B + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = wave + 4 * j;
-      dma16(ks + i * 1024, dst + i * 1024);
-    }
+    for (int j = 0; j < 4; ++j) dma16(src + j * 4096 + lane_off, dst + j * 4096);
+    if (wave == 0) dma16(src + 4 * 4096 + lane_off, dst + 4 * 4096);
+  };
+  auto issue_v = [&](int t, int stage) {
+    const unsigned char* src = Vt0 + static_cast<long long>(t) * VTILE_B + wave * 1024;
+    unsigned char* dst = ring + 2 * KTILE_B + stage * VTILE_B + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = wave + 4 * j;
-      dma16(vsrc + i * 1024, dst + TILE_B + i * 1024);
-    }
+    for (int j = 0; j < 4; ++j) dma16(src + j * 4096 + lane_off, dst + j * 4096);
+    if (wave < 2) dma16(src + 4 * 4096 + lane_off, dst + 4 * 4096);
   };
 
   f32x16 o[4];
@@ -298,161 +341,279 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
   float m_run = -1.0e30f;
   float l_run = 0.f;
 
   const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
   const int t_begin = grp ? nhalf : 0;
   const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
-  if (t_begin < t_end) issue_tile(t_begin, 0);
 
-  // per-lane fragment addressing inside a stage
-  const unsigned kx = l31 & 15, vx = (l31 >> 1) & 7;
-  const unsigned k_row = l31 * 512;   // + ((2 st + half) ^ kx) * 16 (+ 256 for lo)
-  const unsigned v_row = TILE_B + l31 * 128;  // + 32 dd * 128 + ((2 tt + half) ^ vx) * 16 (lo: ^ 64)
+  // per-lane fragment base inside a stage
+  const unsigned k_row = l31 * KPITCH + 16 * half;
+  const unsigned v_row = 2 * KTILE_B + l31 * VPITCH + 16 * half;
+  i32x4v fh0, fl0, fh1, fl1, fh2, fl2, fh3, fl3;    // four fragment pairs in flight
 
-  for (int it = 0; it < nhalf; ++it) {
+  // ---- prologue: S of the group's first tile ----
+  f32x16 sA, sB;
+  if (t_begin < t_end) issue_k(t_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t_begin < t_end) {
+    if (t_begin + 1 < t_end) issue_k(t_begin + 1, 1);
+    issue_v(t_begin, 0);
+    const unsigned ka = ring_lds + k_row;
+    f32x16 sx;
+    LDC_RD_K(fh0, fl0, 0)
+    LDC_RD_K(fh1, fl1, 1)
+    LDC_RD_K(fh2, fl2, 2)
+    LDC_RD_K(fh3, fl3, 3)
+#define LDC_QK(FH, FL, ST, C)                                                                               \
+  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), qh[ST], C, 0, 0, 0);         \
+  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ql[ST], sx, 0, 0, 0);        \
+  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], sx, 0, 0, 0);
+    LDC_W6(fh0, fl0);
+    LDC_QK(fh0, fl0, 0, zero16)
+    LDC_RD_K(fh0, fl0, 4)
+    LDC_W6(fh1, fl1);
+    LDC_QK(fh1, fl1, 1, sx)
+    LDC_RD_K(fh1, fl1, 5)
+    LDC_W6(fh2, fl2);
+    LDC_QK(fh2, fl2, 2, sx)
+    LDC_RD_K(fh2, fl2, 6)
+    LDC_W6(fh3, fl3);
+    LDC_QK(fh3, fl3, 3, sx)
+    LDC_RD_K(fh3, fl3, 7)
+    LDC_W6(fh0, fl0);
+    LDC_QK(fh0, fl0, 4, sx)
+    LDC_WN(4, fh1, fl1);
+    LDC_QK(fh1, fl1, 5, sx)
+    LDC_WN(2, fh2, fl2);
+    LDC_QK(fh2, fl2, 6, sx)
+    LDC_WN(0, fh3, fl3);
+    LDC_QK(fh3, fl3, 7, sx)
+#undef LDC_QK
+    sA = sx;
+  }
+
+  // ---- one iteration: tile t = t_begin + it.  S_cur = S of tile t (from the previous iteration), S_next = S of t+1 ----
+  auto iteration = [&](int it, f32x16& scv, f32x16& sxv) __attribute__((always_inline)) {
     const int t = t_begin + it;
-    const bool active = t < t_end;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (active) {
-      if (t + 1 < t_end) issue_tile(t + 1, (it + 1) & 1);
-      const unsigned sbase = ring_lds + (it & 1) * STAGE_B;
-      const unsigned ka = sbase + k_row;
-      const unsigned va = sbase + v_row;
-
-      // four fragment pairs in flight: K steps 0..7, then V pairs (tt, dd) 0..7 reuse the same registers
-      i32x4v fh0, fl0, fh1, fl1, fh2, fl2, fh3, fl3;
-#define LDC_RD_K(FH, FL, ST)                                                     \
-  {                                                                              \
-    const unsigned a_ = ka + (((2 * (ST) + half) ^ kx) << 4);                    \
-    LDC_DS_READ(FH, a_, 0);                                                      \
-    LDC_DS_READ(FL, a_, 256);                                                    \
-  }
-#define LDC_RD_V(FH, FL, J) /* pair J = 4 tt + dd */                             \
-  {                                                                              \
-    const unsigned a_ = va + ((J) & 3) * 4096 + (((2 * ((J) >> 2) + half) ^ vx) << 4); \
-    const unsigned b_ = a_ ^ 64u;                                                \
-    LDC_DS_READ(FH, a_, 0);                                                      \
-    LDC_DS_READ(FL, b_, 0);                                                      \
-  }
-#define LDC_W6(FH, FL) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(FH), "+v"(FL))
-#define LDC_WN(N, FH, FL) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FH), "+v"(FL))
+    __syncthreads();  // K_{t+1} and V_t landed; everyone is done with K_t and V_{t-1}
+    if (t >= t_end) return;
+    // the DMA instructions of K_{t+2} (into K_t's stage) and V_{t+1} (into V_{t-1}'s stage) sit one per MFMA gap in
+    // the second half of phase A instead of as a burst behind the barrier
+    const bool kq = t + 2 < t_end, vq = t + 1 < t_end;
+    const unsigned char* const ksrc = Kt0 + static_cast<long long>(t + 2) * KTILE_B + wave * 1024 + lane_off;
+    const unsigned char* const vsrc = Vt0 + static_cast<long long>(t + 1) * VTILE_B + wave * 1024 + lane_off;
+    unsigned char* const kdst = ring + (it & 1) * KTILE_B + wave * 1024;
+    unsigned char* const vdst = ring + 2 * KTILE_B + ((it + 1) & 1) * VTILE_B + wave * 1024;
+    auto dma_k = [&](int j) __attribute__((always_inline)) { dma16(ksrc + j * 4096, kdst + j * 4096); };
+    auto dma_v = [&](int j) __attribute__((always_inline)) { dma16(vsrc + j * 4096, vdst + j * 4096); };
+    const unsigned ka = ring_lds + ((it + 1) & 1) * KTILE_B + k_row;  // K_{t+1} (stale data in the last iteration: S_next is then never used)
+    const unsigned va = ring_lds + (it & 1) * VTILE_B + v_row;        // V_t
+    float sc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = scv[r];
+    if (t == nt - 1) {  // keys past S
+      const int key_base = t * KT + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_base + (r & 3) + 8 * (r >> 2);
+        if (key >= S) sc[r] = -1.0e30f;
+      }
+    }
+    f32x16 sx;
+    float m_new, alpha;
+    float r0, r1, r2, r3, r4, r5, r6, r7;
+    i32x4v ph0, pl0, ph1, pl1;
+      // ---- phase A: S_next = K_{t+1} . Q^T (24 MFMAs) with the softmax of S_cur in the MFMA gaps ----
       LDC_RD_K(fh0, fl0, 0)
       LDC_RD_K(fh1, fl1, 1)
       LDC_RD_K(fh2, fl2, 2)
       LDC_RD_K(fh3, fl3, 3)
-
-      // ---- S^T = K . Q^T  (24 MFMAs) ----
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#define LDC_QK(FH, FL, ST)                                                                                  \
-  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), qh[ST], s, 0, 0, 0);          \
-  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ql[ST], s, 0, 0, 0);          \
-  s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], s, 0, 0, 0);
-      LDC_W6(fh0, fl0);
-      LDC_QK(fh0, fl0, 0)
+      LDC_SB;
+      {
+        float m0 = max3f(sc[0], sc[1], sc[2]), m1 = max3f(sc[3], sc[4], sc[5]), m2 = max3f(sc[6], sc[7], sc[8]), m3 = max3f(sc[9], sc[10], sc[11]);
+        const float m4 = max3f(sc[12], sc[13], sc[14]);
+        m0 = max3f(m0, m1, m2); m3 = max3f(m3, m4, sc[15]); m0 = fmaxf(m0, m3);
+        m0 = xor32_max(m0);
+        m_new = fmaxf(m_run, m0);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        asm volatile("" : "+v"(m_new), "+v"(alpha));
+      }
+      LDC_SB;
+      LDC_W6(fh0, fl0); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), qh[0], zero16, 0, 0, 0); LDC_SB;
+      sc[0] = __builtin_amdgcn_exp2f(sc[0] - m_new); sc[1] = __builtin_amdgcn_exp2f(sc[1] - m_new); asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), ql[0], sx, 0, 0, 0); LDC_SB;
+      sc[2] = __builtin_amdgcn_exp2f(sc[2] - m_new); sc[3] = __builtin_amdgcn_exp2f(sc[3] - m_new); asm volatile("" : "+v"(sc[2]), "+v"(sc[3]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), qh[0], sx, 0, 0, 0); LDC_SB;
       LDC_RD_K(fh0, fl0, 4)
-      LDC_W6(fh1, fl1);
-      LDC_QK(fh1, fl1, 1)
+      sc[4] = __builtin_amdgcn_exp2f(sc[4] - m_new); sc[5] = __builtin_amdgcn_exp2f(sc[5] - m_new); asm volatile("" : "+v"(sc[4]), "+v"(sc[5]));
+      LDC_SB;
+      LDC_W6(fh1, fl1); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), qh[1], sx, 0, 0, 0); LDC_SB;
+      sc[6] = __builtin_amdgcn_exp2f(sc[6] - m_new); sc[7] = __builtin_amdgcn_exp2f(sc[7] - m_new); asm volatile("" : "+v"(sc[6]), "+v"(sc[7]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), ql[1], sx, 0, 0, 0); LDC_SB;
+      sc[8] = __builtin_amdgcn_exp2f(sc[8] - m_new); sc[9] = __builtin_amdgcn_exp2f(sc[9] - m_new); asm volatile("" : "+v"(sc[8]), "+v"(sc[9]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), qh[1], sx, 0, 0, 0); LDC_SB;
       LDC_RD_K(fh1, fl1, 5)
-      LDC_W6(fh2, fl2);
-      LDC_QK(fh2, fl2, 2)
+      sc[10] = __builtin_amdgcn_exp2f(sc[10] - m_new); sc[11] = __builtin_amdgcn_exp2f(sc[11] - m_new); asm volatile("" : "+v"(sc[10]), "+v"(sc[11]));
+      LDC_SB;
+      LDC_W6(fh2, fl2); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), qh[2], sx, 0, 0, 0); LDC_SB;
+      sc[12] = __builtin_amdgcn_exp2f(sc[12] - m_new); sc[13] = __builtin_amdgcn_exp2f(sc[13] - m_new); asm volatile("" : "+v"(sc[12]), "+v"(sc[13]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), ql[2], sx, 0, 0, 0); LDC_SB;
+      sc[14] = __builtin_amdgcn_exp2f(sc[14] - m_new); sc[15] = __builtin_amdgcn_exp2f(sc[15] - m_new); asm volatile("" : "+v"(sc[14]), "+v"(sc[15]));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), qh[2], sx, 0, 0, 0); LDC_SB;
       LDC_RD_K(fh2, fl2, 6)
-      LDC_W6(fh3, fl3);
-      LDC_QK(fh3, fl3, 3)
+      r0 = sc[0] + sc[1]; r1 = sc[2] + sc[3]; r2 = sc[4] + sc[5]; r3 = sc[6] + sc[7]; asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+      LDC_SB;
+      LDC_W6(fh3, fl3); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), qh[3], sx, 0, 0, 0); LDC_SB;
+      r4 = sc[8] + sc[9]; r5 = sc[10] + sc[11]; r6 = sc[12] + sc[13]; r7 = sc[14] + sc[15]; asm volatile("" : "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), ql[3], sx, 0, 0, 0); LDC_SB;
+      r0 += r1; r2 += r3; r4 += r5; r6 += r7; asm volatile("" : "+v"(r0), "+v"(r2), "+v"(r4), "+v"(r6));
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), qh[3], sx, 0, 0, 0); LDC_SB;
       LDC_RD_K(fh3, fl3, 7)
-      LDC_W6(fh0, fl0);
-      LDC_QK(fh0, fl0, 4)
+      r0 += r2; r4 += r6; r0 += r4; r0 = xor32_add(r0); l_run = l_run * alpha + r0; m_run = m_new; asm volatile("" : "+v"(l_run));
+      LDC_SB;
+      LDC_W6(fh0, fl0); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), qh[4], sx, 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph0, pl0, 0, sc[0], sc[1])
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), ql[4], sx, 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph0, pl0, 1, sc[2], sc[3])
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), qh[4], sx, 0, 0, 0); LDC_SB;
       LDC_RD_V(fh0, fl0, 0)
-      LDC_W6(fh1, fl1);
-      LDC_QK(fh1, fl1, 5)
+      LDC_SPLIT_PAIR(ph0, pl0, 2, sc[4], sc[5])
+      LDC_SB;
+      LDC_W6(fh1, fl1); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), qh[5], sx, 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph0, pl0, 3, sc[6], sc[7])
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), ql[5], sx, 0, 0, 0); LDC_SB;
+      if (kq) dma_k(0);
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), qh[5], sx, 0, 0, 0); LDC_SB;
       LDC_RD_V(fh1, fl1, 1)
-      LDC_W6(fh2, fl2);
-      LDC_QK(fh2, fl2, 6)
+      if (kq) dma_k(1);
+      LDC_SB;
+      LDC_W6(fh2, fl2); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), qh[6], sx, 0, 0, 0); LDC_SB;
+      if (kq) dma_k(2);
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), ql[6], sx, 0, 0, 0); LDC_SB;
+      if (kq) dma_k(3);
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), qh[6], sx, 0, 0, 0); LDC_SB;
       LDC_RD_V(fh2, fl2, 2)
-      LDC_W6(fh3, fl3);
-      LDC_QK(fh3, fl3, 7)
+      if (vq) dma_v(0);
+      LDC_SB;
+      LDC_W6(fh3, fl3); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), qh[7], sx, 0, 0, 0); LDC_SB;
+      if (vq) dma_v(1);
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), ql[7], sx, 0, 0, 0); LDC_SB;
+      if (vq) dma_v(2);
+      LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), qh[7], sx, 0, 0, 0); LDC_SB;
       LDC_RD_V(fh3, fl3, 3)
-
-      // ---- online softmax over the key axis (registers + the other lane half) ----
-      const int key_base = t * KT + 4 * half;
-      if (t == nt - 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key_base + (r & 3) + 8 * (r >> 2);
-          if (key >= S) s[r] = -1.0e30f;
-        }
-      }
-      float m_t = s[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) m_t = fmaxf(m_t, s[r]);
-      m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
-      const float m_new = fmaxf(m_run, m_t);
-      const float alpha = exp2f(m_run - m_new);
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = exp2f(s[r] - m_new);
-        rs += s[r];
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
+      if (vq) { dma_v(3); if (wave < 2) dma_v(4); } if (kq && wave == 0) dma_k(4);
+      LDC_SB;
+      // ---- rare: the running max moved -> rescale O ----
       if (!__all(alpha == 1.0f)) {
-#pragma unroll
+      #pragma unroll
         for (int d = 0; d < 4; ++d)
-#pragma unroll
+      #pragma unroll
           for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
       }
-
-      // ---- O^T += V^T . P^T  (24 MFMAs); P split on the fly ----
-      bf16x8 ph, pl;
-      {
-        uint4 h4, l4;
-        split8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], h4, l4);
-        ph = __builtin_bit_cast(bf16x8, h4);
-        pl = __builtin_bit_cast(bf16x8, l4);
-      }
-#define LDC_PV(FH, FL, DD)                                                                                  \
-  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), ph, o[DD], 0, 0, 0);      \
-  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), pl, o[DD], 0, 0, 0);      \
-  o[DD] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ph, o[DD], 0, 0, 0);
-      LDC_W6(fh0, fl0);
-      LDC_PV(fh0, fl0, 0)
+      LDC_SB;
+      // ---- phase B: O^T += V_t^T . P^T (24 MFMAs); the second half of P is split in the gaps of the first ----
+      LDC_W6(fh0, fl0); LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph0), o[0], 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph1, pl1, 0, sc[8], sc[9])
+      LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl0), o[0], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, ph0), o[0], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh0, fl0, 4)
-      LDC_W6(fh1, fl1);
-      LDC_PV(fh1, fl1, 1)
+      LDC_SPLIT_PAIR(ph1, pl1, 1, sc[10], sc[11])
+      LDC_SB;
+      LDC_W6(fh1, fl1); LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph0), o[1], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl0), o[1], 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph1, pl1, 2, sc[12], sc[13])
+      LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, ph0), o[1], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh1, fl1, 5)
-      LDC_W6(fh2, fl2);
-      LDC_PV(fh2, fl2, 2)
+      LDC_SB;
+      LDC_W6(fh2, fl2); LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph0), o[2], 0, 0, 0); LDC_SB;
+      LDC_SPLIT_PAIR(ph1, pl1, 3, sc[14], sc[15])
+      LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl0), o[2], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, ph0), o[2], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh2, fl2, 6)
-      LDC_W6(fh3, fl3);
-      LDC_PV(fh3, fl3, 3)
+      LDC_SB;
+      LDC_W6(fh3, fl3); LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph0), o[3], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl0), o[3], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, ph0), o[3], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh3, fl3, 7)
-      {
-        uint4 h4, l4;
-        split8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], h4, l4);
-        ph = __builtin_bit_cast(bf16x8, h4);
-        pl = __builtin_bit_cast(bf16x8, l4);
-      }
-      LDC_W6(fh0, fl0);
-      LDC_PV(fh0, fl0, 0)
-      LDC_WN(4, fh1, fl1);
-      LDC_PV(fh1, fl1, 1)
-      LDC_WN(2, fh2, fl2);
-      LDC_PV(fh2, fl2, 2)
-      LDC_WN(0, fh3, fl3);
-      LDC_PV(fh3, fl3, 3)
-#undef LDC_RD_K
-#undef LDC_RD_V
-#undef LDC_W6
-#undef LDC_WN
-#undef LDC_QK
-#undef LDC_PV
-    }  // active
+      LDC_SB;
+      LDC_W6(fh0, fl0); LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph1), o[0], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl1), o[0], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, ph1), o[0], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      LDC_WN(4, fh1, fl1); LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph1), o[1], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl1), o[1], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, ph1), o[1], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      LDC_WN(2, fh2, fl2); LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph1), o[2], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl1), o[2], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, ph1), o[2], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      LDC_WN(0, fh3, fl3); LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph1), o[3], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl1), o[3], 0, 0, 0); LDC_SB;
+      LDC_SB;
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, ph1), o[3], 0, 0, 0); LDC_SB;
+      LDC_SB;
+
+    sxv = sx;
+  };
+
+  for (int it = 0; it < nhalf; it += 2) {
+    iteration(it, sA, sB);
+    if (it + 1 < nhalf) iteration(it + 1, sB, sA);
   }
   __syncthreads();  // everyone is done reading the rings
 
@@ -499,7 +660,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
 
 extern "C" long long ldc_attn_packed_bytes(int B, int S, int H) {
   if (B <= 0 || S <= 0 || H <= 0) return 0;
-  return 3LL * B * H * ldc_cdiv(S, KT) * TILE_B;
+  return static_cast<long long>(B) * H * ldc_cdiv(S, KT) * (QTILE_B + KTILE_B + VTILE_B);
 }
 
 extern "C" int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, int S, int H, int ld_qkv,
@@ -528,10 +689,10 @@ extern "C" int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float*
   p.eps = eps;
   p.qscale = 0.08838834764831845f * 1.4426950408889634f;
   p.nt = ldc_cdiv(S, KT);
-  const long long plane = static_cast<long long>(B) * H * p.nt * TILE_B;
+  const long long tiles = static_cast<long long>(B) * H * p.nt;
   p.Qp = static_cast<unsigned char*>(packed);
-  p.Kp = p.Qp + plane;
-  p.Vp = p.Kp + plane;
+  p.Kp = p.Qp + tiles * QTILE_B;
+  p.Vp = p.Kp + tiles * KTILE_B;
   hipLaunchKernelGGL(attn_pack_kernel, dim3(p.nt, H, B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }
@@ -547,10 +708,10 @@ extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, i
   if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   AttnArgs p{};
   p.nt = ldc_cdiv(S, KT);
-  const long long plane = static_cast<long long>(B) * H * p.nt * TILE_B;
+  const long long tiles = static_cast<long long>(B) * H * p.nt;
   p.Qp = static_cast<const unsigned char*>(packed);
-  p.Kp = p.Qp + plane;
-  p.Vp = p.Kp + plane;
+  p.Kp = p.Qp + tiles * QTILE_B;
+  p.Vp = p.Kp + tiles * KTILE_B;
   p.O = O;
   p.S = S; p.H = H; p.ldo = ldo; p.o_bs = o_bs;
   p.nq = ldc_cdiv(S, QB);
@@ -558,16 +719,16 @@ extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, i
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_B);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
     attr_set = true;
   }
   const long long nwg = static_cast<long long>(p.nq) * H * B;
   if (nwg <= 256) {
-    hipLaunchKernelGGL(attn_fwd_packed_kernel<2>, grid, dim3(512), 4 * STAGE_B, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(attn_fwd_packed_kernel<2>, grid, dim3(512), 2 * GROUP_LDS, static_cast<hipStream_t>(stream), p);
   } else {
-    hipLaunchKernelGGL(attn_fwd_packed_kernel<1>, grid, dim3(256), 2 * STAGE_B, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(attn_fwd_packed_kernel<1>, grid, dim3(256), GROUP_LDS, static_cast<hipStream_t>(stream), p);
   }
   return ldc_launch_status();
 }
