@@ -57,7 +57,18 @@ typedef struct ldc_gemm_desc {
   long long a_bs, c_bs, r_bs; /* batch strides (elements) */
   int gate_bs;                /* batch stride of gate (elements) */
   int act;                    /* enum ldc_act */
+  int flags;                  /* LDC_GEMM_* bits below; 0 = plain fp32 A and C */
+  int reserved;               /* 0 */
 } ldc_gemm_desc;
+/* Split-bf16 activation format (only ldc_gemm_grouped_bf16x3 takes these; every other entry rejects them):
+ * columns 8c..8c+7 of a row occupy the SAME 32 bytes as 8 floats would, holding [hi x8 | lo x8] bf16
+ * (hi = bf16(x), lo = bf16(x - hi)), so every pointer / stride / column offset that is a multiple of 8
+ * elements addresses the same data in both formats.
+ *   LDC_GEMM_A_SPLIT  A is in that format (made by a producer kernel that split it once) instead of fp32:
+ *                     the GEMM then skips its own split of every A fragment; results are bit-identical.
+ *   LDC_GEMM_C_SPLIT  C is written in that format (after bias / activation / gate / residual). */
+#define LDC_GEMM_A_SPLIT 1
+#define LDC_GEMM_C_SPLIT 2
 int ldc_sizeof_gemm_desc(void);
 int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const float* gate,
                       const float* R, float* C, const ldc_gemm_desc* d, void* stream);
@@ -138,7 +149,8 @@ int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, 
                          const float* cos0, const float* sin0, const float* wq1, const float* wk1,
                          const float* cos1, const float* sin1, float eps, void* packed, void* stream);
 int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
-                               void* stream);
+                               int out_split, void* stream);
+/* out_split != 0: O is written in the split activation format of LDC_GEMM_A_SPLIT (ldo, o_bs multiples of 8). */
 
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),
@@ -157,7 +169,9 @@ int ldc_qk_rmsnorm_rope(float* q, float* k, int B, int row0, int rows, int H, in
  * models/LaDCast_3D_model.py:257,270,287,299,441,502,507,524-529,546-555,1044. */
 int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs,
                       int ldy, long long y_bs, const float* scale, const float* shift, int mod_bs,
-                      int mode, float eps, void* stream);
+                      int mode, float eps, int out_split, void* stream);
+/* out_split != 0: y is written in the split activation format of LDC_GEMM_A_SPLIT (the consumer GEMM then
+ * does not split it again); D, ldy, y_bs multiples of 8. */
 
 /* y[b][c] = mean over rows of x[b][r][c]   (hidden_states.mean(dim=1),
  * models/LaDCast_3D_model.py:382,955) */

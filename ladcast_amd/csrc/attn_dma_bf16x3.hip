@@ -224,6 +224,7 @@ struct AttnArgs {
   int S, H, ldo;
   long long o_bs;
   int nq, nt;
+  int out_split;  // O in the split activation format of LDC_GEMM_A_SPLIT
 };
 
 #define LDC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
@@ -651,7 +652,19 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+        if (p.out_split) {  // this lane has half (4 half .. 4 half + 3) of the 8-column group 32 d + 8 g
+          float r0, r1, r2, r3;
+          uint2 hi, lo;
+          hi.x = split_pair(v.x, v.y, r0, r1);
+          hi.y = split_pair(v.z, v.w, r2, r3);
+          lo.x = pack_pair(r0, r1);
+          lo.y = pack_pair(r2, r3);
+          unsigned char* grp = reinterpret_cast<unsigned char*>(op - 4 * half + 32 * d + 8 * g) + 8 * half;
+          *reinterpret_cast<uint2*>(grp) = hi;
+          *reinterpret_cast<uint2*>(grp + 16) = lo;
+        } else {
+          *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+        }
       }
   }
 }
@@ -698,15 +711,17 @@ extern "C" int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float*
 }
 
 extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
-                                          void* stream) {
+                                          int out_split, void* stream) {
   LDC_CHECK_PTR(packed);
   LDC_CHECK_PTR(O);
   if (B <= 0 || S <= 0 || H <= 0) return LDC_ERR_ARG;
   LDC_CHECK_ALIGN16(packed);
   LDC_CHECK_ALIGN16(O);
   if ((ldo & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
+  if (out_split && ((ldo & 7) || (o_bs & 7) || (reinterpret_cast<unsigned long long>(O) & 31ull))) return LDC_ERR_ALIGN;
   if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   AttnArgs p{};
+  p.out_split = out_split ? 1 : 0;
   p.nt = ldc_cdiv(S, KT);
   const long long tiles = static_cast<long long>(B) * H * p.nt;
   p.Qp = static_cast<const unsigned char*>(packed);

@@ -43,6 +43,21 @@ __device__ __forceinline__ float ldc_apply_act(float v, int act) {
   }
 }
 
+// split-bf16 helpers: x = hi + lo, hi = bf16(x) (RNE), lo = bf16(x - hi); a pair packs into one dword (first value low)
+__device__ __forceinline__ unsigned ldc_pack_pair(float a, float b) {
+  typedef __bf16 ldc_bf16x2 __attribute__((ext_vector_type(2)));
+  ldc_bf16x2 v;
+  v.x = static_cast<__bf16>(a);
+  v.y = static_cast<__bf16>(b);
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned ldc_split_pair(float a, float b, float& ra, float& rb) {
+  const unsigned u = ldc_pack_pair(a, b);
+  ra = a - __uint_as_float(u << 16);
+  rb = b - __uint_as_float(u & 0xffff0000u);
+  return u;
+}
+
 // wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -61,6 +61,8 @@ struct DevProblem {
   int tm, tn, kt;
   long long unit0;
   long long tile0;
+  int vec4;     // epilogue may use 16-byte accesses
+  int c_split;  // LDC_GEMM_C_SPLIT
 };
 
 struct SKArgs {
@@ -113,7 +115,11 @@ __device__ __forceinline__ void split8(const float4 p, const float4 q, bf16x8& h
   lo = __builtin_bit_cast(bf16x8, l);
 }
 
-// acc[j][r]: wave w owns rows [32w, 32w+32) of the tile and all 128 columns (4 MFMA column tiles)
+// acc[j]: wave w owns rows [32w, 32w+32) of the tile and all 128 columns (4 MFMA column tiles j).  The MFMAs are
+// issued as W-fragment x A-fragment, so a lane holds ONE output row (m = 32w + lane % 32) and its registers run along
+// the columns: register r of tile j is column 32 j + 8 (r >> 2) + 4 (lane / 32) + (r & 3).  Four consecutive registers
+// are 16 contiguous bytes of C: the epilogue is 16 dwordx4 stores per lane instead of 64 dword stores (the store
+// tail of a tile is issue-bound, MI355X_MICROARCH.md "attention epilogue store tail").
 template <int BM>
 __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x16 (&acc)[4], int wave,
                                               int lane) {
@@ -122,21 +128,61 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
   const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
   const int act = P.d.act;
+  const int m = bm * BM + wave * 32 + (lane & 31);
+  if (m >= M) return;
+  float* crow = C + static_cast<long long>(m) * P.d.ldc;
+  const float* rrow = R ? R + static_cast<long long>(m) * P.d.ldr : nullptr;
+  const int n_lane = bn * BN + 4 * (lane >> 5);
+  if (P.vec4) {  // N % 4 == 0 and every row / vector 16-byte aligned (checked on the host)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = bn * BN + j * 32 + (lane & 31);
-    if (n >= N) continue;
-    const float bias_n = P.bias ? P.bias[n] : 0.f;
-    const float gate_n = gate ? gate[n] : 1.f;
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = bm * BM + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= M) continue;
-      float v = acc[j][r] + bias_n;
-      v = ldc_apply_act(v, act);
-      if (gate) v *= gate_n;
-      if (R) v += R[static_cast<long long>(m) * P.d.ldr + n];
-      C[static_cast<long long>(m) * P.d.ldc + n] = v;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_lane + 32 * j + 8 * g;
+        if (n >= N) continue;
+        float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        if (P.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
+        if (gate) {
+          const float4 gv = *reinterpret_cast<const float4*>(gate + n);
+          v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
+        }
+        if (rrow) {
+          const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (P.c_split) {
+          // LDC_GEMM_C_SPLIT: columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group
+          float r0, r1, r2, r3;
+          uint2 hi, lo;
+          hi.x = split_pair(v.x, v.y, r0, r1);
+          hi.y = split_pair(v.z, v.w, r2, r3);
+          lo.x = pack_pair(r0, r1);
+          lo.y = pack_pair(r2, r3);
+          unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 2 * (n & 4);
+          *reinterpret_cast<uint2*>(grp) = hi;
+          *reinterpret_cast<uint2*>(grp + 16) = lo;
+        } else {
+          *reinterpret_cast<float4*>(crow + n) = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n_lane + 32 * j + 8 * (r >> 2) + (r & 3);
+        if (n >= N) continue;
+        float v = acc[j][r] + (P.bias ? P.bias[n] : 0.f);
+        v = ldc_apply_act(v, act);
+        if (gate) v *= gate[n];
+        if (rrow) v += rrow[n];
+        crow[n] = v;
+      }
     }
   }
 }
@@ -170,7 +216,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_w
 #define LDC_STAMP_CLK(i)
 #endif
 
-template <int BM>
+template <int BM, bool APK>
 __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
   constexpr int NW = BM / 32;                  // waves per workgroup, 8(M) x 1(N) or 4(M) x 1(N)
   constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
@@ -309,17 +355,17 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
     const unsigned c00 = ((2u * fh) ^ swz) << 4, c01 = c00 ^ 16u;            // s2 = 0
     const unsigned c10 = ((2u * (2 + fh)) ^ swz) << 4, c11 = c10 ^ 16u;      // s2 = 1
 
-    f32x4v p, q;
+    f32x4v p = {0.f, 0.f, 0.f, 0.f}, q = p;
     i32x4v h0, l0, h1, l1, h2, l2, h3, l3;
-    i32x4v ahA, alA, ahB, alB;
+    i32x4v ahA = {0, 0, 0, 0}, alA = ahA, ahB = ahA, alB = ahA;
 
 #define LDC_SB __builtin_amdgcn_sched_barrier(0)
 #define LDC_MFMA(ACC, X, Y)                                                                                 \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, X), __builtin_bit_cast(bf16x8, Y), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Y), __builtin_bit_cast(bf16x8, X), ACC, 0, 0, 0); \
   LDC_SB;
     // split piece 1 of a pair (x0, x1): hi pair -> AH[i]; the two hi values as fp32 stay in t0, t1
 #define LDC_SPLIT_A(AH, I, X0, X1)                                                                          \
-  {                                                                                                         \
+  if constexpr (!APK) {                                                                                     \
     unsigned u_ = pack_pair(X0, X1);                                                                        \
     asm volatile("" : "+v"(u_)); /* keep ONE cvt_pk: the compiler otherwise re-converts x0 alone */         \
     AH[I] = static_cast<int>(u_);                                                                           \
@@ -329,26 +375,33 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
   }
     // split piece 2: residuals -> lo pair -> AL[i]
 #define LDC_SPLIT_B(AL, I, X0, X1)                                                                          \
-  {                                                                                                         \
+  if constexpr (!APK) {                                                                                     \
     unsigned lo_ = pack_pair(X0 - t0, X1 - t1);                                                             \
     asm volatile("" : "+v"(lo_));                                                                           \
     AL[I] = static_cast<int>(lo_);                                                                          \
   }
-#define LDC_READ_PQ(SB, C0, C1)                                                                             \
+    // raw fp32 activations: two chunks of 4 floats into p, q (split below); pre-split activations
+    // (LDC_GEMM_A_SPLIT): the same two chunks ARE the hi and lo fragments
+#define LDC_READ_PQ(SB, C0, C1, AHN, ALN)                                                                   \
   {                                                                                                         \
     const unsigned a0_ = arow + (SB) + (C0), a1_ = arow + (SB) + (C1);                                      \
-    LDC_DS_READ(p, a0_, 0);                                                                                 \
-    LDC_DS_READ(q, a1_, 0);                                                                                 \
+    if constexpr (APK) {                                                                                    \
+      LDC_DS_READ(AHN, a0_, 0);                                                                             \
+      LDC_DS_READ(ALN, a1_, 0);                                                                             \
+    } else {                                                                                                \
+      LDC_DS_READ(p, a0_, 0);                                                                               \
+      LDC_DS_READ(q, a1_, 0);                                                                               \
+    }                                                                                                       \
   }
     // one half-step: 12 MFMAs with A fragments (AH, AL); loads for H+1 from stage offset SBN with chunk offsets
     // CN0/CN1; builds (AHN, ALN); DMA part (kt DK, stage DS, half DH) when DP
 #define LDC_HALF_STEP(AH, AL, AHN, ALN, SBN, CN0, CN1, W_H1, DP, DK, DS, DH)                                \
   {                                                                                                         \
-    float t0, t1;                                                                                           \
+    float t0 = 0.f, t1 = 0.f;                                                                               \
     const unsigned w0_ = wrow + (SBN) + (CN0), w1_ = wrow + (SBN) + (CN1);                                  \
     LDC_SB;                                                                                                 \
     LDC_MFMA(acc[0], AL, h0)                                                                                \
-    LDC_READ_PQ(SBN, CN0, CN1)                                                                              \
+    LDC_READ_PQ(SBN, CN0, CN1, AHN, ALN)                                                                    \
     LDC_SB;                                                                                                 \
     LDC_MFMA(acc[0], AH, l0)                                                                                \
     LDC_DS_READ(l0, w1_, 0);                                                                                \
@@ -359,7 +412,11 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
     W_H1                                                                                                    \
     LDC_SB;                                                                                                 \
     LDC_MFMA(acc[1], AL, h1)                                                                                \
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(p), "+v"(q), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));        \
+    if constexpr (APK) {                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(AHN), "+v"(ALN), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));  \
+    } else {                                                                                                \
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(p), "+v"(q), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));      \
+    }                                                                                                       \
     LDC_SB;                                                                                                 \
     LDC_SPLIT_A(AHN, 0, p.x, p.y)                                                                           \
     LDC_SB;                                                                                                 \
@@ -411,7 +468,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
     __builtin_amdgcn_s_barrier();
     LDC_STAMP(1 + 4 * seg_)
     if (seg_ == 0) { LDC_STAMP_CLK(13) }
-    LDC_READ_PQ(0u, c00, c01)
+    LDC_READ_PQ(0u, c00, c01, ahA, alA)
     {
       const unsigned w0_ = wrow + c00, w1_ = wrow + c01;
       LDC_DS_READ(l0, w1_, 0);
@@ -428,10 +485,11 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
       for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
     }
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+                 : "+v"(p), "+v"(q), "+v"(ahA), "+v"(alA), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3),
+                   "+v"(l3));
     LDC_SB;
     {
-      float t0, t1;
+      float t0 = 0.f, t1 = 0.f;
       LDC_SPLIT_A(ahA, 0, p.x, p.y)
       LDC_SPLIT_B(alA, 0, p.x, p.y)
       LDC_SPLIT_A(ahA, 1, p.z, p.w)
@@ -480,7 +538,8 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
     }
     // drain the (unused) reads of the last half-step before their registers are reused
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(p), "+v"(q), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2), "+v"(l2), "+v"(h3), "+v"(l3));
+                 : "+v"(p), "+v"(q), "+v"(ahA), "+v"(alA), "+v"(ahB), "+v"(alB), "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1), "+v"(h2),
+                   "+v"(l2), "+v"(h3), "+v"(l3));
 #undef LDC_READ_PQ
 #undef LDC_HALF_STEP
 #undef LDC_SPLIT_A
@@ -607,7 +666,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_fixup_kernel(SKArgs a)
 // returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back)
 namespace {
 
-template <int BM>
+template <int BM, bool APK>
 int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
@@ -635,6 +694,21 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
     P.R = q.R;
     P.C = q.C;
     P.d = d;
+    {
+      auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
+      bool v4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.c_bs % 4 == 0) && al16(q.C);
+      if (q.bias) v4 = v4 && al16(q.bias);
+      if (q.gate) v4 = v4 && al16(q.gate) && (d.gate_bs % 4 == 0);
+      if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
+      P.vec4 = v4 ? 1 : 0;
+      P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? 1 : 0;
+      if (P.c_split && !(v4 && d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_bs % 8 == 0 &&
+                         (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
+        return LDC_ERR_ALIGN;
+      if ((d.flags & LDC_GEMM_A_SPLIT) && ((d.lda % 8) || (d.a_bs % 8) || (reinterpret_cast<unsigned long long>(q.A) & 31ull)))
+        return LDC_ERR_ALIGN;
+      if (((d.flags & LDC_GEMM_A_SPLIT) != 0) != APK) return LDC_ERR_UNSUPPORTED;  // one activation format per launch
+    }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
     P.kt = d.K / BK;
@@ -693,12 +767,12 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
   const size_t lds = NSTAGE * STAGE_B;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM, APK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     attr_set = true;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<BM>, dim3(a.G), dim3(BM * 2), lds, s, a);
+  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<BM, APK>), dim3(a.G), dim3(BM * 2), lds, s, a);
   int st = ldc_launch_status();
   if (st != LDC_OK || a.counters != nullptr) return st;
   hipLaunchKernelGGL(gemm_bf16x3_dma_fixup_kernel<BM>, dim3(static_cast<unsigned>(tiles)), dim3(BM * 2), 0, s, a);
@@ -722,6 +796,10 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
   }
   bool small = tiles256 <= 128;  // measured cross-over (tools/gemm_bench.py, both heights forced): about half the CUs
   if (const char* e = getenv("LDC_BF16X3_BM")) small = (atoi(e) == 128);
-  return small ? launch_dma<128>(problems, n, workspace, workspace_bytes, stream)
-               : launch_dma<256>(problems, n, workspace, workspace_bytes, stream);
+  const bool apk = (problems[0].d.flags & LDC_GEMM_A_SPLIT) != 0;
+  if (apk)
+    return small ? launch_dma<128, true>(problems, n, workspace, workspace_bytes, stream)
+                 : launch_dma<256, true>(problems, n, workspace, workspace_bytes, stream);
+  return small ? launch_dma<128, false>(problems, n, workspace, workspace_bytes, stream)
+               : launch_dma<256, false>(problems, n, workspace, workspace_bytes, stream);
 }

@@ -222,6 +222,7 @@ extern "C" int ldc_gemm_bias_act(const float* A, const float* W, const float* bi
   LDC_CHECK_ALIGN16(W);
   if ((d->K & 3) || (d->lda & 3) || (d->ldw & 3) || (d->a_bs & 3)) return LDC_ERR_ALIGN;
   if (d->act < LDC_ACT_NONE || d->act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
+  if (d->flags != 0) return LDC_ERR_UNSUPPORTED;  // split activation formats: ldc_gemm_grouped_bf16x3 only
   if (d->batch > 65535 || ldc_cdiv(d->M, BM) > 65535) return LDC_ERR_UNSUPPORTED;
   GemmArgs p{A, W, bias, gate, R, C, *d, 0, 0, 0, 0};
   dim3 grid(ldc_cdiv(d->N, BN), ldc_cdiv(d->M, BM), d->batch);

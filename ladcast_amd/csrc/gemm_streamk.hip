@@ -489,6 +489,7 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
     if ((d.K & 3) || (d.lda & 3) || (d.a_bs & 3)) return LDC_ERR_ALIGN;
     if (split_bf16 ? (d.K & 7) != 0 : (d.ldw & 3) != 0) return LDC_ERR_ALIGN;
     if (d.act < LDC_ACT_NONE || d.act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
+    if (d.flags != 0) return LDC_ERR_UNSUPPORTED;  // split activation formats: the LDS-DMA bf16x3 kernel only (K % 32 == 0)
     DevProblem& P = a.pr[i];
     P.A = q.A;
     P.W = q.W;

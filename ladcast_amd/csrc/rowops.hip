@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
                                                             int rows, int D, int ldx, long long x_bs, int ldy,
                                                             long long y_bs, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int mod_bs, int mode,
-                                                            float eps) {
+                                                            float eps, int out_split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -61,7 +61,21 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
       o.y = (v[i].y - mean) * rstd * (one + m.y) + a.y;
       o.z = (v[i].z - mean) * rstd * (one + m.z) + a.z;
       o.w = (v[i].w - mean) * rstd * (one + m.w) + a.w;
-      reinterpret_cast<float4*>(yr)[c] = o;
+      if (out_split) {
+        // split activation format (ladcast_hip.h, LDC_GEMM_A_SPLIT): columns 8g..8g+7 in 32 bytes [hi x8 | lo x8];
+        // this lane has columns 4c..4c+3 = half of group c >> 1
+        float r0, r1, r2, r3;
+        uint2 hi, lo;
+        hi.x = ldc_split_pair(o.x, o.y, r0, r1);
+        hi.y = ldc_split_pair(o.z, o.w, r2, r3);
+        lo.x = ldc_pack_pair(r0, r1);
+        lo.y = ldc_pack_pair(r2, r3);
+        unsigned char* grp = reinterpret_cast<unsigned char*>(yr + 8 * (c >> 1)) + 8 * (c & 1);
+        *reinterpret_cast<uint2*>(grp) = hi;
+        *reinterpret_cast<uint2*>(grp + 16) = lo;
+      } else {
+        reinterpret_cast<float4*>(yr)[c] = o;
+      }
     }
   }
 }
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 
 extern "C" int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, int ldy,
                                  long long y_bs, const float* scale, const float* shift, int mod_bs, int mode,
-                                 float eps, void* stream) {
+                                 float eps, int out_split, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(y);
   if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
@@ -252,9 +266,10 @@ extern "C" int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int 
   if (scale) LDC_CHECK_ALIGN16(scale);
   if (shift) LDC_CHECK_ALIGN16(shift);
   if (mode != 0 && mode != 1) return LDC_ERR_UNSUPPORTED;
+  if (out_split && ((D & 7) || (ldy & 7) || (y_bs & 7) || (reinterpret_cast<unsigned long long>(y) & 31ull))) return LDC_ERR_ALIGN;
   dim3 grid(ldc_cdiv(rows, 4), B);
   hipLaunchKernelGGL(layernorm_mod_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx,
-                     x_bs, ldy, y_bs, scale, shift, mod_bs, mode, eps);
+                     x_bs, ldy, y_bs, scale, shift, mod_bs, mode, eps, out_split);
   return ldc_launch_status();
 }
 

@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
+GEMM_A_SPLIT, GEMM_C_SPLIT = 1, 2
 
 
 class GemmDesc(Structure):
@@ -26,7 +27,7 @@ class GemmDesc(Structure):
         ("M", c_int), ("N", c_int), ("K", c_int), ("batch", c_int),
         ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("ldr", c_int),
         ("a_bs", c_longlong), ("c_bs", c_longlong), ("r_bs", c_longlong),
-        ("gate_bs", c_int), ("act", c_int),
+        ("gate_bs", c_int), ("act", c_int), ("flags", c_int), ("reserved", c_int),
     ]
 
 
@@ -62,8 +63,8 @@ def _load():
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_attn_packed_bytes": (L, [I, I, I]),
         "ldc_attn_pack_bf16x3": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P, P]),
-        "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, P]),
-        "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, P]),
+        "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, I, P]),
+        "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, I, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_chan_to_token": (I, [P, P, I, I, I, I, I, P]),
@@ -127,7 +128,7 @@ def gemm(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_b
     """C[b] = epilogue(A[b] . W^T); A/C/R may be views (data_ptr carries the offset)."""
     _dev(A, W, C, bias, gate, R)
     d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K,
-                 ldc if ldc is not None else N, ldr, a_bs, c_bs, r_bs, gate_bs, act)
+                 ldc if ldc is not None else N, ldr, a_bs, c_bs, r_bs, gate_bs, act, 0, 0)
     _check(lib.ldc_gemm_bias_act(_p(A), _p(W), _p(bias), _p(gate), _p(R), _p(C), ctypes.byref(d), _stream()), "ldc_gemm_bias_act")
 
 
@@ -145,11 +146,11 @@ def _grouped_workspace(device):
 
 
 def gemm_problem(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_bs=0, bias=None, gate=None, gate_bs=0, R=None,
-                 ldr=0, r_bs=0, act=ACT_NONE):
-    """one entry of a grouped launch (same argument meaning as `gemm`)"""
+                 ldr=0, r_bs=0, act=ACT_NONE, flags=0):
+    """one entry of a grouped launch (same argument meaning as `gemm`); flags: GEMM_A_SPLIT | GEMM_C_SPLIT (bf16x3 only)"""
     _dev(A, W, C, bias, gate, R)
     d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K, ldc if ldc is not None else N, ldr,
-                 a_bs, c_bs, r_bs, gate_bs, act)
+                 a_bs, c_bs, r_bs, gate_bs, act, flags, 0)
     pv = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     return GemmProblem(pv(A), pv(W), pv(bias), pv(gate), pv(R), pv(C), d), (A, W, C, bias, gate, R)
 
@@ -207,9 +208,10 @@ def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None
                                     *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
 
 
-def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs):
+def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False):
     _dev(packed, O)
-    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, _stream()), "ldc_attn_fwd_packed_bf16x3")
+    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, 1 if out_split else 0, _stream()),
+           "ldc_attn_fwd_packed_bf16x3")
 
 
 def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, sin=None):
@@ -218,9 +220,10 @@ def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, si
            "ldc_qk_rmsnorm_rope")
 
 
-def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=None, mod_bs=0, mode=0, eps=1e-6):
+def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=None, mod_bs=0, mode=0, eps=1e-6, out_split=False):
     _dev(x, y, scale, shift)
-    _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps, _stream()),
+    _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps,
+                                 1 if out_split else 0, _stream()),
            "ldc_layernorm_mod")
 
 

@@ -420,7 +420,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=pooled_dim, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
         hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
 
-    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c):
+    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False):
         """q/k RMSNorm + RoPE per segment, then attention over token rows [row0, row0 + Sx + Sc) of the fused qkv
         buffer -> out.  seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the next Sc rows seg_c.
         fp32 mode: ldc_qk_rmsnorm_rope in place + ldc_attn_fwd; split-bf16 mode: ldc_attn_pack_bf16x3 (norm, RoPE
@@ -442,7 +442,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             sg.append((None, None, None, None))
             hip.attn_pack(q, k, v, ws.apack, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, split_row=segs[0][0],
                           seg0=sg[0], seg1=sg[1], eps=segs[0][1][0].eps)
-            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs)
+            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs, out_split=out_split)
             return
         r0 = row0
         for rows, (nq, nk, c, s_) in segs:
@@ -544,6 +544,12 @@ class LaDCastTransformer3DModel(ModelMixin):
         split = plan.split
         packed = plan.packed
 
+        # split-bf16 mode: activations that only feed GEMMs (LayerNorm outputs, attention outputs, MLP hidden states)
+        # are written ONCE in the split format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT / _C_SPLIT); the
+        # buffers, strides and column offsets are the same as in fp32 mode
+        AS = hip.GEMM_A_SPLIT if split else 0
+        CS = hip.GEMM_C_SPLIT if split else 0
+
         def G(A, W, C, **kw):  # weight in the format of the active precision mode
             return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
 
@@ -577,17 +583,17 @@ class LaDCastTransformer3DModel(ModelMixin):
         run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps)
-            run1(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)
+            run1(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)
             self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             hip.gate_residual(h_c, ws.att[:, Nx:], ws.mod_a, h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps, out_split=split)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
-            run1(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU)
+            run1(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU, flags=AS | CS)
             run1(ws.cat, f2.weight, h_c, M=Nc, N=D, K=F, batch=B, a_bs=Nc * F, c_bs=SD, bias=f2.bias,
-                        gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD)
+                        gate=ws.mod_a[:, D:], gate_bs=2 * D, R=h_c, ldr=D, r_bs=SD, flags=AS)
 
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
         hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
@@ -605,29 +611,29 @@ class LaDCastTransformer3DModel(ModelMixin):
         for blk in self.transformer_blocks:
             pa = plan.attn[id(blk.attn)]
             mx, mc = mod_of(blk.norm1.linear, 6 * D), mod_of(blk.norm1_context.linear, 6 * D)
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=NM, mode=0, eps=1e-6)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=NM, mode=0, eps=1e-6)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
             run([
-                G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
-                G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c),
+                G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
+                G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
             ])
             self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None))
+                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
             run([
-                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD),
-                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD),
+                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
+                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD, flags=AS),
             ])
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7)
+            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
             up, down = [], []
             for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
                 f0, f2 = ff.net[0].proj, ff.net[2]
                 F = f0.weight.shape[0]
                 hid = ws.cat.view(-1)[off * B * F :]  # [B, rows, F] slab inside the concat scratch
-                up.append(G(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH))
+                up.append(G(nhs, f0.weight, hid, M=rows, N=F, K=D, batch=B, a_bs=SD, c_bs=rows * F, bias=f0.bias, act=hip.ACT_GELU_TANH, flags=AS | CS))
                 down.append(G(hid, f2.weight, hs, M=rows, N=D, K=F, batch=B, a_bs=rows * F, c_bs=SD, bias=f2.bias,
-                              gate=mod[:, 5 * D :], gate_bs=NM, R=hs, ldr=D, r_bs=SD))
+                              gate=mod[:, 5 * D :], gate_bs=NM, R=hs, ldr=D, r_bs=SD, flags=AS))
             run(up)
             run(down)
 
@@ -637,20 +643,21 @@ class LaDCastTransformer3DModel(ModelMixin):
             mod = mod_of(blk.norm.linear, 3 * D)
             F = blk.proj_mlp.weight.shape[0]
             W5 = D + F
-            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6)
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
             run([
-                G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH),
-                G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv),
+                G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
+                  flags=AS | CS),
+                G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
             ])
             self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs))
+                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
-                        gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD)
+                        gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD, flags=AS)
 
         # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
         mo = mod_of(self.norm_out.linear, 2 * D)
-        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mo, shift=mo[:, D:], mod_bs=NM, mode=0, eps=1e-7)
-        run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias)
+        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mo, shift=mo[:, D:], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
+        run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias, flags=AS)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
         return out

@@ -141,6 +141,48 @@ def test_gemm_bf16x3_grouped_epilogue(hip):
         assert rel(Cd, want) < 1e-5
 
 
+def _unsplit(buf, rows, cols):
+    """decode the split activation format: every 32 bytes = [hi x8 | lo x8] bf16 -> (hi, lo) as fp32 [rows, cols]"""
+    w = buf.detach().cpu().contiguous().view(torch.int16).reshape(rows, cols // 8, 2, 8)
+    f = (w.to(torch.int32) << 16).view(torch.float32)
+    return f[:, :, 0].reshape(rows, cols), f[:, :, 1].reshape(rows, cols)
+
+
+@pytest.mark.parametrize("M,N,K", [(2250, 1536, 1536), (450, 4608, 1536), (2250, 1536, 7680), (300, 264, 160), (5000, 6144, 1536)])
+def test_gemm_bf16x3_split_activation_formats(hip, M, N, K):
+    """LDC_GEMM_A_SPLIT: activations pre-split by a producer give the bit-identical product; LDC_GEMM_C_SPLIT: the
+    output is written as the hi / lo split of the very same fp32 values (both heights of the tile are covered)."""
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    gate, res = rnd(N, seed=4), rnd(M, N, seed=5)
+    Wp = hip.pack_weight_bf16x2(dev(W))
+    Ap = hip.pack_weight_bf16x2(dev(A))  # same [rows][K/8][hi|lo] layout
+    kw = dict(M=M, N=N, K=K, bias=dev(b), gate=dev(gate), R=dev(res), ldr=N, act=2)
+    C0 = torch.empty(M, N, device="cuda")
+    hip.gemm_grouped([hip.gemm_problem(dev(A), Wp, C0, **kw)], split_bf16=True)
+    C1 = torch.empty(M, N, device="cuda")
+    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C1, flags=hip.GEMM_A_SPLIT, **kw)], split_bf16=True)
+    assert torch.equal(C0, C1)
+    C2 = torch.empty(M, N, device="cuda")
+    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C2, flags=hip.GEMM_A_SPLIT | hip.GEMM_C_SPLIT, **kw)], split_bf16=True)
+    hi, lo = _unsplit(C2, M, N)
+    want_hi = C0.cpu().bfloat16().float()
+    want_lo = (C0.cpu() - want_hi).bfloat16().float()
+    assert torch.equal(hi, want_hi) and torch.equal(lo, want_lo)
+    v = A.double() @ W.double().T + b.double()
+    want = res.double() + F.gelu(v, approximate="tanh") * gate.double()
+    assert rel(C0, want) < 1e-5
+
+
+def test_gemm_split_flags_rejected_elsewhere(hip):
+    a = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip.gemm_grouped([hip.gemm_problem(a, a, a, M=64, N=64, K=64, flags=hip.GEMM_A_SPLIT)], split_bf16=False)
+    with pytest.raises(RuntimeError):  # mixed activation formats in one launch
+        w = hip.pack_weight_bf16x2(a)
+        hip.gemm_grouped([hip.gemm_problem(a, w, torch.empty_like(a), M=64, N=64, K=64, flags=hip.GEMM_A_SPLIT),
+                          hip.gemm_problem(a, w, torch.empty_like(a), M=64, N=64, K=64)], split_bf16=True)
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_streamk_handoff_stress(hip, split):
     """Split-tile slabs under changing data: back-to-back calls on shapes whose ranges split almost every tile, with NEW
@@ -280,6 +322,34 @@ def test_attention_packed_norm_rope_two_segments(hip, Nx, Nc, rope1):
         v = x[:, :, 2 * D :].reshape(B, S, H, 128).transpose(1, 2)
         want = F.scaled_dot_product_attention(qk[0], qk[1], v).transpose(1, 2).reshape(B, S, D)
     assert rel(out, want) < 2e-5
+
+
+def test_split_activation_producers(hip):
+    """LayerNorm and the packed attention can write their output in the split activation format: it must be the
+    hi / lo split of exactly the fp32 values they write otherwise"""
+    B, rows, D = 2, 53, 1536
+    x = rnd(B, rows, D, seed=1) * 3 + 0.5
+    mod = rnd(B, 3 * D, seed=2) * 0.3
+    kw = dict(B=B, rows=rows, D=D, ldx=D, x_bs=rows * D, ldy=D, y_bs=rows * D, scale=dev(mod)[:, D:], shift=dev(mod), mod_bs=3 * D, mode=0, eps=1e-6)
+    y0, y1 = torch.empty(B, rows, D, device="cuda"), torch.empty(B, rows, D, device="cuda")
+    hip.layernorm_mod(dev(x), y0, **kw)
+    hip.layernorm_mod(dev(x), y1, out_split=True, **kw)
+    hi, lo = _unsplit(y1, B * rows, D)
+    w = y0.cpu().reshape(B * rows, D)
+    assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - w.bfloat16().float()).bfloat16().float())
+
+    Bq, S, H = 1, 300, 3
+    Dh = H * 128
+    qkv = dev(rnd(Bq, S, 3 * Dh, seed=11))
+    pk = _packed(hip, Bq, S, H)
+    hip.attn_pack(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], pk, B=Bq, S=S, H=H, ld_qkv=3 * Dh, qkv_bs=S * 3 * Dh, split_row=S)
+    o0, o1 = torch.empty(Bq, S, Dh + 64, device="cuda"), torch.zeros(Bq, S, Dh + 64, device="cuda")
+    hip.attn_fwd_packed(pk, o0, B=Bq, S=S, H=H, ldo=Dh + 64, o_bs=S * (Dh + 64))
+    hip.attn_fwd_packed(pk, o1, B=Bq, S=S, H=H, ldo=Dh + 64, o_bs=S * (Dh + 64), out_split=True)
+    hi, lo = _unsplit(o1, S, Dh + 64)
+    w = o0.cpu().reshape(S, Dh + 64)[:, :Dh]
+    assert torch.equal(hi[:, :Dh], w.bfloat16().float()) and torch.equal(lo[:, :Dh], (w - w.bfloat16().float()).bfloat16().float())
+    assert (o1[:, :, Dh:] == 0).all()  # pad columns untouched
 
 
 def test_attention_packed_rescale_branch(hip):
