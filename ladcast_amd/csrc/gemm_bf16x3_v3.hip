@@ -1,0 +1,564 @@
+// Split-bf16 ("bf16x3") stream-K GEMM, third generation: pre-split activations (LDC_GEMM_A_SPLIT) only,
+// v_mfma_f32_16x16x32_bf16, 8 waves for both tile heights.
+//
+// Why a third kernel (measurements of gemm_bf16x3_dma.hip, in-kernel clock stamps, tools/gemm_stamps.py):
+//   * the chip is at its power limit in these loops -- the 256-row kernel at 76 % MFMA busy ran at 1.30 GHz, the
+//     128-row kernel at 52 % busy at 1.88 GHz, both delivering about the same FLOP/s per CU -- so what is left to
+//     gain is energy per FLOP.  MI355X_MICROARCH.md (DVFS give-back, item 7) measures the 16x16x32 shape at
+//     1.12-1.15x the FLOP/s of 32x32x16 at equal cycles per FLOP (half the accumulator register traffic per FLOP);
+//   * with the producers writing activations already split (LayerNorm, attention, GEMM epilogues), the main loop has
+//     no VALU work left, so one k-step is just 2 + 16 fragment reads, 6 (4) DMA instructions and 48 (24) MFMAs;
+//   * a 16-row MFMA lets the 128-row tile keep EIGHT waves (16 rows each, two per SIMD) instead of four 32-row waves
+//     at one per SIMD, which is what made the half-height tile 20 % slower per CU.
+// Tile BM x 128 x 32 per k-step, BM = 256 (wave = 2 row tiles of 16) or 128 (1 row tile); operands through the same
+// 3-stage LDS-DMA ring, unit-range stream-K scheduling, XCD-aware placement and in-launch "last arriver reduces"
+// hand-off as gemm_bf16x3_dma.hip (see there for the protocol); only the LDS image swizzle, the k-step body and the
+// accumulator layout differ:
+//   * a row of a stage is 4 k-groups x [hi 16 B | lo 16 B]; chunk c = 2 kg + (0 hi | 1 lo) of row r sits in slot
+//     c ^ f(r), f(r) = ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1): conflict-free for the four 16-lane groups of
+//     a ds_read_b128 when lanes 0-15 / 16-31 / 32-47 / 48-63 read k-group 0 / 1 / 2 / 3 of 16 consecutive rows;
+//   * MFMA(W fragment, A fragment): a lane owns output row m = lane % 16 and 4 consecutive columns
+//     n = 16 ct + 4 (lane / 16) + r of column tile ct -> the epilogue stores 16 bytes per lane and accumulator.
+// k-step kt: column tiles 0-3 (their W fragments were loaded during k-step kt-1), reloading each slot with column
+// tile +4 of the same stage | barrier(kt+1) | A fragments of kt+1 | column tiles 4-7, reloading with tiles 0-3 of kt+1.
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BN = 128, BK = 32;
+constexpr int ROW_B = 128;  // bytes per LDS row (both operands)
+constexpr int NSTAGE = 3;
+constexpr int MAXP = LDC_GEMM_MAX_PROBLEMS;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+struct DevProblem {
+  const float* A;          // split activations
+  const unsigned char* W;  // packed split weights
+  const float* bias;
+  const float* gate;
+  const float* R;
+  float* C;
+  ldc_gemm_desc d;
+  int tm, tn, kt;
+  long long unit0;
+  long long tile0;
+  int vec4;     // epilogue may use 16-byte accesses
+  int c_split;  // LDC_GEMM_C_SPLIT
+};
+
+struct SKArgs {
+  DevProblem pr[MAXP];
+  int np;
+  int G;
+  long long U;
+  long long tiles;
+  float* ws;
+  unsigned* counters;  // one per tile
+};
+
+__device__ __forceinline__ long long range_start(long long g, long long U, int G) { return (g * U) / G; }
+
+__device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u) {
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < MAXP; ++k)
+    if (k < a.np && u >= a.pr[k].unit0) pi = k;
+  return pi;
+}
+
+#define LDC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<unsigned long long>(p));
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
+
+// acc[rt * 8 + ct]: rows 16 (RT wave + rt) + lane % 16, columns 16 ct + 4 (lane / 16) + (0..3)
+template <int BM>
+__device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
+                                              int lane) {
+  constexpr int RT = BM / 128;
+  const int M = P.d.M, N = P.d.N;
+  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
+  const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
+  const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
+  const int act = P.d.act;
+  const int n_lane = bn * BN + 4 * (lane >> 4);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
+    if (m >= M) continue;
+    float* crow = C + static_cast<long long>(m) * P.d.ldc;
+    const float* rrow = R ? R + static_cast<long long>(m) * P.d.ldr : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const int n = n_lane + 16 * ct;
+      if (n >= N) continue;
+      const f32x4 av = acc[rt * 8 + ct];
+      if (P.vec4) {
+        float4 v = make_float4(av[0], av[1], av[2], av[3]);
+        if (P.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
+        if (gate) {
+          const float4 gv = *reinterpret_cast<const float4*>(gate + n);
+          v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
+        }
+        if (rrow) {
+          const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (P.c_split) {  // columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group
+          float r0, r1, r2, r3;
+          uint2 hi, lo;
+          hi.x = ldc_split_pair(v.x, v.y, r0, r1);
+          hi.y = ldc_split_pair(v.z, v.w, r2, r3);
+          lo.x = ldc_pack_pair(r0, r1);
+          lo.y = ldc_pack_pair(r2, r3);
+          unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 2 * (n & 4);
+          *reinterpret_cast<uint2*>(grp) = hi;
+          *reinterpret_cast<uint2*>(grp + 16) = lo;
+        } else {
+          *reinterpret_cast<float4*>(crow + n) = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float v = av[r] + (P.bias ? P.bias[n + r] : 0.f);
+          v = ldc_apply_act(v, act);
+          if (gate) v *= gate[n + r];
+          if (rrow) v += rrow[n + r];
+          crow[n + r] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM>
+__global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
+  constexpr int RT = BM / 128;                 // 16-row tiles per wave
+  constexpr int NACC = RT * 8;                 // accumulators (f32x4) per lane
+  constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
+  constexpr int SLOT_FLOATS = BM * BN;
+  constexpr int NAI = BM / 64;                 // A DMA instructions per wave and k-step (4 / 2); W: always 2
+  constexpr int ND = NAI + 2;                  // DMA instructions per wave and k-step (6 / 4)
+  constexpr int NDH = ND / 2;                  // issued per half k-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g;
+  {  // XCD-aware placement: each XCD gets a contiguous run of unit ranges (gemm_bf16x3_dma.hip)
+    const int bid = blockIdx.x, G = a.G;
+    const int q = G >> 3, r = G & 7, xcd = bid & 7;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const long long u_begin = range_start(g, a.U, a.G);
+  const long long u_end = range_start(g + 1, a.U, a.G);
+  const int fr = lane & 15;   // fragment row (of the 16-row / 16-column MFMA tile)
+  const int kg = lane >> 4;   // k-group: k = 8 kg .. 8 kg + 7 of the k-step
+  // DMA lane geometry: a wave instruction covers 8 rows x 128 B; lane -> (row lr, 16-byte slot lp)
+  const int lr = lane >> 3, lp = lane & 7;
+  const unsigned smem_lds = lds_addr(smem);
+
+  // fragment read addresses inside a stage: A row tile rt of this wave, W column tile ct; hi chunk 2 kg, lo chunk 2 kg + 1
+  const unsigned f_r = swz(fr);  // f only depends on r & 15, and every 16-row tile starts at a multiple of 16
+  const unsigned off_hi = fr * ROW_B + (((2 * kg) ^ f_r) << 4);
+  const unsigned off_lo = fr * ROW_B + (((2 * kg + 1) ^ f_r) << 4);
+  const unsigned a_hi = smem_lds + (16 * RT * wave) * ROW_B + off_hi;  // + rt * 16 * ROW_B
+  const unsigned a_lo = smem_lds + (16 * RT * wave) * ROW_B + off_lo;
+  const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
+  const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
+
+  long long u = u_begin;
+  while (u < u_end) {
+    const int pi = find_problem_by_unit(a, u);
+    const DevProblem& P = a.pr[pi];
+    const long long local = u - P.unit0;
+    const int tile = static_cast<int>(local / P.kt);
+    const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
+    const long long left = u_end - u;
+    const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
+    const int bm = tile % P.tm;  // row tile fastest: consecutive tiles share one W column panel
+    const int bnb = tile / P.tm;
+    const int bn = bnb % P.tn;
+    const int b = bnb / P.tn;
+    const int M = P.d.M, N = P.d.N, K = P.d.K;
+    const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
+    const int lda = P.d.lda;
+    const long long w_row_bytes = static_cast<long long>(K) * 4;
+
+    // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
+    // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
+    const unsigned char* a_src[NAI];
+    const unsigned char* w_src[2];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+      const int r = 8 * (wave + 8 * i) + lr;
+      int gm = bm * BM + r;
+      gm = gm < M ? gm : M - 1;
+      a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + ((lp ^ swz(r)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (wave + 8 * i) + lr;
+      int gn = bn * BN + r;
+      gn = gn < N ? gn : N - 1;
+      w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
+    }
+    auto issue_one = [&](int kt, int stage, int i) {
+      unsigned char* sA = smem + stage * STAGE_B;
+      unsigned char* sW = sA + BM * ROW_B;
+      const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
+      if (i < NAI) dma16(a_src[i] + koff, sA + (wave + 8 * i) * 1024);
+      else dma16(w_src[i - NAI] + koff, sW + (wave + 8 * (i - NAI)) * 1024);
+    };
+
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    i32x4v wh0, wl0, wh1, wl1, wh2, wl2, wh3, wl3;           // W fragment window: 4 column tiles
+    i32x4v ah0[RT], al0[RT], ah1[RT], al1[RT];               // A fragments of the current / next k-step
+
+#define LDC_SB __builtin_amdgcn_sched_barrier(0)
+    // SBH / SBL: lane base (hi / lo chunk) + stage offset; the tile offset is an immediate
+#define LDC_RD_W(WH, WL, SBH, SBL, CT)                                           \
+  {                                                                              \
+    LDC_DS_READ(WH, SBH, (CT) * (16 * ROW_B));                                   \
+    LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));                                   \
+  }
+#define LDC_RD_A(AH, AL, SBH, SBL)                                               \
+  {                                                                              \
+    LDC_DS_READ(AH[0], SBH, 0);                                                  \
+    LDC_DS_READ(AL[0], SBL, 0);                                                  \
+    if constexpr (RT == 2) {                                                     \
+      LDC_DS_READ(AH[RT - 1], SBH, 16 * ROW_B);                                  \
+      LDC_DS_READ(AL[RT - 1], SBL, 16 * ROW_B);                                  \
+    }                                                                            \
+  }
+#define LDC_MM(ACC, WF, AF)                                                                                  \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WF), __builtin_bit_cast(bf16x8, AF), ACC, 0, 0, 0); \
+  LDC_SB;
+    // the 3 RT MFMAs of column tile CT with A fragments (AH, AL)
+#define LDC_CT(CT, WH, WL, AH, AL)                                               \
+  {                                                                              \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_) {                       \
+      LDC_MM(acc[rt_ * 8 + (CT)], WH, AL[rt_])                                   \
+      LDC_MM(acc[rt_ * 8 + (CT)], WL, AH[rt_])                                   \
+      LDC_MM(acc[rt_ * 8 + (CT)], WH, AH[rt_])                                   \
+    }                                                                            \
+  }
+#define LDC_WAIT(N, X, Y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X), "+v"(Y)); LDC_SB;
+    // one k-step: (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt+1
+#define LDC_KSTEP(AH, AL, AHN, ALN)                                                                          \
+  {                                                                                                          \
+    const int st1 = st == NSTAGE - 1 ? 0 : st + 1;                                                           \
+    const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;                                                         \
+    const unsigned sb1 = st1 * STAGE_B;                                                                      \
+    const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                     \
+    const unsigned anh = a_hi + sb1, anl = a_lo + sb1;                                                       \
+    const bool dma2 = kt + 2 < k1;  /* second half of k-step kt+2's DMAs */                                  \
+    const bool dma3 = kt + 3 < k1;  /* first half of k-step kt+3's (into stage st, free behind barrier(kt+1)) */ \
+    /* W(kt, 0..3) were issued in the order 0, 1, 2, 3 and nothing after them except A(kt) before them */    \
+    if constexpr (RT == 2) {                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                 \
+    }                                                                                                        \
+    LDC_SB;                                                                                                  \
+    LDC_CT(0, wh0, wl0, AH, AL)                                                                              \
+    LDC_RD_W(wh0, wl0, wch, wcl, 4)                                                                                \
+    if (dma2) issue_one(kt + 2, st2, NDH + 0);                                                               \
+    LDC_WAIT(6, wh1, wl1)                                                                                    \
+    LDC_CT(1, wh1, wl1, AH, AL)                                                                              \
+    LDC_RD_W(wh1, wl1, wch, wcl, 5)                                                                                \
+    if (dma2) issue_one(kt + 2, st2, NDH + 1);                                                               \
+    LDC_WAIT(6, wh2, wl2)                                                                                    \
+    LDC_CT(2, wh2, wl2, AH, AL)                                                                              \
+    LDC_RD_W(wh2, wl2, wch, wcl, 6)                                                                                \
+    if constexpr (NDH == 3) {                                                                                \
+      if (dma2) issue_one(kt + 2, st2, NDH + 2);                                                             \
+    }                                                                                                        \
+    LDC_WAIT(6, wh3, wl3)                                                                                    \
+    LDC_CT(3, wh3, wl3, AH, AL)                                                                              \
+    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                                \
+    /* barrier(kt+1): this wave is done READING stage kt; its DMAs of k-step kt+1 landed */                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3)); \
+    if (kt + 1 < k1) {                                                                                       \
+      if (dma2) {                                                                                            \
+        if constexpr (ND == 6) {                                                                             \
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                   \
+        } else {                                                                                             \
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                   \
+        }                                                                                                    \
+      } else {                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+      }                                                                                                      \
+      __builtin_amdgcn_s_barrier();                                                                          \
+    }                                                                                                        \
+    LDC_SB;                                                                                                  \
+    /* (in the last k-step the reads below fetch stale ring data that is never used) */                      \
+    LDC_RD_A(AHN, ALN, anh, anl)                                                                                  \
+    LDC_SB;                                                                                                  \
+    LDC_CT(4, wh0, wl0, AH, AL)                                                                              \
+    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                               \
+    if (dma3) issue_one(kt + 3, st, 0);                                                                      \
+    LDC_SB;                                                                                                  \
+    LDC_CT(5, wh1, wl1, AH, AL)                                                                              \
+    LDC_RD_W(wh1, wl1, wnh, wnl, 1)                                                                               \
+    if (dma3) issue_one(kt + 3, st, 1);                                                                      \
+    LDC_SB;                                                                                                  \
+    LDC_CT(6, wh2, wl2, AH, AL)                                                                              \
+    LDC_RD_W(wh2, wl2, wnh, wnl, 2)                                                                               \
+    if constexpr (NDH == 3) {                                                                                \
+      if (dma3) issue_one(kt + 3, st, 2);                                                                    \
+    }                                                                                                        \
+    LDC_SB;                                                                                                  \
+    LDC_CT(7, wh3, wl3, AH, AL)                                                                              \
+    LDC_RD_W(wh3, wl3, wnh, wnl, 3)                                                                               \
+    LDC_SB;                                                                                                  \
+    st = st1;                                                                                                \
+    sb = sb1;                                                                                                \
+  }
+
+    // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
+#pragma unroll
+    for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
+    if (k0 + 1 < k1) {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+      if constexpr (ND == 6) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    LDC_RD_A(ah0, al0, a_hi, a_lo)
+    LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
+    LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
+    LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
+    LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
+    if (k0 + 2 < k1) {
+#pragma unroll
+      for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
+    }
+    LDC_SB;
+
+    unsigned sb = 0;  // LDS byte offset of stage kt
+    int st = 0;       // stage index of k-step kt
+    for (int kt = k0; kt < k1; ++kt) {
+      LDC_KSTEP(ah0, al0, ah1, al1)
+      ++kt;
+      if (kt >= k1) break;
+      LDC_KSTEP(ah1, al1, ah0, al0)
+    }
+    // drain the (unused) reads of the last k-step before their registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(ah0[rt]), "+v"(al0[rt]), "+v"(ah1[rt]), "+v"(al1[rt]));
+#undef LDC_KSTEP
+#undef LDC_WAIT
+#undef LDC_CT
+#undef LDC_MM
+#undef LDC_RD_A
+#undef LDC_RD_W
+#undef LDC_SB
+    // all waves must be done reading the ring before the next segment's prologue overwrites stage 0/1
+    __builtin_amdgcn_s_barrier();
+
+    if (k0 == 0 && k1 == P.kt) {
+      tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+    } else {
+      // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
+      // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
+      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64 + lane, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;
+      const long long l = f + P.kt;
+      long long g_first = g;
+      while (g_first > 0 && range_start(g_first, a.U, a.G) > f) --g_first;
+      long long g_last = g;
+      while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
+      const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
+      unsigned* cnt = a.counters + (P.tile0 + tile);
+      unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
+      if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      const unsigned is_last = *flag;
+      __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
+      if (is_last) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long long gp = g_first; gp <= g_last; ++gp) {
+          const long long s = range_start(gp, a.U, a.G);
+          const float* sl = a.ws + (2 * gp + (s > f ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+          for (int i = 0; i < NACC; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane];
+          }
+        }
+        tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+      }
+    }
+    u += k1 - k0;
+  }
+}
+
+template <int BM>
+int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+  constexpr int SLOT_FLOATS = BM * BN;
+  constexpr int STAGE_B = (BM + BN) * ROW_B;
+  constexpr int CUS = 256;  // one workgroup per CU
+  SKArgs a{};
+  a.np = n;
+  long long U = 0, tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ldc_gemm_problem& q = problems[i];
+    LDC_CHECK_PTR(q.A);
+    LDC_CHECK_PTR(q.W);
+    LDC_CHECK_PTR(q.C);
+    const ldc_gemm_desc& d = q.d;
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
+    if (d.K % BK) return LDC_ERR_UNSUPPORTED;
+    if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
+    LDC_CHECK_ALIGN16(q.A);
+    LDC_CHECK_ALIGN16(q.W);
+    if ((d.lda & 7) || (d.a_bs & 7) || (reinterpret_cast<unsigned long long>(q.A) & 31ull)) return LDC_ERR_ALIGN;
+    if (d.act < LDC_ACT_NONE || d.act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
+    DevProblem& P = a.pr[i];
+    P.A = q.A;
+    P.W = reinterpret_cast<const unsigned char*>(q.W);
+    P.bias = q.bias;
+    P.gate = q.gate;
+    P.R = q.R;
+    P.C = q.C;
+    P.d = d;
+    {
+      auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
+      bool v4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.c_bs % 4 == 0) && al16(q.C);
+      if (q.bias) v4 = v4 && al16(q.bias);
+      if (q.gate) v4 = v4 && al16(q.gate) && (d.gate_bs % 4 == 0);
+      if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
+      P.vec4 = v4 ? 1 : 0;
+      P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? 1 : 0;
+      if (P.c_split && !(v4 && d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_bs % 8 == 0 &&
+                         (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
+        return LDC_ERR_ALIGN;
+    }
+    P.tm = ldc_cdiv(d.M, BM);
+    P.tn = ldc_cdiv(d.N, BN);
+    P.kt = d.K / BK;
+    P.unit0 = U;
+    P.tile0 = tiles;
+    const long long t = static_cast<long long>(d.batch) * P.tm * P.tn;
+    tiles += t;
+    U += t * P.kt;
+  }
+  if (tiles > LDC_GEMM_COUNTER_BYTES / 4) return LDC_ERR_UNSUPPORTED;  // in-launch reduction only
+  const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
+  // grid size: as gemm_bf16x3_dma.hip (phase-aligned divisor of tiles * s when every problem has the same k-depth)
+  long long G = CUS;
+  {
+    bool same_kt = true;
+    for (int i = 1; i < n; ++i) same_kt = same_kt && (a.pr[i].kt == a.pr[0].kt);
+    long long best = 0;
+    if (same_kt) {
+      const int kt = a.pr[0].kt;
+      for (int sfac = 1; sfac <= 4; ++sfac) {
+        if (kt % sfac || kt / sfac < 8) continue;
+        const long long items = tiles * sfac;
+        long long gd = items < CUS ? items : CUS;
+        while (gd > 1 && items % gd) --gd;
+        const long long score = gd * (34 - sfac);
+        if (score > best * (34 - 1) / 33 && gd > best) best = gd;
+      }
+    }
+    if (best >= 160) {
+      G = best;
+    } else {
+      const double kt_avg = static_cast<double>(U) / static_cast<double>(tiles);
+      long long umin = static_cast<long long>(sqrt(kt_avg * 8.0) + 0.5);
+      if (umin < 1) umin = 1;
+      const long long gmax = U / umin > 0 ? U / umin : 1;
+      if (gmax < G) G = gmax;
+    }
+  }
+  if (U < G) G = U;
+  if (workspace == nullptr) return LDC_ERR_ARG;
+  if (workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2 * slot_bytes) return LDC_ERR_ARG;
+  {
+    const long long fit = (workspace_bytes - LDC_GEMM_COUNTER_BYTES) / (2 * slot_bytes);
+    if (fit < G) G = fit;
+  }
+  LDC_CHECK_ALIGN16(workspace);
+  a.G = static_cast<int>(G);
+  a.U = U;
+  a.tiles = tiles;
+  a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
+  a.counters = static_cast<unsigned*>(workspace);
+  const size_t lds = NSTAGE * STAGE_B;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16x3_v3_kernel<BM>, dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+  return ldc_launch_status();
+}
+
+}  // namespace
+
+// returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back to gemm_bf16x3_dma.hip)
+int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                               void* stream) {
+  LDC_CHECK_PTR(problems);
+  if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
+  long long tiles256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ldc_gemm_desc& d = problems[i].d;
+    if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return LDC_ERR_ARG;
+    if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
+    tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
+  }
+  // half-height tiles while 256-row tiles would not fill the chip twice over (both heights run 8 waves here, so the
+  // half-height tile costs no MFMA efficiency, only twice the W traffic per FLOP); LDC_BF16X3_BM forces one
+  bool small = tiles256 < 400;  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
+  if (const char* e = getenv("LDC_BF16X3_BM")) small = (atoi(e) == 128);
+  return small ? launch_v3<128>(problems, n, workspace, workspace_bytes, stream)
+               : launch_v3<256>(problems, n, workspace, workspace_bytes, stream);
+}

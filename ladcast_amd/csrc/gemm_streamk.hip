@@ -556,15 +556,25 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
 
 int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                                 void* stream);  // gemm_bf16x3_dma.hip
+int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                               void* stream);  // gemm_bf16x3_v3.hip
 
 extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace,
                                        long long workspace_bytes, void* stream) {
-  // LDS-DMA ring kernel (256x128 tile) when every K is a multiple of 32, else the register-staged kernel.
-  // LDC_BF16X3_KERNEL=regstage forces the latter (A/B measurements).
-  static const bool force_v1 = [] {
+  // Pre-split activations (LDC_GEMM_A_SPLIT) and K % 32 == 0: the 16x16x32 kernel (gemm_bf16x3_v3.hip); fp32
+  // activations and K % 32 == 0: the 32x32x16 LDS-DMA kernel (gemm_bf16x3_dma.hip); otherwise the register-staged
+  // kernel.  LDC_BF16X3_KERNEL=regstage / dma forces the older ones (A/B measurements).
+  static const int force = [] {
     const char* e = getenv("LDC_BF16X3_KERNEL");
-    return e != nullptr && strcmp(e, "regstage") == 0;
+    if (e != nullptr && strcmp(e, "regstage") == 0) return 1;
+    if (e != nullptr && strcmp(e, "dma") == 0) return 2;
+    return 0;
   }();
+  const bool force_v1 = force == 1;
+  if (force == 0) {
+    const int st = ldc_gemm_grouped_bf16x3_v3(problems, n, workspace, workspace_bytes, stream);
+    if (st != LDC_ERR_UNSUPPORTED) return st;
+  }
   if (!force_v1) {
     const int st = ldc_gemm_grouped_bf16x3_dma(problems, n, workspace, workspace_bytes, stream);
     if (st != LDC_ERR_UNSUPPORTED) return st;

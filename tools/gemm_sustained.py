@@ -16,12 +16,16 @@ calls = {
     "4096^3": [(4096, 4096, 4096)],
 }
 warm_s = float(os.environ.get("WARM_S", "1.5"))
+a_split = os.environ.get("A_SPLIT", "1") != "0"
 for name, probs in calls.items():
     ps = []
     flops = 0
     for (M, N, K) in probs:
         A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); C = torch.empty(M, N, device="cuda")
-        ps.append(hip.gemm_problem(A, hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K))
+        if a_split:  # as the model: activations pre-split by their producer -> the 16x16x32 kernel
+            ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, flags=hip.GEMM_A_SPLIT))
+        else:
+            ps.append(hip.gemm_problem(A, hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K))
         flops += 2 * M * N * K
     fn = lambda: hip.gemm_grouped(ps, split_bf16=True)
     t_end = time.time() + warm_s
