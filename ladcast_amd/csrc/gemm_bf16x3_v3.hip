@@ -20,7 +20,8 @@
 //   * MFMA(W fragment, A fragment): a lane owns output row m = lane % 16 and 4 consecutive columns
 //     n = 16 ct + 4 (lane / 16) + r of column tile ct -> the epilogue stores 16 bytes per lane and accumulator.
 // k-step kt: column tiles 0-3 (their W fragments were loaded during k-step kt-1), reloading each slot with column
-// tile +4 of the same stage | barrier(kt+1) | A fragments of kt+1 | column tiles 4-7, reloading with tiles 0-3 of kt+1.
+// tile +4 of the same stage | column tile 4 | barrier(kt+1) | A fragments of kt+1 | column tiles 5-7, reloading with tiles
+// 0-3 of kt+1 (the barrier's lgkmcnt(0) then waits for reads that were issued a whole column tile earlier).
 #include <math.h>
 #include <stdlib.h>
 
@@ -72,7 +73,11 @@ __device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u
   return pi;
 }
 
+#ifdef LDC_GEMM_DIAG_NOLDS  // diagnostic build: no fragment reads (results are garbage)
+#define LDC_DS_READ(dst, addr, off) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(addr))
+#else
 #define LDC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return static_cast<unsigned>(reinterpret_cast<unsigned long long>(p));
@@ -148,6 +153,20 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
   }
 }
 
+// Diagnostic build only (-DLDC_GEMM_STAMPS, `make stamps`): wall-clock / shader-clock stamps per workgroup into the
+// upper half of the counter block, which nothing else reads; the product build contains no stamp.
+#ifdef LDC_GEMM_STAMPS
+#define LDC_STAMP(i)                                                                                        \
+  if (threadIdx.x == 0)                                                                                     \
+    reinterpret_cast<unsigned long long*>(a.counters)[65536 + blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#define LDC_STAMP_CLK(i)                                                                                    \
+  if (threadIdx.x == 0)                                                                                     \
+    reinterpret_cast<unsigned long long*>(a.counters)[65536 + blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define LDC_STAMP(i)
+#define LDC_STAMP_CLK(i)
+#endif
+
 template <int BM>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
@@ -161,14 +180,24 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LDC_STAMP(0)
+  int seg_ = 0;
+  (void)seg_;
   int g;
   {  // XCD-aware placement: each XCD gets a contiguous run of unit ranges (gemm_bf16x3_dma.hip)
     const int bid = blockIdx.x, G = a.G;
     const int q = G >> 3, r = G & 7, xcd = bid & 7;
     g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const long long u_begin = range_start(g, a.U, a.G);
-  const long long u_end = range_start(g + 1, a.U, a.G);
+  // the 64-bit division runs on the vector ALU: pin the (wave-uniform) results into scalar registers so that the whole
+  // k loop is scalar control flow
+  auto uniform64 = [](long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(static_cast<unsigned long long>(v) >> 32));
+    return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+  };
+  const long long u_begin = uniform64(range_start(g, a.U, a.G));
+  const long long u_end = uniform64(range_start(g + 1, a.U, a.G));
   const int fr = lane & 15;   // fragment row (of the 16-row / 16-column MFMA tile)
   const int kg = lane >> 4;   // k-group: k = 8 kg .. 8 kg + 7 of the k-step
   // DMA lane geometry: a wave instruction covers 8 rows x 128 B; lane -> (row lr, 16-byte slot lp)
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const int pi = find_problem_by_unit(a, u);
     const DevProblem& P = a.pr[pi];
     const long long local = u - P.unit0;
-    const int tile = static_cast<int>(local / P.kt);
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
     const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
     const long long left = u_end - u;
     const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
@@ -220,12 +249,21 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       gn = gn < N ? gn : N - 1;
       w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
     }
-    auto issue_one = [&](int kt, int stage, int i) {
+    // k-steps past the end of the segment are clamped to its last one and land in a per-wave dump slot behind the ring:
+    // the loop body then has no branch around a DMA, every vmcnt is static, and nothing stale can land in the ring (or
+    // on the hand-off flag word in it) after the segment
+    auto issue_one = [&](int kt_, int stage, int i) {
+      const bool live = kt_ < k1;
       unsigned char* sA = smem + stage * STAGE_B;
       unsigned char* sW = sA + BM * ROW_B;
+      unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
+      const int kt = live ? kt_ : k1 - 1;
       const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
-      if (i < NAI) dma16(a_src[i] + koff, sA + (wave + 8 * i) * 1024);
-      else dma16(w_src[i - NAI] + koff, sW + (wave + 8 * (i - NAI)) * 1024);
+#ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
+      if (kt >= 0) return;
+#endif
+      if (i < NAI) dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
+      else dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
     };
 
     f32x4 acc[NACC];
@@ -254,15 +292,27 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #define LDC_MM(ACC, WF, AF)                                                                                  \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WF), __builtin_bit_cast(bf16x8, AF), ACC, 0, 0, 0); \
   LDC_SB;
-    // the 3 RT MFMAs of column tile CT with A fragments (AH, AL)
+    // the 3 RT MFMAs of column tile CT with A fragments (AH, AL); with two row tiles their accumulation chains alternate
 #define LDC_CT(CT, WH, WL, AH, AL)                                               \
   {                                                                              \
-    _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_) {                       \
-      LDC_MM(acc[rt_ * 8 + (CT)], WH, AL[rt_])                                   \
-      LDC_MM(acc[rt_ * 8 + (CT)], WL, AH[rt_])                                   \
-      LDC_MM(acc[rt_ * 8 + (CT)], WH, AH[rt_])                                   \
+    if constexpr (RT == 2) {                                                     \
+      LDC_MM(acc[(CT)], WH, AL[0])                                               \
+      LDC_MM(acc[8 + (CT)], WH, AL[RT - 1])                                      \
+      LDC_MM(acc[(CT)], WL, AH[0])                                               \
+      LDC_MM(acc[8 + (CT)], WL, AH[RT - 1])                                      \
+      LDC_MM(acc[(CT)], WH, AH[0])                                               \
+      LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])                                      \
+    } else {                                                                     \
+      LDC_MM(acc[(CT)], WH, AL[0])                                               \
+      LDC_MM(acc[(CT)], WL, AH[0])                                               \
+      LDC_MM(acc[(CT)], WH, AH[0])                                               \
     }                                                                            \
   }
+#ifdef LDC_GEMM_DIAG_NOBARRIER  // diagnostic build: what the k-step costs without its barrier (results are garbage)
+#define LDC_KSTEP_BARRIER
+#else
+#define LDC_KSTEP_BARRIER __builtin_amdgcn_s_barrier();
+#endif
 #define LDC_WAIT(N, X, Y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X), "+v"(Y)); LDC_SB;
     // one k-step: (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt+1
 #define LDC_KSTEP(AH, AL, AHN, ALN)                                                                          \
@@ -272,8 +322,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const unsigned sb1 = st1 * STAGE_B;                                                                      \
     const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                     \
     const unsigned anh = a_hi + sb1, anl = a_lo + sb1;                                                       \
-    const bool dma2 = kt + 2 < k1;  /* second half of k-step kt+2's DMAs */                                  \
-    const bool dma3 = kt + 3 < k1;  /* first half of k-step kt+3's (into stage st, free behind barrier(kt+1)) */ \
+    constexpr bool dma2 = true; /* second half of k-step kt+2's DMAs (clamped past the end) */             \
+    constexpr bool dma3 = true; /* first half of k-step kt+3's (into stage st, free behind barrier(kt+1)) */ \
     /* W(kt, 0..3) were issued in the order 0, 1, 2, 3 and nothing after them except A(kt) before them */    \
     if constexpr (RT == 2) {                                                                                 \
       asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
@@ -296,27 +346,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     }                                                                                                        \
     LDC_WAIT(6, wh3, wl3)                                                                                    \
     LDC_CT(3, wh3, wl3, AH, AL)                                                                              \
-    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                                \
-    /* barrier(kt+1): this wave is done READING stage kt; its DMAs of k-step kt+1 landed */                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3)); \
-    if (kt + 1 < k1) {                                                                                       \
-      if (dma2) {                                                                                            \
-        if constexpr (ND == 6) {                                                                             \
-          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                   \
-        } else {                                                                                             \
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                   \
-        }                                                                                                    \
-      } else {                                                                                               \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
-      }                                                                                                      \
-      __builtin_amdgcn_s_barrier();                                                                          \
+    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                          \
+    LDC_WAIT(6, wh0, wl0)                                                                                    \
+    LDC_CT(4, wh0, wl0, AH, AL)                                                                              \
+    /* barrier(kt+1): this wave is done READING stage kt (its last reads were issued one column tile ago);  \
+       its DMAs of k-step kt+1 landed */                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3)); \
+    if constexpr (ND == 6) {                                                                                 \
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                       \
     }                                                                                                        \
+    LDC_KSTEP_BARRIER                                                                                        \
     LDC_SB;                                                                                                  \
     /* (in the last k-step the reads below fetch stale ring data that is never used) */                      \
-    LDC_RD_A(AHN, ALN, anh, anl)                                                                                  \
-    LDC_SB;                                                                                                  \
-    LDC_CT(4, wh0, wl0, AH, AL)                                                                              \
-    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                               \
+    LDC_RD_A(AHN, ALN, anh, anl)                                                                             \
+    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                          \
     if (dma3) issue_one(kt + 3, st, 0);                                                                      \
     LDC_SB;                                                                                                  \
     LDC_CT(5, wh1, wl1, AH, AL)                                                                              \
@@ -339,27 +384,23 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
 #pragma unroll
     for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
-    if (k0 + 1 < k1) {
 #pragma unroll
-      for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
-      if constexpr (ND == 6) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      }
+    for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+    if constexpr (ND == 6) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    LDC_STAMP(1 + 4 * seg_)
+    if (seg_ == 0) { LDC_STAMP_CLK(13) }
     LDC_RD_A(ah0, al0, a_hi, a_lo)
     LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
     LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
     LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
     LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
-    if (k0 + 2 < k1) {
 #pragma unroll
-      for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
-    }
+    for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
     LDC_SB;
 
     unsigned sb = 0;  // LDS byte offset of stage kt
@@ -383,6 +424,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #undef LDC_SB
     // all waves must be done reading the ring before the next segment's prologue overwrites stage 0/1
     __builtin_amdgcn_s_barrier();
+    if (seg_ == 0) { LDC_STAMP_CLK(14) }
+    LDC_STAMP(2 + 4 * seg_)
 
     if (k0 == 0 && k1 == P.kt) {
       tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
@@ -417,6 +460,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
         *flag = last;
       }
       __syncthreads();
+      LDC_STAMP(3 + 4 * seg_)
       const unsigned is_last = *flag;
       __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
       if (is_last) {
@@ -435,7 +479,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       }
     }
     u += k1 - k0;
+    LDC_STAMP(4 + 4 * seg_)
+#ifdef LDC_GEMM_STAMPS
+    if (seg_ < 2) ++seg_;
+#endif
   }
+  LDC_STAMP(15)
 }
 
 template <int BM>
@@ -530,7 +579,7 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
-  const size_t lds = NSTAGE * STAGE_B;
+  const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM>),
