@@ -77,7 +77,15 @@ class KernelTimer:
             timer._orig["gemm_grouped"](problems, split_bf16=split_bf16)
             e.record()
             work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
-            timer.records.setdefault("gemm_streamk_kernel", []).append((s, e, work))
+            # which kernel the C ABI dispatches to (gemm_streamk.hip, ldc_gemm_grouped_bf16x3): pre-split activations and
+            # K % 32 == 0 -> the 16x16x32 kernel; fp32 activations and K % 32 == 0 -> the 32x32x16 LDS-DMA kernel
+            if not split_bf16:
+                name = "gemm_streamk_kernel"
+            elif all(p[0].d.K % 32 == 0 for p in problems):
+                name = "gemm_bf16x3_v3_kernel" if all(p[0].d.flags & 1 for p in problems) else "gemm_bf16x3_dma_kernel"
+            else:
+                name = "gemm_streamk_bf16x3_kernel"
+            timer.records.setdefault(name, []).append((s, e, work))
 
         def gemm(A, W, C, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -261,10 +269,11 @@ def main():
         ks = timer.summary()
         roof = None
         split = args.precision == "bf16x3"
-        dom = "gemm_streamk_kernel" if "gemm_streamk_kernel" in ks else "gemm_nt_f32_kernel"
+        gemm_names = [n for n in ks if n.startswith("gemm_")]
+        dom = max(gemm_names, key=lambda n: ks[n]["total_ms"]) if gemm_names else None  # the GEMM kernel with the most time
         if dom in ks:
             k = ks[dom]
-            kname = "gemm_bf16x3_dma_kernel" if split else dom
+            kname = dom
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
