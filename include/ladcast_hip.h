@@ -266,6 +266,25 @@ int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B,
  * or repeat_interleave (cin < cout; decoder in shortcut, :720-722). */
 int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Ensemble scoring of one lead time of a decoded forecast:
+ *   forecast [M members][C][H*W] with member / channel strides in elements (the H*W plane contiguous), so a
+ *   `[:, :, t]` slice of the reference's (ens, C, T, H, W) array needs no copy; truth / clim [C][H*W] with a channel
+ *   stride (clim NULL = no ACC); lat_weight [H]; M <= 64.
+ *   out [5][C] = ens_acc, ens_mse, crps_spread, crps_skill, crps, each the (nan)mean over the grid of the
+ *   latitude-weighted point values; channel `nan_channel` (the SST channel, NaN over land) uses nanmean, the others
+ *   mean (-1 = none); ACC always nanmean.  skill_map / spread_map: optional [C][H*W] unweighted point values.
+ * Replaces pointwise_crps_skill / pointwise_crps_spread / get_crps / get_acc (ladcast/evaluate/utils.py:51-149) and
+ * the per-lead-time block of ladcast/evaluate/evaluate_ens_gpu.py:339-425; one pass over the forecast.
+ * workspace: ldc_ensemble_scores_workspace_bytes(C, H, W) bytes of device scratch.
+ * ------------------------------------------------------------------------- */
+long long ldc_ensemble_scores_workspace_bytes(int C, int H, int W);
+int ldc_ensemble_scores(const float* forecast, long long member_stride, long long channel_stride,
+                        const float* truth, long long truth_channel_stride, const float* clim,
+                        long long clim_channel_stride, const float* lat_weight, int M, int C, int H, int W,
+                        int nan_channel, float* out, float* skill_map, float* spread_map, void* workspace,
+                        long long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
+        "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
+        "ldc_ensemble_scores": (I, [P, L, L, P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P]),
         "ldc_attn_packed_bytes": (L, [I, I, I]),
         "ldc_attn_pack_bf16x3": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P, P]),
         "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, I, P]),
@@ -192,6 +194,23 @@ def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False
     _dev(Q, K, V, O)
     fn = lib.ldc_attn_fwd_bf16x3 if split_bf16 else lib.ldc_attn_fwd
     _check(fn(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd" + ("_bf16x3" if split_bf16 else ""))
+
+
+_score_ws = {}
+
+
+def ensemble_scores(forecast, truth, clim, lat_weight, out, *, M, C, H, W, member_stride, channel_stride, truth_channel_stride,
+                    clim_channel_stride=0, nan_channel=-1, skill_map=None, spread_map=None):
+    """out: [5][C] = acc, mse, crps_spread, crps_skill, crps (ladcast_hip.h: ldc_ensemble_scores)"""
+    _dev(forecast, truth, clim, lat_weight, out, skill_map, spread_map)
+    need = int(lib.ldc_ensemble_scores_workspace_bytes(C, H, W))
+    key = (str(forecast.device), torch.cuda.current_stream(forecast.device).cuda_stream)
+    if key not in _score_ws or _score_ws[key].numel() * 4 < need:
+        _score_ws[key] = torch.empty(need // 4 + 1, device=forecast.device, dtype=torch.float32)
+    ws = _score_ws[key]
+    _check(lib.ldc_ensemble_scores(_p(forecast), member_stride, channel_stride, _p(truth), truth_channel_stride, _p(clim),
+                                   clim_channel_stride, _p(lat_weight), M, C, H, W, nan_channel, _p(out), _p(skill_map), _p(spread_map),
+                                   _p(ws), ws.numel() * 4, _stream()), "ldc_ensemble_scores")
 
 
 def attn_packed_bytes(B, S, H):

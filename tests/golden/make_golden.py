@@ -6,6 +6,11 @@ reference module):  python tests/golden/make_golden.py
 * sphere_conv_ref.npz   -- inputs / weights / outputs of the REFERENCE class
   ladcast.models.sphere_conv.SphereConv2d (imported from /root/reference), plus
   its docstring known-answer vector (models/sphere_conv.py:142-172).
+* scoring_ref.npz       -- inputs / outputs of the REFERENCE scoring functions
+  (ladcast/evaluate/utils.py:9-149).  That module imports xarray at the top,
+  which is not installed, and none of these six functions uses it: their
+  definitions are taken from the reference file's syntax tree at generation
+  time and executed as they stand (nothing of the file is copied into the repo).
 * oracle_pins.npz       -- outputs of THIS repo's oracle on seeded synthetic
   inputs (regression pins; they are not reference outputs -- the reference's
   diffusers-dependent path cannot be imported here, see oracle/__init__.py).
@@ -59,6 +64,43 @@ def sphere_conv_fixtures():
     np.savez_compressed(os.path.join(HERE, "sphere_conv_ref.npz"), **out)
 
 
+def scoring_fixtures():
+    import ast
+    from typing import Optional, Union
+
+    src = open("/root/reference/ladcast/evaluate/utils.py").read()
+    want = {"get_lat_weights_from_lat_tensor", "get_normalized_lat_weights_based_on_cos", "pointwise_crps_skill",
+            "pointwise_crps_spread", "get_crps", "get_acc"}
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert {n.name for n in body} == want
+    ns = {"torch": torch, "np": np, "Optional": Optional, "Union": Union}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "ladcast/evaluate/utils.py", "exec"), ns)
+
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    for i, (M, C, H, W) in enumerate([(5, 3, 6, 8), (1, 2, 4, 6), (16, 4, 9, 12), (50, 2, 8, 10)]):
+        fc = torch.randn(M, C, H, W, generator=g) * 2 + 0.3
+        tr = torch.randn(C, H, W, generator=g)
+        cl = torch.randn(C, H, W, generator=g) * 0.5
+        if i == 0:  # SST-like NaNs over "land" in channel 1 (same points in forecast and truth), one tie
+            mask = torch.rand(H, W, generator=g) < 0.3
+            fc[:, 1][:, mask] = float("nan")
+            tr[1][mask] = float("nan")
+            fc[1, 0, 0, 0] = fc[0, 0, 0, 0]
+        lat = torch.linspace(-88.5, 88.5, H)
+        w_cos = ns["get_normalized_lat_weights_based_on_cos"](lat)
+        w_area = ns["get_lat_weights_from_lat_tensor"](lat[None])[0]
+        out[f"s{i}_fc"], out[f"s{i}_tr"], out[f"s{i}_cl"], out[f"s{i}_lat"] = fc.numpy(), tr.numpy(), cl.numpy(), lat.numpy()
+        out[f"s{i}_w_cos"], out[f"s{i}_w_area"] = w_cos.numpy(), w_area.numpy()
+        out[f"s{i}_skill"] = ns["pointwise_crps_skill"](fc, tr.unsqueeze(0), 0).numpy()
+        out[f"s{i}_spread"] = ns["pointwise_crps_spread"](fc, 0).numpy()
+        out[f"s{i}_crps"] = ns["get_crps"](fc, tr.unsqueeze(0), 0).numpy()
+        out[f"s{i}_acc_w"] = ns["get_acc"](fc.mean(dim=0), tr, cl, w_cos.view(1, -1, 1)).numpy()
+        out[f"s{i}_acc"] = ns["get_acc"](fc.mean(dim=0), tr, cl, None).numpy()
+    np.savez_compressed(os.path.join(HERE, "scoring_ref.npz"), **out)
+
+
 def oracle_pins():
     from tests.synth import tiny_ar_config, tiny_dcae_config, make_ar, make_dcae, synth_known, synth_field
 
@@ -93,5 +135,6 @@ def oracle_pins():
 
 if __name__ == "__main__":
     sphere_conv_fixtures()
+    scoring_fixtures()
     oracle_pins()
     print("wrote", sorted(os.listdir(HERE)))

@@ -1,0 +1,34 @@
+"""ensemble scoring of one lead time at the BASELINE field size: fused HIP kernel vs the torch op sequence of the
+reference (evaluate_ens_gpu.py:339-425) run on the same GPU, and the kernel's HBM rate.  usage: python tools/scoring_bench.py [ens]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ladcast_amd.evaluate as E
+from oracle import scoring as S
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+C, H, W, sst = 84, 120, 240, 68
+g = torch.Generator().manual_seed(0)
+dec = (torch.randn(M, C, H, W, generator=g) * 2).cuda(); ref = torch.randn(C, H, W, generator=g).cuda(); clim = torch.randn(C, H, W, generator=g).cuda()
+w = S.get_normalized_lat_weights_based_on_cos(torch.linspace(-89, 89, H)).cuda()
+
+def timed(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+
+def torch_ops():  # the oracle's torch restatement, on the device
+    wv = w.view(1, -1, 1)
+    mean_t = dec.mean(dim=0)
+    S.get_acc(mean_t, ref, clim, wv)
+    ((mean_t - ref) ** 2 * wv).mean(dim=(1, 2))
+    sp = S.pointwise_crps_spread(dec, 0) * wv
+    sk = S.pointwise_crps_skill(dec, ref.unsqueeze(0), 0) * wv
+    (sk - 0.5 * sp).mean(dim=(1, 2)); sp.mean(dim=(1, 2)); sk.mean(dim=(1, 2))
+
+t_hip = timed(lambda: E.ensemble_scores(dec, ref, clim, w, sst))
+t_torch = timed(torch_ops, 5)
+nbytes = dec.numel() * 4 + 2 * ref.numel() * 4
+print(f"ens={M}: ldc_ensemble_scores {t_hip * 1e6:.1f} us = {nbytes / t_hip / 1e12:.2f} TB/s of algorithmic bytes ({nbytes / 1e6:.0f} MB read once); "
+      f"torch op sequence on the same GPU {t_torch * 1e6:.1f} us ({t_torch / t_hip:.1f}x)")
