@@ -6,3 +6,4 @@ from .utils import (  # noqa: F401
     ensemble_AR_sampler,
     roll_out_serial,
 )
+from .io import latent_file_name, list_latent_files, load_latent_npy, save_latent_npy  # noqa: F401

@@ -109,3 +109,31 @@ def test_year_embedding_and_rope_tables_match_oracle():
     grids = [torch.arange(1, 5).float(), torch.linspace(-8.7, 8.9, 15), torch.linspace(0.09, 6.17, 30)]
     a, b = rope_tables_from_grid((16, 56, 56), grids, 256.0), rope_from_grid((16, 56, 56), grids, 256.0)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[0].shape == (1800, 128)
+
+
+def test_latent_npy_conventions(tmp_path):
+    """file names, shapes and reader rules of the reference (evaluate/pred_rollout.py:421-430,
+    evaluate/evaluate_ens_gpu.py:208-283, pipelines/utils.py:129-137); host-side, no device needed"""
+    import datetime as dt
+
+    import numpy as np
+
+    from ladcast_amd.pipelines.io import latent_file_name, list_latent_files, load_latent_npy, save_latent_npy
+
+    res = torch.arange(2 * 3 * 4 * 5 * 2 * 2, dtype=torch.float32).reshape(2, 3, 4, 5, 2, 2)
+    stamps = [dt.datetime(2018, 1, 1, 0), np.datetime64("2018-01-03T12")]
+    paths = save_latent_npy(res, stamps, str(tmp_path))
+    assert [p.split("/")[-1] for p in paths] == ["latent_2018010100.npy", "latent_2018010312.npy"]
+    assert latent_file_name(2018123118) == "latent_2018123118.npy"
+    raw = np.load(paths[1])  # what the reference's np.load sees
+    assert raw.shape == (3, 4, 5, 2, 2) and raw.dtype == np.float32 and np.array_equal(raw, res[1].numpy())
+    t, ts = load_latent_npy(paths[0], crop_init=True, force_ens_size=2)
+    assert ts == 2018010100 and torch.equal(t, res[0][:2, :, 1:])
+    np.save(str(tmp_path / "latent_2018010500.npy"), res[:1].numpy())  # 6-D file: first entry is used
+    t6, _ = load_latent_npy(str(tmp_path / "latent_2018010500.npy"))
+    assert torch.equal(t6, res[0])
+    listed = list_latent_files(str(tmp_path), end_date="2018-01-06T00:00:00", total_lead_time_hour=48)
+    assert [s for s, _ in listed] == ["2018010100", "2018010312"]  # 2018-01-05 + 48 h is past the end date
+    assert [s for s, _ in list_latent_files(str(tmp_path))] == ["2018010100", "2018010312", "2018010500"]
+    with pytest.raises(ValueError):
+        save_latent_npy(res[0], stamps, str(tmp_path))
