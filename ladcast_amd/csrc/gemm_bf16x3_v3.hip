@@ -125,16 +125,17 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
           v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
-        if (P.c_split) {  // columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group
+        if (P.c_split) {
+          // columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16 further
+          // (k-group ^ 1) the other half of the same row: v_permlane16_swap hands the even k-group both hi halves and the
+          // odd one both lo halves, so each lane stores 16 contiguous bytes instead of two 8-byte pieces
           float r0, r1, r2, r3;
-          uint2 hi, lo;
-          hi.x = ldc_split_pair(v.x, v.y, r0, r1);
-          hi.y = ldc_split_pair(v.z, v.w, r2, r3);
-          lo.x = ldc_pack_pair(r0, r1);
-          lo.y = ldc_pack_pair(r2, r3);
-          unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 2 * (n & 4);
-          *reinterpret_cast<uint2*>(grp) = hi;
-          *reinterpret_cast<uint2*>(grp + 16) = lo;
+          const unsigned hx = ldc_split_pair(v.x, v.y, r0, r1), hy = ldc_split_pair(v.z, v.w, r2, r3);
+          const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
+          const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);  // [0]: even rows keep hi, odd rows get lo(even)
+          const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);  // [1]: even rows get hi(odd), odd rows keep lo
+          unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
+          *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         } else {
           *reinterpret_cast<float4*>(crow + n) = v;
         }
