@@ -7,3 +7,4 @@ from .utils import (  # noqa: F401
     roll_out_serial,
 )
 from .io import latent_file_name, list_latent_files, load_latent_npy, save_latent_npy  # noqa: F401
+from .encode import encode_latents  # noqa: F401

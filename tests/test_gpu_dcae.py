@@ -185,3 +185,20 @@ def test_decode_latent_ens_and_error_conventions():
     with pytest.raises(NotImplementedError):
         g.encode(synth_field(2, 13, 48, 64).cuda())
     g.disable_slicing()
+
+
+def test_bulk_encoder_matches_frame_by_frame_oracle():
+    """SURVEY 8(f) rank 3 (preprocecss/encode_data.py:20-100): the reference encodes one frame per call; the batched
+    path must give the same latents, for a tensor and for a callable source, incl. a ragged last batch"""
+    from ladcast_amd.pipelines import encode_latents
+
+    o, g = _pair(tiny_dcae_config())
+    frames, st = synth_field(5, 8, 48, 64, seed=3), synth_field(1, 5, 48, 64, seed=1)[0]
+    with torch.no_grad():
+        want = torch.cat([o.encode(frames[i : i + 1], static_conditioning_tensor=st.unsqueeze(0)).latent for i in range(5)], dim=0)
+    got = encode_latents(g, frames, static_conditioning_tensor=st, batch_size=2)
+    assert got.device.type == "cpu" and got.shape == want.shape and rel_l2(got, want) < 2e-5
+    got2 = encode_latents(g, lambda i: frames[i], total_samples=5, static_conditioning_tensor=st, batch_size=4)
+    assert torch.equal(got, got2)  # the batch split does not change a frame's result
+    with pytest.raises(ValueError):
+        encode_latents(g, lambda i: frames[i], static_conditioning_tensor=st)
