@@ -38,6 +38,49 @@ CONFIGS = {
     ),  # configs/ladcast_375M.yaml:1-30
 }
 CONFIGS["1.6B"] = dict(CONFIGS["375M"], num_attention_heads=16, num_layers=5, num_single_layers=10, num_refiner_layers=3)
+CONFIG_DCAE_84 = dict(  # configs/DC_AE_84_pretrain.yaml:1-48
+    in_channels=89, out_channels=89, latent_channels=84, attention_head_dim=32,
+    encoder_block_types=("ResBlock", "ResBlock", "EfficientViTBlock", "EfficientViTBlock"),
+    decoder_block_types=("ResBlock", "ResBlock", "EfficientViTBlock", "EfficientViTBlock"),
+    encoder_block_out_channels=(252, 504, 504, 1008), decoder_block_out_channels=(252, 504, 504, 1008),
+    encoder_layers_per_block=(4, 4, 4, 4), decoder_layers_per_block=(4, 4, 4, 4),
+    encoder_qkv_multiscales=((), (), (5,), (5,)), decoder_qkv_multiscales=((), (), (5,), (5,)),
+    upsample_block_type="pixel_shuffle", downsample_block_type="pixel_unshuffle", static_channels=5,
+)
+
+
+def dcae_workload(args):
+    """`--workload dcae` (BASELINE configs[0] / the decode leg of configs[4]; not the headline): full-size DCAE encode +
+    decode of 240x120x84 frames on the MI355X (HIP, NHWC) for 1 / 8 / 32 frames, and -- cpu_baseline leg -- one frame with
+    the CPU oracle.  Prints one JSON object."""
+    from ladcast_amd.models import AutoencoderDC
+
+    torch.manual_seed(1234)
+    g = AutoencoderDC.from_config(CONFIG_DCAE_84).cuda().eval()
+    res = {"workload": "DCAE (DC_AE_84_pretrain) encode + decode, 84 x 120 x 240 frames + 5 static channels, fp32 MFMA, random-init seed 1234"}
+    for frames in (1, 8, 32):
+        x = torch.randn(frames, 84, 120, 240, device="cuda"); st = torch.randn(1, 5, 120, 240, device="cuda")
+        z = g.encode(x, static_conditioning_tensor=st).latent; g.decode(z); torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): z = g.encode(x, static_conditioning_tensor=st).latent
+        torch.cuda.synchronize(); te = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for _ in range(n): g.decode(z)
+        torch.cuda.synchronize(); td = (time.perf_counter() - t0) / n
+        res[f"gpu_{frames}"] = dict(encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2), encode_tflops=round(0.695 * frames / te, 1),
+                                    decode_tflops=round(0.7814 * frames / td, 1))
+    if args.cpu_forwards > 0:
+        from oracle.dcae import AutoencoderDC as OracleAE  # cpu_baseline leg only
+
+        o = OracleAE.from_config(CONFIG_DCAE_84).eval()
+        x = torch.randn(1, 84, 120, 240); st = torch.randn(1, 5, 120, 240)
+        with torch.no_grad():
+            o.encode(x, static_conditioning_tensor=st)
+            t0 = time.perf_counter(); z = o.encode(x, static_conditioning_tensor=st).latent; te = time.perf_counter() - t0
+            t0 = time.perf_counter(); o.decode(z); td = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(encode_ms=round(te * 1e3, 1), decode_ms=round(td * 1e3, 1), cores=torch.get_num_threads(), kind="port",
+                                   sample="1 frame by the PyTorch CPU oracle")
+    print(json.dumps(res))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is never used)
@@ -166,10 +209,14 @@ def main():
     ap.add_argument("--share-gpus", action="store_true", help="dry-run aid: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one captured hipGraph per model forward "
                     "(graph replay keeps the GPU fed regardless of host speed; kernels and numerics are identical)")
+    ap.add_argument("--workload", default="rollout", choices=["rollout", "dcae"], help="rollout = the headline (AR sampler chunk); dcae = DCAE "
+                    "encode / decode timing (BASELINE configs[0], secondary)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="token-stream GEMM arithmetic: exact fp32 MFMA, or split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate)")
     args = ap.parse_args()
 
+    if args.workload == "dcae":
+        return dcae_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -107,7 +107,7 @@ def test_tiny_sampler_chunk_matches_oracle(tiny_pair, sampler_type):
 
 def test_bf16x3_mode_stays_inside_the_parity_budget(tiny_pair):
     """split-bf16 GEMM mode: per-forward and per-chunk rel-L2 vs the fp32 CPU oracle.  Budget: 1e-4 (north star);
-    measured on CPU emulation: 4e-6 / 2e-6 (tools/split_precision_study.py)."""
+    measured on CPU emulation: 4e-6 / 2e-6 (tests/split_precision_study.py)."""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 

@@ -4,13 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ladcast_amd.evaluate as E
-from oracle import scoring as S
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 C, H, W, sst = 84, 120, 240, 68
 g = torch.Generator().manual_seed(0)
 dec = (torch.randn(M, C, H, W, generator=g) * 2).cuda(); ref = torch.randn(C, H, W, generator=g).cuda(); clim = torch.randn(C, H, W, generator=g).cuda()
-w = S.get_normalized_lat_weights_based_on_cos(torch.linspace(-89, 89, H)).cuda()
+w = E.get_normalized_lat_weights_based_on_cos(torch.linspace(-89, 89, H)).cuda()
 
 def timed(fn, n=20):
     for _ in range(3): fn()
@@ -18,13 +17,16 @@ def timed(fn, n=20):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n
 
-def torch_ops():  # the oracle's torch restatement, on the device
+def torch_ops():  # the same quantities as a sequence of torch ops on the device (what the reference driver issues)
     wv = w.view(1, -1, 1)
     mean_t = dec.mean(dim=0)
-    S.get_acc(mean_t, ref, clim, wv)
+    fa, ta = mean_t - clim, ref - clim
+    (fa * ta * wv).nanmean(dim=(-2, -1)) / torch.sqrt((fa**2 * wv).nanmean(dim=(-2, -1)) * (ta**2 * wv).nanmean(dim=(-2, -1)))
     ((mean_t - ref) ** 2 * wv).mean(dim=(1, 2))
-    sp = S.pointwise_crps_spread(dec, 0) * wv
-    sk = S.pointwise_crps_skill(dec, ref.unsqueeze(0), 0) * wv
+    srt, _ = torch.sort(dec, dim=0)
+    wts = (2 * torch.arange(1, M + 1, device=dec.device, dtype=dec.dtype) - M - 1).view(-1, 1, 1, 1)
+    sp = 2 * (srt * wts).sum(dim=0) / (M * (M - 1)) * wv
+    sk = torch.abs(ref.unsqueeze(0) - dec).mean(dim=0) * wv
     (sk - 0.5 * sp).mean(dim=(1, 2)); sp.mean(dim=(1, 2)); sk.mean(dim=(1, 2))
 
 t_hip = timed(lambda: E.ensemble_scores(dec, ref, clim, w, sst))
