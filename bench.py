@@ -58,17 +58,19 @@ def dcae_workload(args):
     torch.manual_seed(1234)
     g = AutoencoderDC.from_config(CONFIG_DCAE_84).cuda().eval()
     res = {"workload": "DCAE (DC_AE_84_pretrain) encode + decode, 84 x 120 x 240 frames + 5 static channels, fp32 MFMA, random-init seed 1234"}
-    for frames in (1, 8, 32):
-        x = torch.randn(frames, 84, 120, 240, device="cuda"); st = torch.randn(1, 5, 120, 240, device="cuda")
-        z = g.encode(x, static_conditioning_tensor=st).latent; g.decode(z); torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 3
-        for _ in range(n): z = g.encode(x, static_conditioning_tensor=st).latent
-        torch.cuda.synchronize(); te = (time.perf_counter() - t0) / n
-        t0 = time.perf_counter()
-        for _ in range(n): g.decode(z)
-        torch.cuda.synchronize(); td = (time.perf_counter() - t0) / n
-        res[f"gpu_{frames}"] = dict(encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2), encode_tflops=round(0.695 * frames / te, 1),
-                                    decode_tflops=round(0.7814 * frames / td, 1))
+    for prec in ("fp32", "bf16x3"):  # bf16x3: the dense 3x3 convs as split-bf16 implicit GEMMs (AutoencoderDC.set_gemm_precision)
+        g.set_gemm_precision(prec)
+        for frames in (1, 4, 8, 32):
+            x = torch.randn(frames, 84, 120, 240, device="cuda"); st = torch.randn(1, 5, 120, 240, device="cuda")
+            z = g.encode(x, static_conditioning_tensor=st).latent; g.decode(z); torch.cuda.synchronize()
+            t0 = time.perf_counter(); n = 3
+            for _ in range(n): z = g.encode(x, static_conditioning_tensor=st).latent
+            torch.cuda.synchronize(); te = (time.perf_counter() - t0) / n
+            t0 = time.perf_counter()
+            for _ in range(n): g.decode(z)
+            torch.cuda.synchronize(); td = (time.perf_counter() - t0) / n
+            res[f"gpu_{prec}_{frames}"] = dict(encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2), encode_tflops=round(0.695 * frames / te, 1),
+                                               decode_tflops=round(0.7814 * frames / td, 1))
     if args.cpu_forwards > 0:
         from oracle.dcae import AutoencoderDC as OracleAE  # cpu_baseline leg only
 

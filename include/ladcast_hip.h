@@ -266,6 +266,13 @@ int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B,
  * or repeat_interleave (cin < cout; decoder in shortcut, :720-722). */
 int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, void* stream);
 
+/* Split-bf16 form of ldc_sphere_conv_nhwc (dense SphereConv2d, same contract): Wp is ldc_pack_weight_bf16x2 of the
+ * tap-major weight [cout][k*k][cin_p], cin_p = 32 * 2^j >= cin with zeros behind cin; runs on the LDS-DMA stream-K
+ * kernel (pole mirror / roll / wrap are per-lane DMA source addresses).  workspace: as ldc_gemm_grouped. */
+int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B,
+                                int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act,
+                                void* workspace, long long workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Ensemble scoring of one lead time of a decoded forecast:
  *   forecast [M members][C][H*W] with member / channel strides in elements (the H*W plane contiguous), so a

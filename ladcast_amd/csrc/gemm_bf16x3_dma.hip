@@ -63,6 +63,11 @@ struct DevProblem {
   long long tile0;
   int vec4;     // epilogue may use 16-byte accesses
   int c_split;  // LDC_GEMM_C_SPLIT
+  // implicit-GEMM SphereConv2d (CONV instantiation): A is an NHWC image [B][cH][cW][lda], M = B*cH*cW; the reduction
+  // runs over ks*ks taps x (cin rounded up to 32 << kshift ... i.e. 2^kshift k-steps per tap); W is packed with the
+  // same per-tap padding (zero weights behind cin)
+  int cH, cW, cin, ks, kshift;
+  const unsigned char* zero16;  // 16 zero bytes (for the lanes of a tap's last k-step that lie behind cin)
 };
 
 struct SKArgs {
@@ -216,7 +221,28 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_w
 #define LDC_STAMP_CLK(i)
 #endif
 
-template <int BM, bool APK>
+// Source pixel of tap (ky, kx) for output pixel (h, w) under SphereConv2d's padding and pole rule
+// (models/sphere_conv.py:62-129,174-192; same index arithmetic as gemm_f32.hip): rows beyond a pole are the first /
+// last p rows mirrored and rolled by W/2, columns wrap, and output row 0 (H-1) sees the first (last) p kernel rows
+// flipped horizontally = the mirrored column with the unflipped weight.
+__device__ __forceinline__ int sphere_src_pixel(int h, int w, int ky, int kx, int H, int W, int ks) {
+  const int p = ks >> 1;
+  if ((h == 0 && ky < p) || (h == H - 1 && ky >= ks - p)) kx = ks - 1 - kx;
+  int r = h + ky - p;
+  int c = w + kx - p;
+  if (r < 0) {
+    r = -1 - r;
+    c -= W >> 1;
+  } else if (r >= H) {
+    r = 2 * H - 1 - r;
+    c -= W >> 1;
+  }
+  c %= W;
+  if (c < 0) c += W;
+  return r * W + c;
+}
+
+template <int BM, bool APK, bool CONV = false>
 __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
   constexpr int NW = BM / 32;                  // waves per workgroup, 8(M) x 1(N) or 4(M) x 1(N)
   constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
@@ -270,6 +296,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
     // W instruction q (0..15) covers tile rows [8q, 8q+8); this wave issues q = wave + NW i, i = 0..NWI-1
     const unsigned char* a_src[4];
     const unsigned char* w_src[NWI];
+    int pix_b[4], pix_h[4], pix_w[4], a_chan[4];  // CONV: image base pixel, (h, w) and first channel (4 c) of this lane's chunk
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 8 * (wave + NW * i) + lr;
@@ -280,7 +307,28 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
 #endif
       gm = gm < M ? gm : M - 1;
       const int c = lp ^ ((r >> 1) & 7);
-      a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + c * 16;
+      if constexpr (CONV) {
+        const int hw = P.cH * P.cW;
+        const int bimg = gm / hw;
+        const int rem = gm - bimg * hw;
+        pix_b[i] = bimg * hw;
+        pix_h[i] = rem / P.cW;
+        pix_w[i] = rem - pix_h[i] * P.cW;
+        a_chan[i] = 4 * c;
+        a_src[i] = nullptr;  // per tap, below
+      } else {
+        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + c * 16;
+      }
+    }
+    // CONV: source of this lane's chunk for tap `tap`: pixel under the sphere padding rule, channel a_chan
+    auto conv_tap_base = [&](int i, int tap) {
+      const int ky = tap / P.ks, kx = tap - ky * P.ks;
+      const int src = pix_b[i] + sphere_src_pixel(pix_h[i], pix_w[i], ky, kx, P.cH, P.cW, P.ks);
+      return reinterpret_cast<const unsigned char*>(A + static_cast<long long>(src) * lda + a_chan[i]);
+    };
+    if constexpr (CONV) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_src[i] = conv_tap_base(i, k0 >> P.kshift);
     }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -304,8 +352,23 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_kernel(SKArgs a) {
 #ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
       if (kt >= 0) return;
 #endif
-      if (i < 4) dma16(a_src[i] + koff, sA + (wave + NW * i) * 1024);
-      else dma16(w_src[i - 4] + koff, sW + (wave + NW * (i - 4)) * 1024);
+      if (i < 4) {
+        if constexpr (CONV) {
+          // 2^kshift k-steps per tap: k-step kt = (tap, 32-channel chunk).  Piece i is issued once per k-step in
+          // increasing kt, so its per-tap base is recomputed exactly when a tap starts (wave-uniform branch).
+          const int chunk = kt & ((1 << P.kshift) - 1);
+          if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
+          const unsigned char* src = a_src[i] + chunk * (BK * 4);
+          if (chunk * BK + BK > P.cin) {  // the tap's last k-step: lanes behind cin read zeros (their weights are zero too)
+            if (chunk * BK + a_chan[i] >= P.cin) src = P.zero16;
+          }
+          dma16(src, sA + (wave + NW * i) * 1024);
+        } else {
+          dma16(a_src[i] + koff, sA + (wave + NW * i) * 1024);
+        }
+      } else {
+        dma16(w_src[i - 4] + koff, sW + (wave + NW * (i - 4)) * 1024);
+      }
     };
     auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -666,8 +729,13 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16x3_dma_fixup_kernel(SKArgs a)
 // returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back)
 namespace {
 
-template <int BM, bool APK>
-int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+struct ConvParams {
+  int H, W, cin, ks, kshift;
+};
+
+template <int BM, bool APK, bool CONV = false>
+int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream,
+               const ConvParams* cp = nullptr) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
   constexpr int CUS = 256;  // one workgroup per CU
@@ -708,6 +776,11 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
       if ((d.flags & LDC_GEMM_A_SPLIT) && ((d.lda % 8) || (d.a_bs % 8) || (reinterpret_cast<unsigned long long>(q.A) & 31ull)))
         return LDC_ERR_ALIGN;
       if (((d.flags & LDC_GEMM_A_SPLIT) != 0) != APK) return LDC_ERR_UNSUPPORTED;  // one activation format per launch
+    }
+    if constexpr (CONV) {
+      P.cH = cp->H; P.cW = cp->W; P.cin = cp->cin; P.ks = cp->ks; P.kshift = cp->kshift;
+      // 16 zero bytes: the tail of the counter block (zeroed by ldc_gemm_grouped_workspace_init, written by nobody)
+      P.zero16 = static_cast<const unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES - 64;
     }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
@@ -763,16 +836,16 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
   a.U = U;
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
-  a.counters = (tiles <= LDC_GEMM_COUNTER_BYTES / 4) ? static_cast<unsigned*>(workspace) : nullptr;
+  a.counters = (tiles <= LDC_GEMM_COUNTER_BYTES / 4 - 16) ? static_cast<unsigned*>(workspace) : nullptr;  // last 64 B: zero page
   const size_t lds = NSTAGE * STAGE_B;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM, APK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM, APK, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     attr_set = true;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<BM, APK>), dim3(a.G), dim3(BM * 2), lds, s, a);
+  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<BM, APK, CONV>), dim3(a.G), dim3(BM * 2), lds, s, a);
   int st = ldc_launch_status();
   if (st != LDC_OK || a.counters != nullptr) return st;
   hipLaunchKernelGGL(gemm_bf16x3_dma_fixup_kernel<BM>, dim3(static_cast<unsigned>(tiles)), dim3(BM * 2), 0, s, a);
@@ -802,4 +875,42 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
                  : launch_dma<256, true>(problems, n, workspace, workspace_bytes, stream);
   return small ? launch_dma<128, false>(problems, n, workspace, workspace_bytes, stream)
                : launch_dma<256, false>(problems, n, workspace, workspace_bytes, stream);
+}
+
+// SphereConv2d (dense, stride 1, k = 3 / 5) as an implicit GEMM on the split-bf16 kernel: X is NHWC fp32 [B*H*W][ldx],
+// Wp = ldc_pack_weight_bf16x2 of the [cout][k*k][cin rounded up to 32 * 2^j] tap-major weight (zero behind cin).
+extern "C" int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B,
+                                           int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act,
+                                           void* workspace, long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(X);
+  LDC_CHECK_PTR(Wp);
+  LDC_CHECK_PTR(Y);
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
+  if (ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
+  if ((W & 1) || H < 2 || H < ksize / 2) return LDC_ERR_UNSUPPORTED;  // reference asserts even width
+  if ((cin & 3) || (ldx & 3) || ldx < cin || ldy < cout) return LDC_ERR_ALIGN;
+  const long long M = static_cast<long long>(B) * H * W;
+  if (M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  ConvParams cp{H, W, cin, ksize, 0};
+  int ktpt = ldc_cdiv(cin, BK);  // k-steps per tap, rounded up to a power of two (the kernel shifts instead of dividing)
+  while ((1 << cp.kshift) < ktpt) ++cp.kshift;
+  ktpt = 1 << cp.kshift;
+  ldc_gemm_problem q{};
+  q.A = X;
+  q.W = static_cast<const float*>(Wp);
+  q.bias = bias;
+  q.R = R;
+  q.C = Y;
+  q.d.M = static_cast<int>(M);
+  q.d.N = cout;
+  q.d.K = ksize * ksize * ktpt * BK;
+  q.d.batch = 1;
+  q.d.lda = ldx;
+  q.d.ldw = q.d.K;
+  q.d.ldc = ldy;
+  q.d.ldr = ldr;
+  q.d.act = act;
+  const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
+  return tiles256 <= 128 ? launch_dma<128, false, true>(&q, 1, workspace, workspace_bytes, stream, &cp)
+                         : launch_dma<256, false, true>(&q, 1, workspace, workspace_bytes, stream, &cp);
 }

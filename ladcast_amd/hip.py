@@ -61,6 +61,7 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
+        "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
         "ldc_ensemble_scores": (I, [P, L, L, P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P]),
         "ldc_attn_packed_bytes": (L, [I, I, I]),
@@ -328,6 +329,24 @@ def sphere_conv_nhwc(X, Wt, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=N
     _dev(X, Wt, Y, bias, R)
     _check(lib.ldc_sphere_conv_nhwc(_p(X), _p(Wt), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx if ldx is not None else cin, cout,
                                     ldy if ldy is not None else cout, ldr, ksize, act, _stream()), "ldc_sphere_conv_nhwc")
+
+
+def conv_cin_padded(cin):
+    """channels per tap of a packed split-bf16 conv weight: 32 * 2^j >= cin"""
+    kt = -(-cin // 32)
+    p2 = 1
+    while p2 < kt:
+        p2 *= 2
+    return 32 * p2
+
+
+def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE):
+    """Wp: pack_weight_bf16x2 of the [cout, k*k*conv_cin_padded(cin)] tap-major weight (zeros behind cin)"""
+    _dev(X, Wp, Y, bias, R)
+    ws = _grouped_workspace(X.device)
+    _check(lib.ldc_sphere_conv_nhwc_bf16x3(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx if ldx is not None else cin, cout,
+                                           ldy if ldy is not None else cout, ldr, ksize, act, _p(ws), ws.numel() * 4, _stream()),
+           "ldc_sphere_conv_nhwc_bf16x3")
 
 
 def sphere_dwconv_nhwc(x, wt, y, *, B, H, W, C, ldx=None, ldy=None, bias=None, ksize=3, glu=False):

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import hip
 from .modeling_utils import ModelMixin
-from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_depthwise_weight
+from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_dense_weight_bf16x3, pack_depthwise_weight
 
 
 class EncoderOutput(SimpleNamespace):
@@ -202,6 +202,18 @@ class AutoencoderDC(ModelMixin):
         self.static_channels = static_channels
         self.requires_grad_(False)
         self._plan = None
+        self.gemm_precision = "fp32"
+
+    def set_gemm_precision(self, precision: str):
+        """'fp32' (default): every conv on the exact-fp32 matrix cores; 'bf16x3': the dense 3x3 SphereConv2d layers
+        (75 % of the FLOPs) as split-bf16 implicit GEMMs (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~4e-6 per layer) --
+        1x1 convs, depthwise convs, norms and the linear attention stay fp32."""
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("gemm precision must be 'fp32' or 'bf16x3'")
+        if precision != self.gemm_precision:
+            self.gemm_precision = precision
+            self._plan = None
+        return self
 
     def enable_tiling(self, *a, **k):
         self.use_tiling = True
@@ -230,9 +242,14 @@ class AutoencoderDC(ModelMixin):
         if not next(self.parameters()).is_cuda:
             raise RuntimeError("AutoencoderDC must live on a HIP device (no CPU fallback)")
         plan = {}
+        split = self.gemm_precision == "bf16x3"
         for mod in self.modules():
             if isinstance(mod, SphereConv2d):
-                plan[id(mod)] = pack_dense_weight(mod.weight) if mod.groups == 1 else pack_depthwise_weight(mod.weight)
+                if mod.groups == 1:
+                    k3 = mod.kernel_size[0] == 3
+                    plan[id(mod)] = pack_dense_weight_bf16x3(mod.weight) if (split and k3) else pack_dense_weight(mod.weight)
+                else:
+                    plan[id(mod)] = pack_depthwise_weight(mod.weight)
             elif isinstance(mod, nn.Conv2d):  # 1x1 convs
                 plan[id(mod)] = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
             elif isinstance(mod, SanaMultiscaleLinearAttention):
@@ -243,8 +260,9 @@ class AutoencoderDC(ModelMixin):
     def _conv(self, x, B, H, W, conv, act=hip.ACT_NONE, R=None, ldx=None):
         cin_p = ceil4(conv.in_channels)
         y = torch.empty(B * H * W, conv.out_channels, device=x.device, dtype=torch.float32)
-        hip.sphere_conv_nhwc(x, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=ldx if ldx is not None else cin_p,
-                             cout=conv.out_channels, bias=conv.bias, R=R, ldr=conv.out_channels if R is not None else 0, ksize=3, act=act)
+        fn = hip.sphere_conv_nhwc_bf16x3 if self.gemm_precision == "bf16x3" else hip.sphere_conv_nhwc
+        fn(x, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=ldx if ldx is not None else cin_p,
+           cout=conv.out_channels, bias=conv.bias, R=R, ldr=conv.out_channels if R is not None else 0, ksize=3, act=act)
         return y
 
     def _resblock(self, blk, x, B, H, W):

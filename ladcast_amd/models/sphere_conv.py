@@ -26,6 +26,16 @@ def pack_dense_weight(w: torch.Tensor) -> torch.Tensor:
     return out.reshape(co, k * k * cp).contiguous()
 
 
+def pack_dense_weight_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, k, k] -> split-bf16 packed weight of the tap-major [Cout, k*k*Cin_pp] matrix, Cin_pp = 32 * 2^j >= Cin
+    with zeros behind Cin (ldc_sphere_conv_nhwc_bf16x3)."""
+    co, ci, k, _ = w.shape
+    cpp = hip.conv_cin_padded(ci)
+    out = torch.zeros(co, k * k, cpp, device=w.device, dtype=torch.float32)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, k * k, ci)
+    return hip.pack_weight_bf16x2(out.reshape(co, k * k * cpp))
+
+
 def pack_depthwise_weight(w: torch.Tensor) -> torch.Tensor:
     """[C, 1, k, k] -> [k*k, C]"""
     c, _, k, _ = w.shape

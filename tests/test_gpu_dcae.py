@@ -202,3 +202,62 @@ def test_bulk_encoder_matches_frame_by_frame_oracle():
     assert torch.equal(got, got2)  # the batch split does not change a frame's result
     with pytest.raises(ValueError):
         encode_latents(g, lambda i: frames[i], static_conditioning_tensor=st)
+
+
+@pytest.mark.parametrize("ci,co,k,B,H,W", [(8, 8, 3, 2, 9, 16), (252, 252, 3, 1, 30, 60), (92, 252, 3, 1, 12, 24), (504, 252, 3, 2, 15, 30),
+                                            (12, 20, 5, 1, 7, 12), (1008, 1008, 3, 1, 15, 30), (252, 252, 3, 1, 120, 240)])
+def test_sphere_conv_bf16x3_vs_oracle(ci, co, k, B, H, W):
+    """split-bf16 implicit-GEMM SphereConv2d (ldc_sphere_conv_nhwc_bf16x3): pole rows, wrap, channel counts that are not
+    a multiple of 32 (zero-padded taps), bias + residual + activation epilogue; 1e-5 like the bf16x3 GEMM"""
+    import ladcast_amd.hip as hip
+    from ladcast_amd.models.sphere_conv import ceil4, pack_dense_weight_bf16x3
+    from oracle.sphere_conv import SphereConv2d as OSC
+
+    o = OSC(ci, co, k, 1, k // 2, bias=True)
+    with torch.no_grad():
+        o.weight.copy_(rnd(*o.weight.shape, seed=1) / (ci * k * k) ** 0.5)
+        o.bias.copy_(rnd(co, seed=2))
+    x, res = rnd(B, ci, H, W, seed=3), rnd(B, co, H, W, seed=4)
+    with torch.no_grad():
+        want = torch.nn.functional.silu(o(x)) + res
+    cp = ceil4(ci)
+    tok = torch.zeros(B * H * W, cp, device="cuda")
+    tok[:, :ci] = x.cuda().permute(0, 2, 3, 1).reshape(B * H * W, ci)
+    r = res.cuda().permute(0, 2, 3, 1).reshape(B * H * W, co).contiguous()
+    y = torch.full((B * H * W, co), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_bf16x3(tok, pack_dense_weight_bf16x3(o.weight.cuda()), y, B=B, H=H, W=W, cin=cp, cout=co, bias=o.bias.cuda(), R=r, ldr=co,
+                                ksize=k, act=hip.ACT_SILU)
+    got = y.reshape(B, H, W, co).permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 1e-5
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 1e-5 and rel_l2(got[:, :, -1], want[:, :, -1]) < 1e-5  # pole rows
+
+
+def test_dcae_bf16x3_mode_matches_oracle():
+    """AutoencoderDC.set_gemm_precision('bf16x3'): dense 3x3 convs as split-bf16 implicit GEMMs; tiny config (both paths of
+    the encoder / decoder) and one full 84 x 120 x 240 frame; tolerance 5e-5 (~40 conv layers at ~4e-6 each, fp32 budget 1e-4)"""
+    o, g = _pair(tiny_dcae_config())
+    g.set_gemm_precision("bf16x3")
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        yo = o.decode(zo).sample
+    zg = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+    yg = g.decode(zo.cuda()).sample
+    assert rel_l2(zg.cpu(), zo) < 5e-5 and rel_l2(yg.cpu(), yo) < 5e-5
+    g.set_gemm_precision("fp32")
+    assert rel_l2(g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent.cpu(), zo) < 2e-5  # switching back re-packs
+
+
+def test_full_dcae_bf16x3_single_frame_matches_oracle():
+    from oracle.dcae import CONFIG_DCAE_84
+
+    o, g = _pair(CONFIG_DCAE_84)
+    g.set_gemm_precision("bf16x3")
+    f, st = synth_field(1, 84, 120, 240), synth_field(1, 5, 120, 240, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st).latent
+        yo = o.decode(zo).sample
+    zg = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+    yg = g.decode(zo.cuda()).sample
+    assert rel_l2(zg.cpu(), zo) < 5e-5 and rel_l2(yg.cpu(), yo) < 5e-5
