@@ -250,7 +250,10 @@ int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* y, long lon
 /* ReLU linear attention over consecutive 96-channel groups (q|k|v = 32|32|32) of qkv[B][P][ldq];
  * y[B][P][groups*32] (models/DCAE.py:158-175,239-253; fp32, eps 1e-15). */
 int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
-                              void* stream);
+                              void* workspace, long long workspace_bytes, void* stream);
+/* workspace: ldc_relu_linear_attn_workspace_bytes(B, P, groups) bytes of device scratch (partial KV sums of the pixel
+ * slices: one frame has only ~63 groups, so the KV pass is cut along the pixels to fill the chip). */
+long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups);
 /* y = act(RMSNorm_C(x) * w + b (+ resid)) per pixel row (models/DCAE.py:259-260,317-322,371-377,729-730). */
 int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y, long long rows,
                      int C, int ldx, int ldr, int ldy, float eps, int act, void* stream);
@@ -268,7 +271,8 @@ int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, v
 
 /* Split-bf16 form of ldc_sphere_conv_nhwc (dense SphereConv2d, same contract): Wp is ldc_pack_weight_bf16x2 of the
  * tap-major weight [cout][k*k][cin_p], cin_p = 32 * 2^j >= cin with zeros behind cin; runs on the LDS-DMA stream-K
- * kernel (pole mirror / roll / wrap are per-lane DMA source addresses).  workspace: as ldc_gemm_grouped. */
+ * kernel (pole mirror / roll / wrap are per-lane DMA source addresses).  ksize = 1 is the pointwise conv / Linear for
+ * any cin % 4 == 0 (K need not be a multiple of 32: the padding lanes read a zero page).  workspace: as ldc_gemm_grouped. */
 int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B,
                                 int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act,
                                 void* workspace, long long workspace_bytes, void* stream);

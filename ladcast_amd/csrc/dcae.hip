@@ -91,28 +91,33 @@ __global__ __launch_bounds__(256) void grouped_conv1x1_kernel(const float* __res
 // ReLU linear attention of one (batch, 96-channel group): q = ch 0..31, k = 32..63, v = 64..95
 //   KV[c][j] = sum_p vpad[p][c] relu(k[p][j]), c = 0..32 (row 32 = ones);  out[p][c] = sum_j KV[c][j] relu(q[p][j])
 //   y[p][c] = out[p][c] / (out[p][32] + eps)                 (models/DCAE.py:158-175,239-249; fp32)
-__global__ __launch_bounds__(256) void relu_linear_attn_kernel(const float* __restrict__ qkv, float* __restrict__ y, int P,
-                                                               int ldq, int ldy, float eps) {
+// Two launches so that one frame (63 groups) still fills the chip: (1) partial KV over a slice of the pixels per
+// workgroup, (2) per 64 pixels: add the slices' partials in order (deterministic) and apply.
+constexpr int KV_N = 33 * 32;
+
+__global__ __launch_bounds__(256) void relu_linear_attn_kv_kernel(const float* __restrict__ qkv, float* __restrict__ part, int P,
+                                                                  int ldq, int pix_per_wg) {
   __shared__ float tile[64][97];  // 64 pixels x 96 channels (+1 pad)
-  __shared__ float kv[33][32];
-  const int g = blockIdx.x, b = blockIdx.y;
+  const int sl = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x;
   const float* base = qkv + static_cast<long long>(b) * P * ldq + g * 96;
+  const int p_begin = sl * pix_per_wg;
+  const int p_end = min(P, p_begin + pix_per_wg);
   // each thread owns up to 5 (c, j) entries of KV: e = t + 256*i < 1056
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int p0 = 0; p0 < P; p0 += 64) {
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
     for (int i = t; i < 64 * 96; i += 256) {
       const int pp = i / 96, ch = i - pp * 96;
-      float v = (p0 + pp < P) ? base[static_cast<long long>(p0 + pp) * ldq + ch] : 0.f;
+      float v = (p0 + pp < p_end) ? base[static_cast<long long>(p0 + pp) * ldq + ch] : 0.f;
       if (ch >= 32 && ch < 64) v = fmaxf(v, 0.f);  // relu(k)
       tile[pp][ch] = v;
     }
     __syncthreads();
-    const int np = min(64, P - p0);
+    const int np = min(64, p_end - p0);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int e = t + 256 * i;
-      if (e < 33 * 32) {
+      if (e < KV_N) {
         const int c = e >> 5, j = e & 31;
         float s = acc[i];
         if (c < 32) {
@@ -125,40 +130,60 @@ __global__ __launch_bounds__(256) void relu_linear_attn_kernel(const float* __re
     }
     __syncthreads();
   }
+  float* dst = part + ((static_cast<long long>(b) * gridDim.y + g) * gridDim.x + sl) * KV_N;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int e = t + 256 * i;
-    if (e < 33 * 32) kv[e >> 5][e & 31] = acc[i];
+    if (e < KV_N) dst[e] = acc[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ part,
+                                                                     float* __restrict__ y, int P, int ldq, int ldy, float eps,
+                                                                     int nslice) {
+  __shared__ float kv[33][32];
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int t = threadIdx.x;
+  const float* src = part + (static_cast<long long>(b) * gridDim.y + g) * nslice * KV_N;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int e = t + 256 * i;
+    if (e < KV_N) {
+      float s = 0.f;
+      for (int sl = 0; sl < nslice; ++sl) s += src[static_cast<long long>(sl) * KV_N + e];
+      kv[e >> 5][e & 31] = s;
+    }
   }
   __syncthreads();
-  float* yb = y + static_cast<long long>(b) * P * ldy + g * 32;
-  for (int p = t; p < P; p += 256) {
-    float q[32];
-    const float* qp = base + static_cast<long long>(p) * ldq;
+  // 64 pixels per workgroup, 4 threads per pixel: thread (pixel, quarter) writes channels [8 quarter, 8 quarter + 8)
+  const int p = blockIdx.x * 64 + (t >> 2), qt = t & 3;
+  if (p >= P) return;
+  const float* qp = qkv + static_cast<long long>(b) * P * ldq + g * 96 + static_cast<long long>(p) * ldq;
+  float q[32];
 #pragma unroll
-    for (int j = 0; j < 32; j += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(qp + j);
-      q[j] = fmaxf(v.x, 0.f);
-      q[j + 1] = fmaxf(v.y, 0.f);
-      q[j + 2] = fmaxf(v.z, 0.f);
-      q[j + 3] = fmaxf(v.w, 0.f);
+  for (int j = 0; j < 32; j += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(qp + j);
+    q[j] = fmaxf(v.x, 0.f);
+    q[j + 1] = fmaxf(v.y, 0.f);
+    q[j + 2] = fmaxf(v.z, 0.f);
+    q[j + 3] = fmaxf(v.w, 0.f);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) den = fmaf(kv[32][j], q[j], den);
+  const float inv = 1.0f / (den + eps);
+  float* yp = y + static_cast<long long>(b) * P * ldy + g * 32 + static_cast<long long>(p) * ldy + 8 * qt;
+#pragma unroll
+  for (int c = 0; c < 8; c += 4) {
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s = fmaf(kv[8 * qt + c + u][j], q[j], s);
+      o[u] = s * inv;
     }
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) den = fmaf(kv[32][j], q[j], den);
-    const float inv = 1.0f / (den + eps);
-    float* yp = yb + static_cast<long long>(p) * ldy;
-    for (int c = 0; c < 32; c += 4) {
-      float o[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) s = fmaf(kv[c + u][j], q[j], s);
-        o[u] = s * inv;
-      }
-      *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
-    }
+    *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -308,16 +333,40 @@ extern "C" int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* 
   return ldc_launch_status();
 }
 
+// pixel slices per (batch, group) of the KV pass: enough workgroups to fill the chip, at most one per 64 pixels
+static int relu_attn_slices(int B, int P, int groups) {
+  const int tiles = ldc_cdiv(P, 64);
+  long long want = 2048 / (static_cast<long long>(B) * groups);
+  if (want < 1) want = 1;
+  return static_cast<int>(want < tiles ? want : tiles);
+}
+
+extern "C" long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups) {
+  if (B <= 0 || P <= 0 || groups <= 0) return 0;
+  return static_cast<long long>(B) * groups * relu_attn_slices(B, P, groups) * KV_N * static_cast<long long>(sizeof(float));
+}
+
 extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
-                                         void* stream) {
+                                         void* workspace, long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(qkv);
   LDC_CHECK_PTR(y);
+  LDC_CHECK_PTR(workspace);
   if (B <= 0 || P <= 0 || groups <= 0) return LDC_ERR_ARG;
   if ((ldq & 3) || (ldy & 3)) return LDC_ERR_ALIGN;
+  if (groups > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
-  dim3 grid(groups, B);
-  hipLaunchKernelGGL(relu_linear_attn_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), qkv, y, P, ldq, ldy, eps);
+  if (workspace_bytes < ldc_relu_linear_attn_workspace_bytes(B, P, groups)) return LDC_ERR_ARG;
+  const int nslice = relu_attn_slices(B, P, groups);
+  const int pix_per_wg = ldc_cdiv(ldc_cdiv(P, 64), nslice) * 64;
+  const int nsl = ldc_cdiv(P, pix_per_wg);  // <= nslice; the apply pass adds exactly the slices that were written
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(relu_linear_attn_kv_kernel, dim3(nsl, groups, B), dim3(256), 0, s, qkv, part, P, ldq, pix_per_wg);
+  int st = ldc_launch_status();
+  if (st != LDC_OK) return st;
+  hipLaunchKernelGGL(relu_linear_attn_apply_kernel, dim3(ldc_cdiv(P, 64), groups, B), dim3(256), 0, s, qkv, part, y, P, ldq, ldy, eps,
+                     nsl);
   return ldc_launch_status();
 }
 

@@ -886,8 +886,8 @@ extern "C" int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const
   LDC_CHECK_PTR(Wp);
   LDC_CHECK_PTR(Y);
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
-  if (ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
-  if ((W & 1) || H < 2 || H < ksize / 2) return LDC_ERR_UNSUPPORTED;  // reference asserts even width
+  if (ksize != 1 && ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;  // 1 = pointwise conv / Linear with any cin % 4 == 0
+  if (ksize > 1 && ((W & 1) || H < 2 || H < ksize / 2)) return LDC_ERR_UNSUPPORTED;  // reference asserts even width
   if ((cin & 3) || (ldx & 3) || ldx < cin || ldy < cout) return LDC_ERR_ALIGN;
   const long long M = static_cast<long long>(B) * H * W;
   if (M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;

@@ -86,7 +86,8 @@ def _load():
         "ldc_sphere_conv_nhwc": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
         "ldc_sphere_dwconv_nhwc": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
         "ldc_grouped_conv1x1_nhwc": (I, [P, P, P, L, I, I, I, P]),
-        "ldc_relu_linear_attn_nhwc": (I, [P, P, I, I, I, I, I, F, P]),
+        "ldc_relu_linear_attn_nhwc": (I, [P, P, I, I, I, I, I, F, P, L, P]),
+        "ldc_relu_linear_attn_workspace_bytes": (L, [I, I, I]),
         "ldc_rmsnorm_rows": (I, [P, P, P, P, P, L, I, I, I, I, F, I, P]),
         "ldc_pixel_unshuffle_shortcut": (I, [P, P, P, I, I, I, I, I, P]),
         "ldc_pixel_shuffle_shortcut": (I, [P, P, P, I, I, I, I, I, P]),
@@ -361,9 +362,18 @@ def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
     _check(lib.ldc_grouped_conv1x1_nhwc(_p(x), _p(wt), _p(y), M, groups, ldx, ldy, _stream()), "ldc_grouped_conv1x1_nhwc")
 
 
+_rla_ws = {}
+
+
 def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
     _dev(qkv, y)
-    _check(lib.ldc_relu_linear_attn_nhwc(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, _stream()), "ldc_relu_linear_attn_nhwc")
+    need = int(lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups))
+    key = (str(qkv.device), torch.cuda.current_stream(qkv.device).cuda_stream)
+    if key not in _rla_ws or _rla_ws[key].numel() * 4 < need:
+        _rla_ws[key] = torch.empty(need // 4 + 1, device=qkv.device, dtype=torch.float32)
+    ws = _rla_ws[key]
+    _check(lib.ldc_relu_linear_attn_nhwc(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, _p(ws), ws.numel() * 4, _stream()),
+           "ldc_relu_linear_attn_nhwc")
 
 
 def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE):

@@ -251,9 +251,13 @@ class AutoencoderDC(ModelMixin):
                 else:
                     plan[id(mod)] = pack_depthwise_weight(mod.weight)
             elif isinstance(mod, nn.Conv2d):  # 1x1 convs
-                plan[id(mod)] = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
+                w = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
+                plan[id(mod)] = pack_dense_weight_bf16x3(w[:, :, None, None]) if (split and mod.groups == 1) else w
             elif isinstance(mod, SanaMultiscaleLinearAttention):
-                plan[id(mod)] = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], dim=0).contiguous()
+                w = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], dim=0).contiguous()
+                plan[id(mod)] = pack_dense_weight_bf16x3(w[:, :, None, None]) if split else w
+                if split:
+                    plan[id(mod.to_out)] = pack_dense_weight_bf16x3(mod.to_out.weight[:, :, None, None])
         self._plan = plan
 
     # -- NHWC building blocks ---------------------------------------------------------------------
@@ -264,6 +268,14 @@ class AutoencoderDC(ModelMixin):
         fn(x, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=ldx if ldx is not None else cin_p,
            cout=conv.out_channels, bias=conv.bias, R=R, ldr=conv.out_channels if R is not None else 0, ksize=3, act=act)
         return y
+
+    def _mm(self, x, key, w_fp32, y, B, H, W, N, K, ldc=None, bias=None, act=hip.ACT_NONE):
+        """pointwise conv / Linear over the B*H*W pixel rows: exact-fp32 GEMM, or (bf16x3 mode) the split-bf16 kernel as
+        a 1x1 conv (any K % 4 == 0)"""
+        if self.gemm_precision == "bf16x3":
+            hip.sphere_conv_nhwc_bf16x3(x, self._plan[key], y, B=B, H=H, W=W, cin=K, cout=N, ldy=ldc, bias=bias, ksize=1, act=act)
+        else:
+            hip.gemm(x, w_fp32, y, M=B * H * W, N=N, K=K, ldc=ldc, bias=bias, act=act)
 
     def _resblock(self, blk, x, B, H, W):
         t = self._conv(x, B, H, W, blk.conv1, act=blk.act)
@@ -281,7 +293,7 @@ class AutoencoderDC(ModelMixin):
         n_ms = len(at.to_qkv_multiscale)
         wide = 3 * inner * (1 + n_ms)
         qkv = torch.empty(M, wide, device=dev, dtype=torch.float32)
-        hip.gemm(x, self._plan[id(at)], qkv, M=M, N=3 * inner, K=C, ldc=wide)
+        self._mm(x, id(at), self._plan[id(at)], qkv, B, H, W, N=3 * inner, K=C, ldc=wide)
         for s, ms in enumerate(at.to_qkv_multiscale):
             dw = torch.empty(M, 3 * inner, device=dev, dtype=torch.float32)
             hip.sphere_dwconv_nhwc(qkv, self._plan[id(ms.proj_in)], dw, B=B, H=H, W=W, C=3 * inner, ldx=wide, ksize=ms.proj_in.kernel_size[0])
@@ -290,18 +302,18 @@ class AutoencoderDC(ModelMixin):
         att = torch.empty(M, groups * 32, device=dev, dtype=torch.float32)
         hip.relu_linear_attn_nhwc(qkv, att, B=B, P=H * W, groups=groups, ldq=wide, ldy=groups * 32, eps=at.eps)
         o = torch.empty(M, C, device=dev, dtype=torch.float32)
-        hip.gemm(att, at.to_out.weight, o, M=M, N=C, K=groups * 32)
+        self._mm(att, id(at.to_out), at.to_out.weight, o, B, H, W, N=C, K=groups * 32)
         y = torch.empty_like(o)
         hip.rmsnorm_rows(o, at.norm_out.weight, y, rows=M, C=C, eps=at.norm_out.eps, b=at.norm_out.bias, resid=x)
         # GLUMBConv, models/DCAE.py:304-324
         g = blk.conv_out
         hid2 = g.conv_inverted.out_channels
         h1 = torch.empty(M, hid2, device=dev, dtype=torch.float32)
-        hip.gemm(y, self._plan[id(g.conv_inverted)], h1, M=M, N=hid2, K=C, bias=g.conv_inverted.bias, act=hip.ACT_SILU)
+        self._mm(y, id(g.conv_inverted), self._plan[id(g.conv_inverted)], h1, B, H, W, N=hid2, K=C, bias=g.conv_inverted.bias, act=hip.ACT_SILU)
         h2 = torch.empty(M, hid2 // 2, device=dev, dtype=torch.float32)
         hip.sphere_dwconv_nhwc(h1, self._plan[id(g.conv_depth)], h2, B=B, H=H, W=W, C=hid2, bias=g.conv_depth.bias, ksize=3, glu=True)
         h3 = torch.empty(M, C, device=dev, dtype=torch.float32)
-        hip.gemm(h2, self._plan[id(g.conv_point)], h3, M=M, N=C, K=hid2 // 2)
+        self._mm(h2, id(g.conv_point), self._plan[id(g.conv_point)], h3, B, H, W, N=C, K=hid2 // 2)
         out = torch.empty_like(h3)
         hip.rmsnorm_rows(h3, g.norm.weight, out, rows=M, C=C, eps=g.norm.eps, b=g.norm.bias, resid=y)
         return out
