@@ -259,3 +259,9 @@ def test_end_to_end_rollout_with_dcae_matches_oracle():
     assert got.shape == want.shape == (1, 2, 84, 4, 120, 240)
     assert torch.isnan(got[:, :, :, 0]).all() and torch.isnan(want[:, :, :, 0]).all()  # slot 0 = raw field, owned by the caller
     assert rel_l2(got[:, :, :, 1:], want[:, :, :, 1:]) < TOL
+    # everything on the bf16 matrix cores: AR GEMMs / attention and the DCAE convs in split-bf16 mode, same 1e-4 budget
+    gae.set_gemm_precision("bf16x3")
+    gar.set_gemm_precision("bf16x3")
+    got3 = roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()),
+                           normalization_param_dict={"mean": fmu, "std": fsd}, encdec_model=gae, **kw)
+    assert rel_l2(got3[:, :, :, 1:], want[:, :, :, 1:]) < TOL
