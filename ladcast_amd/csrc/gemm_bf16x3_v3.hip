@@ -567,6 +567,10 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
       if (gmax < G) G = gmax;
     }
   }
+  if (const char* e = getenv("LDC_BF16X3_G")) {  // measurement aid: force the number of unit ranges
+    const long long g_ = atoll(e);
+    if (g_ > 0 && g_ <= CUS) G = g_;
+  }
   if (U < G) G = U;
   if (workspace == nullptr) return LDC_ERR_ARG;
   if (workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2 * slot_bytes) return LDC_ERR_ARG;
