@@ -290,6 +290,28 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    other_sampler = None
+    if not args.no_kernel_timers and rank == 0 and world == 1:
+        # Secondary number (not `value`): the same workload with the reference's other sampler -- BASELINE's metric says
+        # "20-step DDIM"; `edm` (the reference's default, 39 forwards per chunk) is the headline, `pipeline`
+        # (DPM-Solver++ 2M, 20 forwards per chunk) is reported beside it, and vice versa.
+        alt = "pipeline" if args.sampler == "edm" else "edm"
+
+        def step_alt():
+            return roll_out_serial(
+                None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
+                latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=alt, return_latent=True,
+                known_latents_override=ic, member_ids=member_ids,
+            )
+
+        step_alt()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step_alt()
+        torch.cuda.synchronize()
+        other_sampler = dict(sampler=alt, forwards_per_step=(-(-lead // R)) * (args.solver_steps if alt == "pipeline" else 2 * args.solver_steps - 1),
+                             value=round(m * lead * 2 / (time.perf_counter() - t1), 4), unit="member-steps/s", steps=2)
     instrumented_ms = None
     if not args.no_kernel_timers and rank == 0:
         # Kernel-level numbers for `roofline`: ONE more step of the same workload, right after the timed region, with a
@@ -354,6 +376,7 @@ def main():
                 "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
+            "other_sampler": other_sampler,
             "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
             "roofline": roof,
         }

@@ -254,6 +254,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._te_cache = None
         self._te_buf = {}
         self._graphs = {}
+        self._capture_stream = None
         self.use_hip_graph = False
         self.gemm_precision = "fp32"
 
@@ -498,10 +499,16 @@ class LaDCastTransformer3DModel(ModelMixin):
                 sx.copy_(hidden_states)
                 st.copy_(timestep)
                 sk.copy_(conditioning_tensors)
-                self._forward_device(sx, st, sk, te)  # warm-up on the side stream: workspaces, kernel attributes
+                # warm-up and capture on ONE side stream: per-stream workspaces (stream-K counters, attention operands)
+                # are created and initialised by the warm-up, so no allocation / memset ends up inside the graph
+                if self._capture_stream is None:
+                    self._capture_stream = torch.cuda.Stream(device=dev)
+                self._capture_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(self._capture_stream):
+                    self._forward_device(sx, st, sk, te)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=self._capture_stream):
                     sout = self._forward_device(sx, st, sk, te)
                 ent = (graph, sx, st, sk, sout)
                 self._graphs[gkey] = ent
