@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--share-gpus", action="store_true", help="dry-run aid: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one captured hipGraph per model forward "
                     "(graph replay keeps the GPU fed regardless of host speed; kernels and numerics are identical)")
+    ap.add_argument("--decode", action="store_true", help="secondary workload (BASELINE configs[4]): encode the IC field with the DCAE, roll out, DECODE "
+                    "every lead step to 84 x 120 x 240 fields (DCAE in bf16x3 mode unless --precision fp32); not the headline")
     ap.add_argument("--workload", default="rollout", choices=["rollout", "dcae"], help="rollout = the headline (AR sampler chunk); dcae = DCAE "
                     "encode / decode timing (BASELINE configs[0], secondary)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
@@ -259,6 +261,23 @@ def main():
     targs = {"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5}
     from ladcast_amd.pipelines.distributed import gather_members
 
+    dec_kw = {}
+    if args.decode:  # end-to-end: IC field -> encode -> AR chunks -> decode (roll_out_serial's decoded-field mode)
+        from ladcast_amd.models import AutoencoderDC
+
+        ae = AutoencoderDC.from_config(CONFIG_DCAE_84).to(dev).eval().set_gemm_precision(args.precision)
+        g_ = torch.Generator().manual_seed(3)
+        field = torch.randn(84, 1, 120, 240, generator=g_)
+        static = torch.randn(5, 120, 240, generator=g_)
+        dec_kw = dict(encdec_model=ae, encdec_model_type="ae", static_tensor4encdec=static,
+                      normalization_param_dict={"mean": torch.zeros(84), "std": torch.ones(84)})
+
+        def step_decode():
+            return roll_out_serial(
+                lambda t: field, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
+                latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=False,
+                member_ids=member_ids, **dec_kw)
+
     def step_local():
         return roll_out_serial(
             None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
@@ -267,6 +286,8 @@ def main():
         )
 
     def step():
+        if args.decode:
+            return step_decode()
         out = roll_out_serial(
             None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
             latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
@@ -370,7 +391,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16x3(split-fp32 operands, f32 accumulate; softmax/norms f32, sampler state f64)" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: {args.model} AR transformer, {m} member/GPU, {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
+                "workload": ("cfg5-style END-TO-END (DCAE encode -> AR -> DCAE decode of every lead step), " if args.decode else "") +
+                            f"cfg2: {args.model} AR transformer, {m} member/GPU, {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
                             f"{lead} lead step(s) = {chunks} chunk(s) of return_seq_len {R}, latent 84x15x30, fp32 weights random-init seed 1234, arithmetic {args.precision}",
                 "sampler": args.sampler, "members_per_gpu": m, "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
                 "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
