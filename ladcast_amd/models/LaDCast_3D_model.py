@@ -524,6 +524,30 @@ class LaDCastTransformer3DModel(ModelMixin):
             return (out,)
         return SimpleNamespace(sample=out)
 
+    # -- launch-only entry points for callers that capture a larger graph (pipelines/edm_sampler.py) ------------------
+    def time_elapsed_embedding(self, time_elapsed):
+        """the cached (rows, 2D) time-elapsed embedding of `forward` (None when the model has none / no timestamps)"""
+        if time_elapsed is None or self.time_elapsed_embed is None:
+            return None
+        if self._plan is None:
+            self._build_plan()
+        return self._time_elapsed_embedding(time_elapsed, self.device)
+
+    def plan_identity(self):
+        """changes whenever the packed weights are rebuilt (load_state_dict, .to(), set_gemm_precision): key for graphs
+        captured outside the model"""
+        if self._plan is None:
+            self._build_plan()
+        return id(self._plan)
+
+    @torch.no_grad()
+    def forward_launch_only(self, hidden_states, timestep, conditioning_tensors, te):
+        """`forward` without host work: fp32 device tensors in their final shapes, `te` from `time_elapsed_embedding`;
+        only kernel launches on the current stream (capturable).  Returns the sample tensor."""
+        if self._plan is None:
+            self._build_plan()
+        return self._forward_device(hidden_states, timestep.reshape(-1), conditioning_tensors, te)
+
     def _forward_device(self, hidden_states, timestep, conditioning_tensors, te):
         """Kernel launches only (no host sync, no shape-dependent Python state): capturable into a hipGraph."""
         plan = self._plan
