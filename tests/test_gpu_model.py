@@ -91,6 +91,27 @@ def test_edm_chunk_graph_is_bitwise_equal_to_eager(tiny_pair):
     assert not torch.equal(eager[0], eager[1])
 
 
+def test_checkpoint_folder_loads_into_the_hip_path(tiny_pair, tmp_path):
+    """a diffusers-layout folder (sharded here) written from the oracle's weights loads through
+    ``from_pretrained`` and runs on the HIP path with the same result, bit for bit, as the model it was written from; the AR
+    model is found the way training leaves it (``checkpoint-<step>/ar_model``, train_AR.py:561-570)."""
+    from ladcast_amd.models import LaDCastTransformer3DModel
+    from ladcast_amd.models.modeling_utils import checkpoint_model_folder
+
+    o, g = tiny_pair
+    g.save_pretrained(tmp_path / "checkpoint-200" / "ar_model", max_shard_size=150_000)
+    g.save_pretrained(tmp_path / "checkpoint-1000" / "ar_model", max_shard_size=150_000)
+    loaded = LaDCastTransformer3DModel.from_pretrained(checkpoint_model_folder(str(tmp_path), "latest")).to("cuda")
+    assert str(tmp_path / "checkpoint-1000") in loaded._name_or_path
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+    args = (x, torch.tensor([0.4]).cuda(), synth_known(2).cuda())
+    ts = torch.tensor([2018010100]).cuda()
+    assert torch.equal(loaded(*args, time_elapsed=ts).sample, g(*args, time_elapsed=ts).sample)
+    with torch.no_grad():
+        want = o(*(a.cpu() for a in args), time_elapsed=ts.cpu()).sample
+    assert rel_l2(loaded(*args, time_elapsed=ts).sample.cpu(), want) < 2e-5
+
+
 def test_tiny_forward_matches_golden_pin(tiny_pair, golden_dir):
     """The committed pin (made by the oracle in the build container) must also be hit by the HIP path."""
     _, g = tiny_pair
