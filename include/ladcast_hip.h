@@ -117,6 +117,22 @@ int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bi
                      const float* add, int add_rows, float* y, int rows, int N, int K,
                      int act_in, int act_out, void* stream);
 
+/* Up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears (same formula, same per-output arithmetic as
+ * ldc_linear_small: results are bit-identical) in ONE launch: the two MLPs of
+ * CombinedTimestepTextProjEmbeddings (timestep_embedder / text_embedder, used twice per forward:
+ * models/LaDCast_3D_model.py:362-364,953-969) have independent first and second layers.  No problem's y may be
+ * another problem's x / add / y (LDC_ERR_ARG). */
+#define LDC_LINEAR_SMALL_MAX_GROUPED 4
+typedef struct ldc_linear_small_problem {
+  const float* x;    /* [x_rows][K] */
+  const float* W;    /* [N][K] */
+  const float* bias; /* [N] or NULL */
+  const float* add;  /* [add_rows][N] or NULL */
+  float* y;          /* [rows][N] */
+  int x_rows, add_rows, rows, N, K, act_in, act_out, reserved;
+} ldc_linear_small_problem;
+int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Attention   O = softmax(Q K^T / sqrt(128)) V   per (batch, head), no mask
  *   Q,K,V: token-major [B][S][H][128] views with row stride ld_qkv and batch stride
@@ -172,6 +188,14 @@ int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx,
                       int mode, float eps, int out_split, void* stream);
 /* out_split != 0: y is written in the split activation format of LDC_GEMM_A_SPLIT (the consumer GEMM then
  * does not split it again); D, ldy, y_bs multiples of 8. */
+/* The same over two row segments in one launch: rows [0, split_row) use scale / shift, rows [split_row, rows)
+ * use scale2 / shift2 (same mode, eps and mod_bs).  One call per dual block norm instead of one per stream:
+ * norm1 + norm1_context (models/LaDCast_3D_model.py:524-529) and norm2 + norm2_context (:546-555) when the
+ * two token streams are adjacent rows of one buffer.  Row results are those of ldc_layernorm_mod, bit for bit. */
+int ldc_layernorm_mod2(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs,
+                       int ldy, long long y_bs, const float* scale, const float* shift, int split_row,
+                       const float* scale2, const float* shift2, int mod_bs, int mode, float eps,
+                       int out_split, void* stream);
 
 /* y[b][c] = mean over rows of x[b][r][c]   (hidden_states.mean(dim=1),
  * models/LaDCast_3D_model.py:382,955) */

@@ -15,12 +15,18 @@ constexpr int LN_MAX_V4 = 8;  // D <= 64 lanes * 8 float4 * 4 = 2048
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             int rows, int D, int ldx, long long x_bs, int ldy,
                                                             long long y_bs, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int mod_bs, int mode,
+                                                            const float* __restrict__ shift, int split_row,
+                                                            const float* __restrict__ scale2,
+                                                            const float* __restrict__ shift2, int mod_bs, int mode,
                                                             float eps, int out_split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
   if (row >= rows) return;
+  if (row >= split_row) {  // second row segment (the conditioning stream of a dual block): its own modulation vectors
+    scale = scale2;
+    shift = shift2;
+  }
   const float* xr = x + b * x_bs + static_cast<long long>(row) * ldx;
   float* yr = y + b * y_bs + static_cast<long long>(row) * ldy;
   const int nv4 = D >> 2;
@@ -178,11 +184,10 @@ constexpr int LS_CPW_MAX = 4; // output columns per wave: 4 for wide outputs, 1 
 constexpr int LS_KC = 2048;   // K chunk staged in LDS (8 rows x 2048 x 4 B = 64 KiB)
 
 template <int LS_CPW>
-__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int x_rows,
-                                                           const float* __restrict__ W, const float* __restrict__ bias,
-                                                           const float* __restrict__ add, int add_rows,
-                                                           float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
-                                                           int act_out) {
+__device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, const float* __restrict__ add,
+                                                  int add_rows, float* __restrict__ y, int rows, int N, int K, int kc,
+                                                  int act_in, int act_out) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [rows_here][kc]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -251,26 +256,57 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
   }
 }
 
+template <int LS_CPW>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int x_rows,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ add, int add_rows,
+                                                           float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
+                                                           int act_out) {
+  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out);
+}
+
+// up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears in one launch: blockIdx.z picks the problem
+struct LSGroup {
+  ldc_linear_small_problem p[LDC_LINEAR_SMALL_MAX_GROUPED];
+};
+
+__global__ __launch_bounds__(256) void linear_small_grouped_kernel(LSGroup g) {
+  const ldc_linear_small_problem& q = g.p[blockIdx.z];
+  if (static_cast<int>(blockIdx.x) * 4 >= q.N || static_cast<int>(blockIdx.y) * LS_ROWS >= q.rows) return;  // block-uniform
+  const int kc = q.K < LS_KC ? q.K : LS_KC;
+  linear_small_body<1>(q.x, q.x_rows, q.W, q.bias, q.add, q.add_rows, q.y, q.rows, q.N, q.K, kc, q.act_in, q.act_out);
+}
+
 }  // namespace
 
-extern "C" int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, int ldy,
-                                 long long y_bs, const float* scale, const float* shift, int mod_bs, int mode,
-                                 float eps, int out_split, void* stream) {
+extern "C" int ldc_layernorm_mod2(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, int ldy,
+                                  long long y_bs, const float* scale, const float* shift, int split_row,
+                                  const float* scale2, const float* shift2, int mod_bs, int mode, float eps,
+                                  int out_split, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(y);
-  if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
+  if (B <= 0 || rows <= 0 || D <= 0 || split_row < 0) return LDC_ERR_ARG;
   if ((D & 3) || D > 64 * 4 * LN_MAX_V4) return LDC_ERR_UNSUPPORTED;
   if ((ldx & 3) || (ldy & 3) || (x_bs & 3) || (y_bs & 3) || (mod_bs & 3)) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(y);
   if (scale) LDC_CHECK_ALIGN16(scale);
   if (shift) LDC_CHECK_ALIGN16(shift);
+  if (scale2) LDC_CHECK_ALIGN16(scale2);
+  if (shift2) LDC_CHECK_ALIGN16(shift2);
   if (mode != 0 && mode != 1) return LDC_ERR_UNSUPPORTED;
   if (out_split && ((D & 7) || (ldy & 7) || (y_bs & 7) || (reinterpret_cast<unsigned long long>(y) & 31ull))) return LDC_ERR_ALIGN;
   dim3 grid(ldc_cdiv(rows, 4), B);
   hipLaunchKernelGGL(layernorm_mod_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx,
-                     x_bs, ldy, y_bs, scale, shift, mod_bs, mode, eps, out_split);
+                     x_bs, ldy, y_bs, scale, shift, split_row, scale2, shift2, mod_bs, mode, eps, out_split);
   return ldc_launch_status();
+}
+
+extern "C" int ldc_layernorm_mod(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, int ldy,
+                                 long long y_bs, const float* scale, const float* shift, int mod_bs, int mode,
+                                 float eps, int out_split, void* stream) {
+  return ldc_layernorm_mod2(x, y, B, rows, D, ldx, x_bs, ldy, y_bs, scale, shift, rows, nullptr, nullptr, mod_bs, mode, eps,
+                            out_split, stream);
 }
 
 extern "C" int ldc_qk_rmsnorm_rope(float* q, float* k, int B, int row0, int rows, int H, int ld, long long bs,
@@ -347,5 +383,43 @@ extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, cons
     hipLaunchKernelGGL(linear_small_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add,
                        add_rows, y, rows, N, K, kc, act_in, act_out);
   }
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, void* stream) {
+  LDC_CHECK_PTR(problems);
+  if (n < 1 || n > LDC_LINEAR_SMALL_MAX_GROUPED) return LDC_ERR_ARG;
+  LSGroup g{};
+  int gx = 0, gy = 0, kc_max = 0, rows_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const ldc_linear_small_problem& q = problems[i];
+    LDC_CHECK_PTR(q.x);
+    LDC_CHECK_PTR(q.W);
+    LDC_CHECK_PTR(q.y);
+    if (q.rows <= 0 || q.N <= 0 || q.K <= 0 || q.x_rows <= 0) return LDC_ERR_ARG;
+    if (q.add && q.add_rows <= 0) return LDC_ERR_ARG;
+    if (q.K & 3) return LDC_ERR_ALIGN;
+    LDC_CHECK_ALIGN16(q.x);
+    LDC_CHECK_ALIGN16(q.W);
+    for (int j = 0; j < i; ++j)  // problems of one launch run concurrently: no output may be another's input
+      if (problems[j].y == q.x || problems[j].y == q.add || q.y == problems[j].x || q.y == problems[j].add || q.y == problems[j].y)
+        return LDC_ERR_ARG;
+    g.p[i] = q;
+    const int bx = ldc_cdiv(q.N, 4), by = ldc_cdiv(q.rows, LS_ROWS);
+    gx = bx > gx ? bx : gx;
+    gy = by > gy ? by : gy;
+    const int kc = q.K < LS_KC ? q.K : LS_KC;
+    kc_max = kc > kc_max ? kc : kc_max;
+    const int r = q.rows < LS_ROWS ? q.rows : LS_ROWS;
+    rows_max = r > rows_max ? r : rows_max;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
+    attr_set = true;
+  }
+  const size_t lds = static_cast<size_t>(rows_max) * kc_max * sizeof(float);
+  hipLaunchKernelGGL(linear_small_grouped_kernel, dim3(gx, gy, n), dim3(256), lds, static_cast<hipStream_t>(stream), g);
   return ldc_launch_status();
 }

@@ -38,6 +38,11 @@ class GemmProblem(Structure):
 MAX_GROUPED = 4
 
 
+class LinearSmallProblem(Structure):  # ldc_linear_small_problem
+    _fields_ = [("x", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("add", c_void_p), ("y", c_void_p), ("x_rows", c_int), ("add_rows", c_int),
+                ("rows", c_int), ("N", c_int), ("K", c_int), ("act_in", c_int), ("act_out", c_int), ("reserved", c_int)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -58,6 +63,7 @@ def _load():
         "ldc_gemm_grouped_bf16x3": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
+        "ldc_linear_small_grouped": (I, [POINTER(LinearSmallProblem), I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
@@ -68,6 +74,7 @@ def _load():
         "ldc_attn_pack_bf16x3": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P, P]),
         "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, I, P]),
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, I, P]),
+        "ldc_layernorm_mod2": (I, [P, P, I, I, I, I, L, I, L, P, P, I, P, P, I, I, F, I, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_chan_to_token": (I, [P, P, I, I, I, I, I, P]),
@@ -192,6 +199,25 @@ def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_r
                                 rows, N, K, act_in, act_out, _stream()), "ldc_linear_small")
 
 
+LINEAR_SMALL_MAX_GROUPED = 4  # LDC_LINEAR_SMALL_MAX_GROUPED
+
+
+def linear_small_problem(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE):
+    """one entry of linear_small_grouped (same arguments as linear_small)"""
+    _dev(x, W, y, bias, add)
+    q = LinearSmallProblem(_p(x), _p(W), _p(bias), _p(add), _p(y), x_rows if x_rows is not None else rows, add_rows, rows, N, K, act_in, act_out, 0)
+    return q, (x, W, y, bias, add)
+
+
+def linear_small_grouped(problems):
+    """up to LINEAR_SMALL_MAX_GROUPED independent small linears in one launch"""
+    n = len(problems)
+    if not 1 <= n <= LINEAR_SMALL_MAX_GROUPED:
+        raise ValueError(f"linear_small_grouped takes 1..{LINEAR_SMALL_MAX_GROUPED} problems")
+    arr = (LinearSmallProblem * n)(*[p[0] for p in problems])
+    _check(lib.ldc_linear_small_grouped(arr, n, _stream()), "ldc_linear_small_grouped")
+
+
 def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False):
     _dev(Q, K, V, O)
     fn = lib.ldc_attn_fwd_bf16x3 if split_bf16 else lib.ldc_attn_fwd
@@ -241,11 +267,18 @@ def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, si
            "ldc_qk_rmsnorm_rope")
 
 
-def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=None, mod_bs=0, mode=0, eps=1e-6, out_split=False):
-    _dev(x, y, scale, shift)
-    _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps,
-                                 1 if out_split else 0, _stream()),
-           "ldc_layernorm_mod")
+def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=None, mod_bs=0, mode=0, eps=1e-6, out_split=False,
+                  split_row=None, scale2=None, shift2=None):
+    """split_row: rows [split_row, rows) take scale2 / shift2 (two token streams normalised by one launch)"""
+    _dev(x, y, scale, shift, scale2, shift2)
+    if split_row is None:
+        _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps,
+                                     1 if out_split else 0, _stream()),
+               "ldc_layernorm_mod")
+    else:
+        _check(lib.ldc_layernorm_mod2(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), split_row, _p(scale2), _p(shift2),
+                                      mod_bs, mode, eps, 1 if out_split else 0, _stream()),
+               "ldc_layernorm_mod2")
 
 
 def mean_rows(x, y, *, B, rows, D, ldx, x_bs):

@@ -179,6 +179,8 @@ class _Workspace:
         self.tsin = torch.empty(Bt, 256, **f)
         self.t1 = torch.empty(Bt, D, **f)
         self.t2 = torch.empty(Bt, D, **f)
+        self.t1m = torch.empty(Bt, D, **f)  # main time_text_embed's timestep MLP (computed with the refiner's, one launch per layer)
+        self.t2m = torch.empty(Bt, D, **f)
         self.pooled = torch.empty(B, D, **f)
         self.p1 = torch.empty(B, D, **f)
         self.temb_r = torch.empty(B, D, **f)
@@ -412,14 +414,32 @@ class LaDCastTransformer3DModel(ModelMixin):
         return out
 
     # -- building blocks ---------------------------------------------------------------------
-    def _combined_embed(self, emb, tsin, Bt, pooled, B, pooled_dim, ws, out):
-        """CombinedTimestepTextProjEmbeddings: timestep MLP (Bt rows) + text MLP (B rows)."""
+    def _timestep_mlps(self, tsin, Bt, pooled, B, ws):
+        """Both CombinedTimestepTextProjEmbeddings of one forward (the refiner's and the model's): their timestep MLPs
+        depend only on the timestep, and the refiner's text MLP starts from the first pooled context - three independent
+        first layers in one launch, the two timestep second layers in the next, then the refiner's sum.
+        (diffusers CombinedTimestepTextProjEmbeddings: conditioning = timestep_embedder(proj(t)) + text_embedder(pooled))"""
         D = self.inner_dim
-        te, tx = emb.timestep_embedder, emb.text_embedder
-        hip.linear_small(tsin, te.linear_1.weight, ws.t1, rows=Bt, N=D, K=256, bias=te.linear_1.bias, act_out=hip.ACT_SILU)
-        hip.linear_small(ws.t1, te.linear_2.weight, ws.t2, rows=Bt, N=D, K=D, bias=te.linear_2.bias)
-        hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=pooled_dim, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
-        hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
+        r, m = self.context_refiner.time_text_embed, self.time_text_embed
+        P = hip.linear_small_problem
+        hip.linear_small_grouped([
+            P(tsin, r.timestep_embedder.linear_1.weight, ws.t1, rows=Bt, N=D, K=256, bias=r.timestep_embedder.linear_1.bias, act_out=hip.ACT_SILU),
+            P(tsin, m.timestep_embedder.linear_1.weight, ws.t1m, rows=Bt, N=D, K=256, bias=m.timestep_embedder.linear_1.bias, act_out=hip.ACT_SILU),
+            P(pooled, r.text_embedder.linear_1.weight, ws.p1, rows=B, N=D, K=D, bias=r.text_embedder.linear_1.bias, act_out=hip.ACT_SILU),
+        ])
+        hip.linear_small_grouped([
+            P(ws.t1, r.timestep_embedder.linear_2.weight, ws.t2, rows=Bt, N=D, K=D, bias=r.timestep_embedder.linear_2.bias),
+            P(ws.t1m, m.timestep_embedder.linear_2.weight, ws.t2m, rows=Bt, N=D, K=D, bias=m.timestep_embedder.linear_2.bias),
+        ])
+        tx = r.text_embedder
+        hip.linear_small(ws.p1, tx.linear_2.weight, ws.temb_r, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
+
+    def _text_mlp(self, emb, pooled, B, Bt, t2, ws, out):
+        """text_embedder(pooled) + the timestep MLP output computed earlier"""
+        D = self.inner_dim
+        tx = emb.text_embedder
+        hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=D, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
+        hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt)
 
     def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False):
         """q/k RMSNorm + RoPE per segment, then attention over token rows [row0, row0 + Sx + Sc) of the fused qkv
@@ -508,7 +528,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                     self._forward_device(sx, st, sk, te)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=self._capture_stream):
+                with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
                     sout = self._forward_device(sx, st, sk, te)
                 ent = (graph, sx, st, sk, sout)
                 self._graphs[gkey] = ent
@@ -610,7 +630,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         ref = self.context_refiner
         hip.timestep_embedding(timestep, ws.tsin, Bt)
         hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
-        self._combined_embed(ref.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb_r)
+        self._timestep_mlps(ws.tsin, Bt, ws.pooled, B, ws)
         run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
@@ -628,7 +648,7 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
         hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
-        self._combined_embed(self.time_text_embed, ws.tsin, Bt, ws.pooled, B, D, ws, ws.temb)
+        self._text_mlp(self.time_text_embed, ws.pooled, B, Bt, ws.t2m, ws, ws.temb)
         if te is not None:
             hip.temb_modulate(ws.temb, te, B=B, D=D, te_rows=te.shape[0])
         NM = plan.mod_w.shape[0]
@@ -642,8 +662,9 @@ class LaDCastTransformer3DModel(ModelMixin):
         for blk in self.transformer_blocks:
             pa = plan.attn[id(blk.attn)]
             mx, mc = mod_of(blk.norm1.linear, 6 * D), mod_of(blk.norm1_context.linear, 6 * D)
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, D:], shift=mc, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
+            # norm1 + norm1_context: the two streams are adjacent rows of ws.h -> one launch, two modulation sets
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, split_row=Nx, scale2=mc[:, D:], shift2=mc,
+                              mod_bs=NM, mode=0, eps=1e-6, out_split=split)
             run([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
@@ -655,8 +676,8 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
                 G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD, flags=AS),
             ])
-            hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mc[:, 4 * D :], shift=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], split_row=Nx,
+                              scale2=mc[:, 4 * D :], shift2=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
             up, down = [], []
             for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
                 f0, f2 = ff.net[0].proj, ff.net[2]

@@ -80,7 +80,7 @@ def edm_AR_sampler(
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps)
             ent = (graph, st_lat, st_known, st_out, cn, side)
             cache[key] = ent

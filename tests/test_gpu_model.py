@@ -89,6 +89,7 @@ def test_edm_chunk_graph_is_bitwise_equal_to_eager(tiny_pair):
     for a, b, c in zip(eager, first, second):
         assert torch.equal(a, b) and torch.equal(a, c)  # capture pass and pure replays
     assert not torch.equal(eager[0], eager[1])
+    assert len(g.__dict__["_edm_chunk_graphs"]) == 2  # one graph per chunk shape: new timestamps / conditioning / noise replay it
 
 
 def test_checkpoint_folder_loads_into_the_hip_path(tiny_pair, tmp_path):

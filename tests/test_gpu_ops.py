@@ -483,6 +483,56 @@ def test_linear_small(hip, rows, x_rows, add_rows):
     assert rel(y, want) < 1e-6
 
 
+def test_linear_small_grouped_is_bitwise_the_single_launches(hip):
+    """three independent small linears of different K / rows / activations in one launch == three launches, bit for bit;
+    a problem that reads another's output is refused (the problems of one launch run concurrently)"""
+    D = 384
+    tsin, pooled = dev(rnd(1, 256, seed=1)), dev(rnd(3, D, seed=2))
+    W = [dev(rnd(D, 256, seed=3) / 16), dev(rnd(D - 4, 256, seed=4) / 16), dev(rnd(D, D, seed=5) / 16)]
+    b = [dev(rnd(D, seed=6)), None, dev(rnd(D, seed=7))]
+    add = dev(rnd(1, D, seed=8))
+    specs = [dict(x=tsin, W=W[0], rows=1, N=D, K=256, bias=b[0], act_out=1),
+             dict(x=tsin, W=W[1], rows=1, N=D - 4, K=256, bias=b[1], act_in=1),
+             dict(x=pooled, W=W[2], rows=3, N=D, K=D, bias=b[2], add=add, add_rows=1, act_out=1)]
+    single, grouped = [], []
+    for sp in specs:
+        sp = dict(sp)
+        y = torch.full((sp["rows"], sp["N"]), float("nan"), device="cuda")
+        hip.linear_small(sp.pop("x"), sp.pop("W"), y, **sp)
+        single.append(y)
+    probs = []
+    for sp in specs:
+        sp = dict(sp)
+        y = torch.full((sp["rows"], sp["N"]), float("nan"), device="cuda")
+        grouped.append(y)
+        probs.append(hip.linear_small_problem(sp.pop("x"), sp.pop("W"), y, **sp))
+    hip.linear_small_grouped(probs)
+    for a, g in zip(single, grouped):
+        assert torch.equal(a, g)
+    chained = [hip.linear_small_problem(tsin, W[0], grouped[0], rows=1, N=D, K=256), hip.linear_small_problem(grouped[0], W[2], grouped[2], rows=1, N=D, K=D)]
+    with pytest.raises(RuntimeError):
+        hip.linear_small_grouped(chained)
+    with pytest.raises(ValueError):
+        hip.linear_small_grouped([])
+
+
+def test_layernorm_two_row_segments_is_bitwise_two_launches(hip):
+    """rows [0, split) with one modulation set and [split, rows) with another in one launch (the dual block's
+    norm1 + norm1_context) == two ldc_layernorm_mod launches, bit for bit, in fp32 and in the split format"""
+    B, S, Nx, D = 2, 45, 36, 256
+    x = dev(rnd(B, S, D, seed=1))
+    mods = dev(rnd(B, 4 * D, seed=2))
+    sx, hx, sc, hc = mods[:, :D], mods[:, D : 2 * D], mods[:, 2 * D : 3 * D], mods[:, 3 * D :]
+    for split in (False, True):
+        two = torch.full((B, S, D), float("nan"), device="cuda")
+        kw = dict(B=B, D=D, ldx=D, x_bs=S * D, ldy=D, y_bs=S * D, mod_bs=4 * D, mode=0, eps=1e-6, out_split=split)
+        hip.layernorm_mod(x[:, :Nx], two[:, :Nx], rows=Nx, scale=sx, shift=hx, **kw)
+        hip.layernorm_mod(x[:, Nx:], two[:, Nx:], rows=S - Nx, scale=sc, shift=hc, **kw)
+        one = torch.full((B, S, D), float("nan"), device="cuda")
+        hip.layernorm_mod(x, one, rows=S, scale=sx, shift=hx, split_row=Nx, scale2=sc, shift2=hc, **kw)
+        assert torch.equal(one.view(torch.int32), two.view(torch.int32))
+
+
 def test_layout_and_embedding_kernels(hip):
     B, C, N = 2, 84, 1800
     x = rnd(B, C, N, seed=1)

@@ -17,6 +17,7 @@ for r in seq:
     prev_end = e
     if "token_to_chan" in n:
         break
-print(f"forward total {(prev_end - t0) / 1e3:.1f} us")
+busy = sum(sum(v) for v in agg.values())
+print(f"forward total {(prev_end - t0) / 1e3:.1f} us, kernels {busy:.1f} us, gaps {(prev_end - t0) / 1e3 - busy:.1f} us over {sum(len(v) for v in agg.values())} launches")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {k[0]:30s} grid {k[1]:6d}  x{len(v):2d}  avg {sum(v) / len(v):7.1f} us  total {sum(v):7.1f}")
