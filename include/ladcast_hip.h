@@ -200,6 +200,11 @@ int ldc_layernorm_mod2(const float* x, float* y, int B, int rows, int D, int ldx
 /* y[b][c] = mean over rows of x[b][r][c]   (hidden_states.mean(dim=1),
  * models/LaDCast_3D_model.py:382,955) */
 int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, int ldx, long long x_bs, void* stream);
+/* The same mean (bit-identical y) that also writes x in the split activation format of LDC_GEMM_A_SPLIT to
+ * x_split (row stride lds, batch stride s_bs, in floats; D % 8 == 0), so that the Linear consuming x
+ * (context_refiner.proj_in, models/LaDCast_3D_model.py:362-380) takes the pre-split GEMM kernel. */
+int ldc_mean_rows_split(const float* x, float* y, float* x_split, int B, int rows, int D, int ldx,
+                        long long x_bs, int lds, long long s_bs, void* stream);
 
 /* out[b][r][c] = resid[b][r][c] + gate[b][c] * y[b][r][c]  (refiner gated residual on the
  * projection-less attention output, models/LaDCast_3D_model.py:296-297) */
@@ -213,6 +218,10 @@ int ldc_gate_residual(const float* resid, const float* y, const float* gate, flo
  * Columns [C, fill_cols) of the token-major output are zero-filled (fill_cols <= ldo; lets two
  * calls concatenate channels into one padded row). */
 int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols, void* stream);
+/* out_split != 0: the token rows are written in the split activation format of LDC_GEMM_A_SPLIT
+ * (fill_cols, ldo multiples of 8; out 32-byte aligned). */
+int ldc_chan_to_token_split(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols,
+                            int out_split, void* stream);
 int ldc_token_to_chan(const float* in, float* out, int B, int C, int N, int ldi, void* stream);
 
 /* Sinusoidal timestep embedding [cos | sin], 256 wide (diffusers Timesteps(256,

@@ -804,7 +804,7 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
     if (same_kt) {
       const int kt = a.pr[0].kt;
       for (int sfac = 1; sfac <= 4; ++sfac) {
-        if (kt % sfac || kt / sfac < 8) continue;
+        if (kt % sfac || (sfac > 1 && kt / sfac < 8)) continue;  // whole tiles (sfac 1) at any depth
         const long long items = tiles * sfac;
         long long gd = items < 256 ? items : 256;
         while (gd > 1 && items % gd) --gd;

@@ -549,7 +549,7 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
     if (same_kt) {
       const int kt = a.pr[0].kt;
       for (int sfac = 1; sfac <= 4; ++sfac) {
-        if (kt % sfac || kt / sfac < 8) continue;
+        if (kt % sfac || (sfac > 1 && kt / sfac < 8)) continue;  // whole tiles (sfac 1) at any depth
         const long long items = tiles * sfac;
         long long gd = items < CUS ? items : CUS;
         while (gd > 1 && items % gd) --gd;

@@ -7,7 +7,7 @@ namespace {
 // in: (B, C, N) channel-major, out: (B, N, ldo) token-major; 32x32 LDS tile transpose
 // (33-float pitch: conflict-free column reads).  Columns [C, ldo) are zero-filled.
 __global__ __launch_bounds__(256) void chan_to_token_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                            int C, int N, int ldo, int fill) {
+                                                            int C, int N, int ldo, int fill, int out_split) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -20,6 +20,25 @@ __global__ __launch_bounds__(256) void chan_to_token_kernel(const float* __restr
     tile[ty + 8 * i][tx] = (c < C && n < N) ? ib[static_cast<long long>(c) * N + n] : 0.f;
   }
   __syncthreads();
+  if (out_split) {
+    // split activation format (ladcast_hip.h LDC_GEMM_A_SPLIT): columns 8g..8g+7 in 32 bytes [hi x8 | lo x8] bf16;
+    // lane tx (even) packs columns c, c+1: one 4-byte hi word and one 4-byte lo word.  fill % 8 == 0, c0 % 32 == 0.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + 8 * i, c = c0 + tx;
+      const float v = tile[tx][ty + 8 * i];
+      const float w = __shfl_xor(v, 1);
+      if (!(tx & 1) && n < N && c < fill) {
+        float r0, r1;
+        const unsigned hi = ldc_split_pair(v, w, r0, r1);
+        const unsigned lo = ldc_pack_pair(r0, r1);
+        unsigned char* grp = reinterpret_cast<unsigned char*>(ob + static_cast<long long>(n) * ldo + (c & ~7)) + 2 * (c & 7);
+        *reinterpret_cast<unsigned*>(grp) = hi;
+        *reinterpret_cast<unsigned*>(grp + 16) = lo;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + ty + 8 * i, c = c0 + tx;
@@ -80,15 +99,21 @@ __global__ void chan_affine_kernel(const float* __restrict__ x, float* __restric
 
 }  // namespace
 
-extern "C" int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols,
-                                 void* stream) {
+extern "C" int ldc_chan_to_token_split(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols,
+                                       int out_split, void* stream) {
   LDC_CHECK_PTR(in);
   LDC_CHECK_PTR(out);
   if (B <= 0 || C <= 0 || N <= 0 || fill_cols < C || ldo < fill_cols) return LDC_ERR_ARG;
+  if (out_split && ((fill_cols & 7) || (ldo & 7) || (reinterpret_cast<unsigned long long>(out) & 31ull))) return LDC_ERR_ALIGN;
   dim3 grid(ldc_cdiv(N, 32), ldc_cdiv(fill_cols, 32), B);
   hipLaunchKernelGGL(chan_to_token_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, C, N, ldo,
-                     fill_cols);
+                     fill_cols, out_split ? 1 : 0);
   return ldc_launch_status();
+}
+
+extern "C" int ldc_chan_to_token(const float* in, float* out, int B, int C, int N, int ldo, int fill_cols,
+                                 void* stream) {
+  return ldc_chan_to_token_split(in, out, B, C, N, ldo, fill_cols, 0, stream);
 }
 
 extern "C" int ldc_token_to_chan(const float* in, float* out, int B, int C, int N, int ldi, void* stream) {

@@ -157,6 +157,54 @@ __global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict
   }
 }
 
+// the same mean (same summation order per column: bit-identical y) that also writes the rows it reads in the split
+// activation format (ladcast_hip.h LDC_GEMM_A_SPLIT), so that the GEMM consuming x does not split it again.
+// block = 64 column PAIRS x 16 row-groups
+__global__ __launch_bounds__(1024) void mean_rows_split_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               float* __restrict__ xs, int rows, int D, int ldx,
+                                                               long long x_bs, int lds, long long s_bs) {
+  __shared__ float2 part[16][64];
+  const int c = threadIdx.x & 63;
+  const int col = (blockIdx.x * 64 + c) * 2;
+  const int g = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (col < D) {
+    const float* xb = x + b * x_bs + col;
+    unsigned char* sb = reinterpret_cast<unsigned char*>(xs + b * s_bs + (col & ~7)) + 2 * (col & 7);
+    auto take = [&](int r, float2& acc) {
+      const float2 v = *reinterpret_cast<const float2*>(xb + static_cast<long long>(r) * ldx);
+      acc.x += v.x;
+      acc.y += v.y;
+      float r0, r1;
+      const unsigned hi = ldc_split_pair(v.x, v.y, r0, r1);
+      unsigned char* d = sb + static_cast<long long>(r) * lds * 4;
+      *reinterpret_cast<unsigned*>(d) = hi;
+      *reinterpret_cast<unsigned*>(d + 16) = ldc_pack_pair(r0, r1);
+    };
+    int r = g;
+    for (; r + 48 < rows; r += 64) {
+      take(r, s0);
+      take(r + 16, s1);
+      take(r + 32, s2);
+      take(r + 48, s3);
+    }
+    for (; r < rows; r += 16) take(r, s0);
+  }
+  part[g][c] = make_float2((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y));
+  __syncthreads();
+  if (g == 0 && col < D) {
+    float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      t.x += part[i][c].x;
+      t.y += part[i][c].y;
+    }
+    y[static_cast<long long>(b) * D + col] = t.x / static_cast<float>(rows);
+    y[static_cast<long long>(b) * D + col + 1] = t.y / static_cast<float>(rows);
+  }
+}
+
 // out = resid + gate[b] * y
 __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restrict__ resid, const float* __restrict__ y,
                                                             const float* __restrict__ gate, float* __restrict__ out,
@@ -332,6 +380,22 @@ extern "C" int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, i
   if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
   dim3 grid(ldc_cdiv(D, 64), B);
   hipLaunchKernelGGL(mean_rows_kernel, grid, dim3(1024), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx, x_bs);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_mean_rows_split(const float* x, float* y, float* x_split, int B, int rows, int D, int ldx,
+                                   long long x_bs, int lds, long long s_bs, void* stream) {
+  LDC_CHECK_PTR(x);
+  LDC_CHECK_PTR(y);
+  LDC_CHECK_PTR(x_split);
+  if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
+  if ((D & 7) || (ldx & 1) || (x_bs & 1) || (lds & 7) || (s_bs & 7) || (reinterpret_cast<unsigned long long>(x) & 7ull) ||
+      (reinterpret_cast<unsigned long long>(x_split) & 31ull))
+    return LDC_ERR_ALIGN;
+  if (x == x_split) return LDC_ERR_ARG;  // other workgroups' rows would be read after being overwritten
+  dim3 grid(ldc_cdiv(D, 128), B);
+  hipLaunchKernelGGL(mean_rows_split_kernel, grid, dim3(1024), 0, static_cast<hipStream_t>(stream), x, y, x_split, rows, D,
+                     ldx, x_bs, lds, s_bs);
   return ldc_launch_status();
 }
 

@@ -76,6 +76,8 @@ def _load():
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, I, P]),
         "ldc_layernorm_mod2": (I, [P, P, I, I, I, I, L, I, L, P, P, I, P, P, I, I, F, I, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
+        "ldc_mean_rows_split": (I, [P, P, P, I, I, I, I, L, I, L, P]),
+        "ldc_chan_to_token_split": (I, [P, P, I, I, I, I, I, I, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_chan_to_token": (I, [P, P, I, I, I, I, I, P]),
         "ldc_token_to_chan": (I, [P, P, I, I, I, I, P]),
@@ -281,9 +283,14 @@ def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=N
                "ldc_layernorm_mod2")
 
 
-def mean_rows(x, y, *, B, rows, D, ldx, x_bs):
-    _dev(x, y)
-    _check(lib.ldc_mean_rows(_p(x), _p(y), B, rows, D, ldx, x_bs, _stream()), "ldc_mean_rows")
+def mean_rows(x, y, *, B, rows, D, ldx, x_bs, x_split=None, lds=None, s_bs=None):
+    """x_split: also write x in the split activation format (GEMM_A_SPLIT) to this buffer (row stride lds, batch stride s_bs)"""
+    _dev(x, y, x_split)
+    if x_split is None:
+        _check(lib.ldc_mean_rows(_p(x), _p(y), B, rows, D, ldx, x_bs, _stream()), "ldc_mean_rows")
+    else:
+        _check(lib.ldc_mean_rows_split(_p(x), _p(y), _p(x_split), B, rows, D, ldx, x_bs, lds if lds is not None else ldx,
+                                       s_bs if s_bs is not None else x_bs, _stream()), "ldc_mean_rows_split")
 
 
 def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs):
@@ -292,9 +299,10 @@ def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs
            "ldc_gate_residual")
 
 
-def chan_to_token(x, out, *, B, C, N, ldo, fill_cols=None):
+def chan_to_token(x, out, *, B, C, N, ldo, fill_cols=None, out_split=False):
     _dev(x, out)
-    _check(lib.ldc_chan_to_token(_p(x), _p(out), B, C, N, ldo, ldo if fill_cols is None else fill_cols, _stream()), "ldc_chan_to_token")
+    _check(lib.ldc_chan_to_token_split(_p(x), _p(out), B, C, N, ldo, ldo if fill_cols is None else fill_cols, 1 if out_split else 0, _stream()),
+           "ldc_chan_to_token")
 
 
 def token_to_chan(x, out, *, B, C, N, ldi):

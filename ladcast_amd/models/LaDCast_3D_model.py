@@ -613,11 +613,12 @@ class LaDCastTransformer3DModel(ModelMixin):
         if split:
             KX, KC = plan.kx_pad, plan.kc_pad
             xtok, ctok = ws.xtok.view(-1)[: B * Nx * KX].view(B, Nx, KX), ws.ctok.view(-1)[: B * Nc * KC].view(B, Nc, KC)
-            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX)
-            hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC)
+            # token rows are written in the split format by the transpose itself -> the pre-split GEMM kernel
+            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX, out_split=True)
+            hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC, out_split=True)
             run([
-                G(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias),
-                G(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias),
+                G(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias, flags=AS),
+                G(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias, flags=AS),
             ])
         else:
             hip.chan_to_token(hidden_states, ws.xtok.view(-1)[: B * Nx * C_in].view(B, Nx, C_in), B=B, C=C_in, N=Nx, ldo=C_in)
@@ -629,9 +630,15 @@ class LaDCastTransformer3DModel(ModelMixin):
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
         hip.timestep_embedding(timestep, ws.tsin, Bt)
-        hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
+        if split:  # the pooling pass also leaves the embedded context in the split format for proj_in (nh_c is free until the first norm)
+            hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D, x_split=nh_c, lds=D, s_bs=SD)
+        else:
+            hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
         self._timestep_mlps(ws.tsin, Bt, ws.pooled, B, ws)
-        run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
+        if split:
+            run1(nh_c, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=ref.proj_in.bias, flags=AS)
+        else:
+            run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)

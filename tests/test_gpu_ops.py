@@ -380,6 +380,32 @@ def test_split_activation_producers(hip):
     assert (o1[:, :, Dh:] == 0).all()  # pad columns untouched
 
 
+def test_split_format_from_the_transpose_and_the_pooling_pass(hip):
+    """the channel->token transpose and the token-mean pass can leave their rows in the split format (patch-embed and
+    refiner proj_in inputs): exactly the hi / lo split of the fp32 values; the mean itself is bit-identical"""
+    B, C, N, ld = 2, 84, 450, 96
+    x = rnd(B, C, N, seed=1) * 2
+    t0 = torch.full((B, N, ld), float("nan"), device="cuda")
+    t1 = torch.full((B, N, ld), float("nan"), device="cuda")
+    hip.chan_to_token(dev(x), t0, B=B, C=C, N=N, ldo=ld, fill_cols=ld)
+    hip.chan_to_token(dev(x), t1, B=B, C=C, N=N, ldo=ld, fill_cols=ld, out_split=True)
+    hi, lo = _unsplit(t1, B * N, ld)
+    w = t0.cpu().reshape(B * N, ld)
+    assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - w.bfloat16().float()).bfloat16().float())
+
+    rows, D, S = 450, 256, 470  # the split copy lands inside a longer [B, S, D] buffer (ws.nh[:, Nx:])
+    h = dev(rnd(B, rows, D, seed=2) * 3 + 0.25)
+    m0, m1 = torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda")
+    big = torch.zeros(B, S, D, device="cuda")
+    hip.mean_rows(h, m0, B=B, rows=rows, D=D, ldx=D, x_bs=rows * D)
+    hip.mean_rows(h, m1, B=B, rows=rows, D=D, ldx=D, x_bs=rows * D, x_split=big[:, S - rows :], lds=D, s_bs=S * D)
+    assert torch.equal(m0, m1)
+    assert (big[:, : S - rows] == 0).all()
+    hi, lo = _unsplit(big[:, S - rows :].contiguous(), B * rows, D)
+    w = h.cpu().reshape(B * rows, D)
+    assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - w.bfloat16().float()).bfloat16().float())
+
+
 def test_attention_packed_rescale_branch(hip):
     S = 200
     qkv = rnd(1, S, 3 * 128, seed=5) * 0.1

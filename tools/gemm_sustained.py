@@ -9,7 +9,7 @@ import ladcast_amd.hip as hip
 # the 375M model's launches at one member: (list of (M, N, K)) per grouped call
 calls = {
     "refiner qkv": [(450, 4608, 1536)], "refiner ff up": [(450, 6144, 1536, 1)], "refiner ff down": [(450, 1536, 6144)],
-    "refiner proj_in": [(450, 1536, 1536)],
+    "refiner proj_in": [(450, 1536, 1536)], "patch embeds": [(1800, 1536, 96), (450, 1536, 96)],
     "dual qkv": [(1800, 4608, 1536), (450, 4608, 1536)], "dual out": [(1800, 1536, 1536), (450, 1536, 1536)],
     "dual ff up": [(1800, 6144, 1536, 2), (450, 6144, 1536, 2)], "dual ff down": [(1800, 1536, 6144), (450, 1536, 6144)],
     "single qkv+mlp": [(2250, 6144, 1536, 2), (2250, 4608, 1536)], "single out": [(2250, 1536, 7680)],
@@ -17,7 +17,10 @@ calls = {
 }
 warm_s = float(os.environ.get("WARM_S", "1.5"))
 a_split = os.environ.get("A_SPLIT", "1") != "0"
+only = os.environ.get("ONLY")  # comma-separated call names
 for name, probs in calls.items():
+    if only and name not in only.split(","):
+        continue
     ps = []
     flops = 0
     for prob in probs:  # (M, N, K[, act]): act 1 = SiLU, 2 = GELU-tanh, with bias, as the model's MLP-up epilogues
