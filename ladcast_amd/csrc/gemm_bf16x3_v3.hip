@@ -557,8 +557,19 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
         if (score > best * (34 - 1) / 33 && gd > best) best = gd;
       }
     }
+    long long few = 0;  // few tiles (the 84-column output head: 15 tiles): aligned split-K over more workgroups
+    if (same_kt && best < 160) {
+      const int kt = a.pr[0].kt;
+      for (int sfac = 8; sfac >= 2; --sfac)
+        if (kt % sfac == 0 && kt / sfac >= 8 && tiles * sfac <= CUS) {
+          few = tiles * sfac;
+          break;
+        }
+    }
     if (best >= 160) {
       G = best;
+    } else if (few > 0) {
+      G = few;  // measured on 1800 x 84 x 1536: 24.7 us at the stream-K default (36 ranges), 18.0 at 90
     } else {
       const double kt_avg = static_cast<double>(U) / static_cast<double>(tiles);
       long long umin = static_cast<long long>(sqrt(kt_avg * 8.0) + 0.5);

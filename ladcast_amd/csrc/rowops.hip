@@ -235,70 +235,81 @@ template <int LS_CPW>
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const float* __restrict__ add,
                                                   int add_rows, float* __restrict__ y, int rows, int N, int K, int kc,
-                                                  int act_in, int act_out) {
+                                                  int act_in, int act_out, int iters) {
+  // iters > 1 (host: only when K <= kc, one staged chunk): the workgroup stages act_in(x) once and walks `iters`
+  // consecutive column groups - fewer, longer-lived workgroups for the wide AdaLN modulation GEMV
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [rows_here][kc]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r_base = blockIdx.y * LS_ROWS;
   const int rows_here = rows - r_base < LS_ROWS ? rows - r_base : LS_ROWS;
-  const int n0 = (blockIdx.x * 4 + wave) * LS_CPW;
-  const float* wr[LS_CPW];
+  for (int it = 0; it < iters; ++it) {
+    const int n0 = ((blockIdx.x * iters + it) * 4 + wave) * LS_CPW;
+    const float* wr[LS_CPW];
 #pragma unroll
-  for (int j = 0; j < LS_CPW; ++j) {
-    const int n = n0 + j < N ? n0 + j : N - 1;  // clamped: columns past N are computed and dropped
-    wr[j] = W + static_cast<long long>(n) * K;
-  }
-  float acc[LS_CPW][LS_ROWS];
-#pragma unroll
-  for (int j = 0; j < LS_CPW; ++j)
-#pragma unroll
-    for (int i = 0; i < LS_ROWS; ++i) acc[j][i] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += kc) {
-    const int kn = K - k0 < kc ? K - k0 : kc;  // multiple of 4
-    const int nv4 = kn >> 2;
-    if (k0) __syncthreads();
-    for (int idx = threadIdx.x; idx < rows_here * nv4; idx += 256) {
-      const int i = idx / nv4, c = idx - i * nv4;
-      float4 xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
-      if (act_in != LDC_ACT_NONE) {
-        xv.x = ldc_apply_act(xv.x, act_in);
-        xv.y = ldc_apply_act(xv.y, act_in);
-        xv.z = ldc_apply_act(xv.z, act_in);
-        xv.w = ldc_apply_act(xv.w, act_in);
-      }
-      reinterpret_cast<float4*>(xs + i * kc)[c] = xv;
+    for (int j = 0; j < LS_CPW; ++j) {
+      const int n = n0 + j < N ? n0 + j : N - 1;  // clamped: columns past N are computed and dropped
+      wr[j] = W + static_cast<long long>(n) * K;
     }
-    __syncthreads();
-    if (n0 < N) {
-      for (int c = lane; c < nv4; c += 64) {
-        float4 w[LS_CPW];
+    float acc[LS_CPW][LS_ROWS];
 #pragma unroll
-        for (int j = 0; j < LS_CPW; ++j) w[j] = reinterpret_cast<const float4*>(wr[j] + k0)[c];
+    for (int j = 0; j < LS_CPW; ++j)
 #pragma unroll
-        for (int i = 0; i < LS_ROWS; ++i) {
-          if (i < rows_here) {
-            const float4 xv = reinterpret_cast<const float4*>(xs + i * kc)[c];
+      for (int i = 0; i < LS_ROWS; ++i) acc[j][i] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += kc) {
+      const int kn = K - k0 < kc ? K - k0 : kc;  // multiple of 4
+      const int nv4 = kn >> 2;
+      if (it == 0) {
+        if (k0) __syncthreads();
+        for (int idx = threadIdx.x; idx < rows_here * nv4; idx += 256) {
+          const int i = idx / nv4, c = idx - i * nv4;
+          float4 xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
+          if (act_in != LDC_ACT_NONE) {
+            xv.x = ldc_apply_act(xv.x, act_in);
+            xv.y = ldc_apply_act(xv.y, act_in);
+            xv.z = ldc_apply_act(xv.z, act_in);
+            xv.w = ldc_apply_act(xv.w, act_in);
+          }
+          reinterpret_cast<float4*>(xs + i * kc)[c] = xv;
+        }
+        __syncthreads();
+      }
+      if (n0 < N) {
+#pragma unroll 2
+        for (int c = lane; c < nv4; c += 64) {
+          float4 w[LS_CPW];
 #pragma unroll
-            for (int j = 0; j < LS_CPW; ++j) acc[j][i] += (w[j].x * xv.x + w[j].y * xv.y) + (w[j].z * xv.z + w[j].w * xv.w);
+          for (int j = 0; j < LS_CPW; ++j) {  // weights are streamed once: non-temporal
+            typedef float ls_f32x4 __attribute__((ext_vector_type(4)));
+            const ls_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const ls_f32x4*>(wr[j] + k0) + c);
+            w[j] = make_float4(t.x, t.y, t.z, t.w);
+          }
+#pragma unroll
+          for (int i = 0; i < LS_ROWS; ++i) {
+            if (i < rows_here) {
+              const float4 xv = reinterpret_cast<const float4*>(xs + i * kc)[c];
+#pragma unroll
+              for (int j = 0; j < LS_CPW; ++j) acc[j][i] += (w[j].x * xv.x + w[j].y * xv.y) + (w[j].z * xv.z + w[j].w * xv.w);
+            }
           }
         }
       }
     }
-  }
-  if (n0 >= N) return;
+    if (n0 >= N) continue;
 #pragma unroll
-  for (int j = 0; j < LS_CPW; ++j) {
-    const int n = n0 + j;
+    for (int j = 0; j < LS_CPW; ++j) {
+      const int n = n0 + j;
 #pragma unroll
-    for (int i = 0; i < LS_ROWS; ++i) {
-      const float sum = wave_sum(acc[j][i]);
-      const int r = r_base + i;
-      if (lane == 0 && i < rows_here && n < N) {
-        float v = sum + (bias ? bias[n] : 0.f);
-        v = ldc_apply_act(v, act_out);
-        if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
-        y[static_cast<long long>(r) * N + n] = v;
+      for (int i = 0; i < LS_ROWS; ++i) {
+        const float sum = wave_sum(acc[j][i]);
+        const int r = r_base + i;
+        if (lane == 0 && i < rows_here && n < N) {
+          float v = sum + (bias ? bias[n] : 0.f);
+          v = ldc_apply_act(v, act_out);
+          if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
+          y[static_cast<long long>(r) * N + n] = v;
+        }
       }
     }
   }
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ add, int add_rows,
                                                            float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
-                                                           int act_out) {
-  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out);
+                                                           int act_out, int iters) {
+  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters);
 }
 
 // up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears in one launch: blockIdx.z picks the problem
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(256) void linear_small_grouped_kernel(LSGroup g) {
   const ldc_linear_small_problem& q = g.p[blockIdx.z];
   if (static_cast<int>(blockIdx.x) * 4 >= q.N || static_cast<int>(blockIdx.y) * LS_ROWS >= q.rows) return;  // block-uniform
   const int kc = q.K < LS_KC ? q.K : LS_KC;
-  linear_small_body<1>(q.x, q.x_rows, q.W, q.bias, q.add, q.add_rows, q.y, q.rows, q.N, q.K, kc, q.act_in, q.act_out);
+  linear_small_body<1>(q.x, q.x_rows, q.W, q.bias, q.add, q.add_rows, q.y, q.rows, q.N, q.K, kc, q.act_in, q.act_out, 1);
 }
 
 }  // namespace
@@ -439,13 +450,19 @@ extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, cons
   }
   const int row_groups = ldc_cdiv(rows, LS_ROWS);
   if (static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
-    dim3 grid(ldc_cdiv(N, 4 * LS_CPW_MAX), row_groups);
+    int iters = 1;
+    if (K <= LS_KC) {  // one staged chunk: walk several column groups per workgroup, keep >= 4 workgroups per CU
+      const long long groups = static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups;
+      iters = groups >= 2048 ? 4 : 1;  // measured (tools/gemv_bench.py, 38 D x D): 78 us at 1, 73 at 4, slower at 3 / 8 / 16
+      if (const char* e = getenv("LDC_LINEAR_SMALL_ITERS")) iters = atoi(e) > 0 ? atoi(e) : iters;  // measurement aid
+    }
+    dim3 grid(ldc_cdiv(ldc_cdiv(N, 4 * LS_CPW_MAX), iters), row_groups);
     hipLaunchKernelGGL(linear_small_kernel<LS_CPW_MAX>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W,
-                       bias, add, add_rows, y, rows, N, K, kc, act_in, act_out);
+                       bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters);
   } else {
     dim3 grid(ldc_cdiv(N, 4), row_groups);
     hipLaunchKernelGGL(linear_small_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add,
-                       add_rows, y, rows, N, K, kc, act_in, act_out);
+                       add_rows, y, rows, N, K, kc, act_in, act_out, 1);
   }
   return ldc_launch_status();
 }
