@@ -61,6 +61,14 @@ class AutoRegressive2DPipeline:
         shape = (batch_size, self.ar_model.config.out_channels, return_seq_len, *known_latents.shape[-2:])
         image = randn_tensor(shape, generator=generator, device=dev, dtype=self.ar_model.dtype).contiguous()
         known_latents = known_latents.to(dev)  # the reference discards this result (Q13); we keep it
+        if not do_edm_style:
+            raise NotImplementedError("Only EDM style is supported for now")
+        net, sch = self.ar_model, self.scheduler
+        if getattr(net, "use_hip_graph", False) and hasattr(net, "forward_launch_only") and getattr(sch, "launch_only", False):
+            image = self._graph_loop(net, sch, image, known_latents.contiguous(), timestamps, num_inference_steps, batch_size, dev)
+            if not return_dict:
+                return (image,)
+            return Fields2DPipelineOutput(fields=image)
         self.scheduler.set_timesteps(num_inference_steps)
         for t in self.scheduler.timesteps:
             if not do_edm_style:
@@ -72,3 +80,47 @@ class AutoRegressive2DPipeline:
         if not return_dict:
             return (image,)
         return Fields2DPipelineOutput(fields=image)
+
+    def _graph_loop(self, net, sch, image, known, timestamps, num_inference_steps, batch_size, dev):
+        """hipGraph of the whole scheduler loop (N forwards + N scheduler steps), as edm_AR_sampler does for its chunk: with this
+        build's scheduler every coefficient is a host scalar known before the first launch, so the loop is launches only.  Same
+        kernels and arguments as the eager loop (bit-identical samples); afterwards the scheduler object is left in the state
+        the eager loop leaves it in (step index N, last two x0 predictions)."""
+        sch.set_timesteps(num_inference_steps)
+        te = net.time_elapsed_embedding(timestamps)
+        c = sch.config
+        key = (tuple(image.shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in sch.sigmas.tolist()),
+               (c.solver_order, c.prediction_type, c.final_sigmas_type, c.euler_at_final, c.lower_order_final, c.sigma_data),
+               tuple(sorted(self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity())
+        cache = net.__dict__.setdefault("_pipeline_loop_graphs", {})
+        ent = cache.get(key)
+
+        def loop(img, kn, tsteps):
+            for t, t_dev in zip(sch.timesteps, tsteps):
+                x_in = sch.scale_model_input(img, t)
+                out = net.forward_launch_only(x_in, t_dev, kn, te)
+                img = sch.step(out, t, img, **self.scheduler_step_kwargs, return_dict=False)[0]
+            return img
+
+        if ent is None:
+            st_img, st_known = torch.empty_like(image), torch.empty_like(known)
+            st_img.copy_(image)
+            st_known.copy_(known)
+            tsteps = [t.to(dev).expand(batch_size).contiguous() for t in sch.timesteps]  # what the eager loop feeds the model
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up on the capture stream (per-stream workspaces)
+                loop(st_img, st_known, tsteps)
+            torch.cuda.synchronize()
+            sch.set_timesteps(num_inference_steps)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                st_out = loop(st_img, st_known, tsteps)
+            ent = (graph, st_img, st_known, st_out, tsteps, side, list(sch.model_outputs), sch.lower_order_nums, sch._step_index)
+            cache[key] = ent
+        graph, st_img, st_known, st_out = ent[:4]
+        st_img.copy_(image)
+        st_known.copy_(known)
+        graph.replay()
+        sch.model_outputs, sch.lower_order_nums, sch._step_index = list(ent[6]), ent[7], ent[8]
+        return st_out.clone()

@@ -22,6 +22,8 @@ from .. import hip
 class EDMDPMSolverMultistepScheduler:
     order = 1
 
+    launch_only = True  # every method is host scalars + kernel launches: a whole sampling loop can be captured into one hipGraph
+
     def __init__(
         self,
         sigma_min: float = 0.002,

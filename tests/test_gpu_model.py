@@ -92,6 +92,34 @@ def test_edm_chunk_graph_is_bitwise_equal_to_eager(tiny_pair):
     assert len(g.__dict__["_edm_chunk_graphs"]) == 2  # one graph per chunk shape: new timestamps / conditioning / noise replay it
 
 
+def test_pipeline_loop_graph_is_bitwise_equal_to_eager(tiny_pair):
+    """the diffusers-style loop (scale_model_input -> model -> scheduler.step, N times) captured as one hipGraph: bit-identical
+    samples for new noise / conditioning / timestamps, and the scheduler object ends in the state the eager loop leaves"""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    _, g = tiny_pair
+    outs, states = {}, {}
+    for mode in (False, True, True):
+        g.enable_hip_graph(mode)
+        pipe = AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())
+        res = []
+        for seed, stamp, scale in ((0, 2018010100, 1.0), (1, 2019063012, 0.5)):
+            gen = [torch.Generator().manual_seed(seed + k) for k in range(2)]
+            res.append(pipe(batch_size=2, return_seq_len=4, known_latents=(synth_known(2) * scale).cuda(), timestamps=torch.tensor([stamp]).cuda(),
+                            generator=gen, num_inference_steps=5, return_dict=False)[0].clone())
+        outs.setdefault(mode, []).append(res)
+        sch = pipe.scheduler
+        states.setdefault(mode, []).append((sch._step_index, sch.lower_order_nums, [m.clone() for m in sch.model_outputs]))
+    g.enable_hip_graph(False)
+    for a, b, c in zip(outs[False][0], outs[True][0], outs[True][1]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert not torch.equal(outs[False][0][0], outs[False][0][1])
+    (i0, l0, m0), (i1, l1, m1) = states[False][0], states[True][1]
+    assert (i0, l0) == (i1, l1) == (5, 2) and all(torch.equal(x, y) for x, y in zip(m0, m1))
+    assert len(g.__dict__["_pipeline_loop_graphs"]) == 1
+
+
 def test_checkpoint_folder_loads_into_the_hip_path(tiny_pair, tmp_path):
     """a diffusers-layout folder (sharded here) written from the oracle's weights loads through
     ``from_pretrained`` and runs on the HIP path with the same result, bit for bit, as the model it was written from; the AR
