@@ -149,7 +149,7 @@ def _unsplit(buf, rows, cols):
 
 
 @pytest.mark.parametrize("M,N,K", [(2250, 1536, 1536), (450, 4608, 1536), (2250, 1536, 7680), (300, 264, 160), (5000, 6144, 1536), (1, 8, 32),
-                                   (37, 200, 96), (18000, 1536, 1536)])
+                                   (37, 200, 96), (18000, 1536, 1536), (4500, 1536, 2048), (2250, 1528, 1024)])
 def test_gemm_bf16x3_split_activation_formats(hip, M, N, K):
     """LDC_GEMM_A_SPLIT: activations pre-split by a producer give the same product (the split is the same operation,
     moved; the 16x16x32 kernel that serves this format sums in a different order than the 32x32x16 one, hence 1e-6
