@@ -71,6 +71,18 @@ def dcae_workload(args):
             torch.cuda.synchronize(); td = (time.perf_counter() - t0) / n
             res[f"gpu_{prec}_{frames}"] = dict(encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2), encode_tflops=round(0.695 * frames / te, 1),
                                                decode_tflops=round(0.7814 * frames / td, 1))
+            if prec == "bf16x3" and frames <= g.GRAPH_MAX_FRAMES:  # the same through one hipGraph per direction (launch-bound sizes)
+                g.enable_hip_graph(True)
+                z = g.encode(x, static_conditioning_tensor=st).latent; g.decode(z); torch.cuda.synchronize()
+                t0 = time.perf_counter(); n = 5
+                for _ in range(n): z = g.encode(x, static_conditioning_tensor=st).latent
+                torch.cuda.synchronize(); te = (time.perf_counter() - t0) / n
+                t0 = time.perf_counter()
+                for _ in range(n): g.decode(z)
+                torch.cuda.synchronize(); td = (time.perf_counter() - t0) / n
+                g.enable_hip_graph(False)
+                res[f"gpu_{prec}_graph_{frames}"] = dict(encode_ms=round(te * 1e3, 2), decode_ms=round(td * 1e3, 2), encode_tflops=round(0.695 * frames / te, 1),
+                                                         decode_tflops=round(0.7814 * frames / td, 1))
     if args.cpu_forwards > 0:
         from oracle.dcae import AutoencoderDC as OracleAE  # cpu_baseline leg only
 
@@ -265,7 +277,7 @@ def main():
     if args.decode:  # end-to-end: IC field -> encode -> AR chunks -> decode (roll_out_serial's decoded-field mode)
         from ladcast_amd.models import AutoencoderDC
 
-        ae = AutoencoderDC.from_config(CONFIG_DCAE_84).to(dev).eval().set_gemm_precision(args.precision)
+        ae = AutoencoderDC.from_config(CONFIG_DCAE_84).to(dev).eval().set_gemm_precision(args.precision).enable_hip_graph(not args.no_graph)
         g_ = torch.Generator().manual_seed(3)
         field = torch.randn(84, 1, 120, 240, generator=g_)
         static = torch.randn(5, 120, 240, generator=g_)

@@ -404,6 +404,7 @@ def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
 
 
 _rla_ws = {}
+_rla_keep = []
 
 
 def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
@@ -411,6 +412,8 @@ def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
     need = int(lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups))
     key = (str(qkv.device), torch.cuda.current_stream(qkv.device).cuda_stream)
     if key not in _rla_ws or _rla_ws[key].numel() * 4 < need:
+        if key in _rla_ws:
+            _rla_keep.append(_rla_ws[key])  # a captured hipGraph may still point at the smaller one
         _rla_ws[key] = torch.empty(need // 4 + 1, device=qkv.device, dtype=torch.float32)
     ws = _rla_ws[key]
     _check(lib.ldc_relu_linear_attn_nhwc(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, _p(ws), ws.numel() * 4, _stream()),

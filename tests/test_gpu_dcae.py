@@ -249,6 +249,32 @@ def test_dcae_bf16x3_mode_matches_oracle():
     assert rel_l2(g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent.cpu(), zo) < 2e-5  # switching back re-packs
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_dcae_hip_graph_is_bitwise_equal_to_eager(prec):
+    """enable_hip_graph: one captured graph per (direction, shape), replayed with new inputs - the same launches, so encode and
+    decode are bit-identical to eager launching; a second shape and a precision switch get their own graphs"""
+    _, g = _pair(tiny_dcae_config())
+    g.set_gemm_precision(prec)
+    cases = [(synth_field(2, 8, 48, 64).cuda(), synth_field(1, 5, 48, 64, seed=1).cuda()), (synth_field(2, 8, 48, 64, seed=5).cuda() * 0.5, synth_field(1, 5, 48, 64, seed=6).cuda()),
+             (synth_field(1, 8, 32, 64, seed=7).cuda(), synth_field(1, 5, 32, 64, seed=8).cuda())]
+    runs = {}
+    for mode in (False, True, True):
+        g.enable_hip_graph(mode)
+        res = []
+        for f, st in cases:
+            z = g.encode(f, static_conditioning_tensor=st).latent
+            res.append((z.clone(), g.decode(z).sample.clone(), g.decode(z, return_static=True).sample.clone()))
+        runs.setdefault(mode, []).append(res)
+        if mode:
+            assert len(g._graphs) == 6  # (encode, decode, decode with static) x two shapes
+    g.enable_hip_graph(False)
+    assert g._graphs == {}
+    for a, b, c in zip(runs[False][0], runs[True][0], runs[True][1]):
+        for x, y, z in zip(a, b, c):
+            assert torch.equal(x, y) and torch.equal(x, z)
+    assert runs[False][0][0][2].shape[1] == runs[False][0][0][1].shape[1] + 5
+
+
 def test_full_dcae_bf16x3_single_frame_matches_oracle():
     from oracle.dcae import CONFIG_DCAE_84
 
