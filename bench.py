@@ -208,8 +208,8 @@ def cpu_baseline(cfg_name, R, n_forwards):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="375M", choices=list(CONFIGS))
     ap.add_argument("--members-per-gpu", type=int, default=1)
     ap.add_argument("--return-seq-len", type=int, default=4)
