@@ -358,14 +358,14 @@ extern "C" int ldc_attn_fwd_bf16x3(const float* Q, const float* K, const float* 
   AttnArgs p{Q, K, V, O, S, H, ld_qkv, ldo, qkv_bs, o_bs, 0.08838834764831845f * 1.4426950408889634f};
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bf16x3_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bf16x3_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   // few workgroups (one member per GPU): split the keys over two 4-wave groups so every SIMD has two waves;
   // enough workgroups: two 4-wave workgroups per CU do the same job without the merge
   const long long nwg = static_cast<long long>(p.nq) * H * B;

@@ -731,14 +731,14 @@ extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, i
   p.S = S; p.H = H; p.ldo = ldo; p.o_bs = o_bs;
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   const long long nwg = static_cast<long long>(p.nq) * H * B;
   if (nwg <= 256) {
     hipLaunchKernelGGL(attn_fwd_packed_kernel<2>, grid, dim3(512), 2 * GROUP_LDS, static_cast<hipStream_t>(stream), p);

@@ -229,12 +229,12 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   const size_t lds = 2 * STAGE * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }

@@ -838,12 +838,12 @@ int launch_dma(const ldc_gemm_problem* problems, int n, void* workspace, long lo
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = (tiles <= LDC_GEMM_COUNTER_BYTES / 4 - 16) ? static_cast<unsigned*>(workspace) : nullptr;  // last 64 B: zero page
   const size_t lds = NSTAGE * STAGE_B;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<BM, APK, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<BM, APK, CONV>), dim3(a.G), dim3(BM * 2), lds, s, a);
   int st = ldc_launch_status();
@@ -868,7 +868,8 @@ int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* w
     tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
   }
   bool small = tiles256 <= 128;  // measured cross-over (tools/gemm_bench.py, both heights forced): about half the CUs
-  if (const char* e = getenv("LDC_BF16X3_BM")) small = (atoi(e) == 128);
+  static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
+  if (force_bm) small = (atoi(force_bm) == 128);
   const bool apk = (problems[0].d.flags & LDC_GEMM_A_SPLIT) != 0;
   if (apk)
     return small ? launch_dma<128, true>(problems, n, workspace, workspace_bytes, stream)

@@ -578,8 +578,9 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
       if (gmax < G) G = gmax;
     }
   }
-  if (const char* e = getenv("LDC_BF16X3_G")) {  // measurement aid: force the number of unit ranges
-    const long long g_ = atoll(e);
+  static const char* const force_g = getenv("LDC_BF16X3_G");  // measurement aid (read once): force the number of unit ranges
+  if (force_g) {
+    const long long g_ = atoll(force_g);
     if (g_ > 0 && g_ <= CUS) G = g_;
   }
   if (U < G) G = U;
@@ -596,12 +597,12 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL(gemm_bf16x3_v3_kernel<BM>, dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
   return ldc_launch_status();
 }
@@ -623,7 +624,8 @@ int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* wo
   // half-height tiles while 256-row tiles would not fill the chip twice over (both heights run 8 waves here, so the
   // half-height tile costs no MFMA efficiency, only twice the W traffic per FLOP); LDC_BF16X3_BM forces one
   bool small = tiles256 < 400;  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
-  if (const char* e = getenv("LDC_BF16X3_BM")) small = (atoi(e) == 128);
+  static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
+  if (force_bm) small = (atoi(force_bm) == 128);
   return small ? launch_v3<128>(problems, n, workspace, workspace_bytes, stream)
                : launch_v3<256>(problems, n, workspace, workspace_bytes, stream);
 }

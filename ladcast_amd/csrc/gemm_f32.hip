@@ -227,12 +227,12 @@ extern "C" int ldc_gemm_bias_act(const float* A, const float* W, const float* bi
   GemmArgs p{A, W, bias, gate, R, C, *d, 0, 0, 0, 0};
   dim3 grid(ldc_cdiv(d->N, BN), ldc_cdiv(d->M, BM), d->batch);
   const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }
@@ -265,12 +265,12 @@ extern "C" int ldc_sphere_conv_nhwc(const float* X, const float* Wt, const float
   GemmArgs p{X, Wt, bias, nullptr, R, Y, d, H, W, cin, ksize};
   dim3 grid(ldc_cdiv(cout, BN), ldc_cdiv(M, BM), 1);
   const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }

@@ -531,14 +531,14 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(2 * STAGE_FLOATS * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_bf16x3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES_B);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (split_bf16) hipLaunchKernelGGL(gemm_streamk_bf16x3_kernel, dim3(a.G), dim3(256), lds, s, a);
   else hipLaunchKernelGGL(gemm_streamk_kernel, dim3(a.G), dim3(256), lds, s, a);

@@ -440,21 +440,22 @@ extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, cons
   const int kc = K < LS_KC ? K : LS_KC;
   const int rows_max = rows < LS_ROWS ? rows : LS_ROWS;
   const size_t lds = static_cast<size_t>(rows_max) * kc * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_kernel<LS_CPW_MAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   const int row_groups = ldc_cdiv(rows, LS_ROWS);
   if (static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
     int iters = 1;
     if (K <= LS_KC) {  // one staged chunk: walk several column groups per workgroup, keep >= 4 workgroups per CU
       const long long groups = static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups;
       iters = groups >= 2048 ? 4 : 1;  // measured (tools/gemv_bench.py, 38 D x D): 78 us at 1, 73 at 4, slower at 3 / 8 / 16
-      if (const char* e = getenv("LDC_LINEAR_SMALL_ITERS")) iters = atoi(e) > 0 ? atoi(e) : iters;  // measurement aid
+      static const char* const force_iters = getenv("LDC_LINEAR_SMALL_ITERS");  // measurement aid, read once
+      if (force_iters && atoi(force_iters) > 0) iters = atoi(force_iters);
     }
     dim3 grid(ldc_cdiv(ldc_cdiv(N, 4 * LS_CPW_MAX), iters), row_groups);
     hipLaunchKernelGGL(linear_small_kernel<LS_CPW_MAX>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W,
@@ -494,12 +495,12 @@ extern "C" int ldc_linear_small_grouped(const ldc_linear_small_problem* problems
     const int r = q.rows < LS_ROWS ? q.rows : LS_ROWS;
     rows_max = r > rows_max ? r : rows_max;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_small_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LS_ROWS * LS_KC * static_cast<int>(sizeof(float)));
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   const size_t lds = static_cast<size_t>(rows_max) * kc_max * sizeof(float);
   hipLaunchKernelGGL(linear_small_grouped_kernel, dim3(gx, gy, n), dim3(256), lds, static_cast<hipStream_t>(stream), g);
   return ldc_launch_status();

@@ -61,13 +61,14 @@ def edm_AR_sampler(
     # solver are known on the host before the first launch, so one replay per chunk replaces ~3000 launches and the
     # copies around 39 per-forward graphs (2.5 % of the chunk), and the host's speed stops mattering (8 ranks on one box).
     # Used when the model runs in hipGraph mode and exposes its launch-only forward; same kernels, same numbers.
-    chunk_graph = bool(getattr(net, "use_hip_graph", False)) and hasattr(net, "forward_launch_only")
+    chunk_graph = bool(getattr(net, "use_hip_graph", False)) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs")
     if chunk_graph:
         te = net.time_elapsed_embedding(timestamps)  # eager, cached per chunk; the graph reads its persistent buffer
         plan_id = net.plan_identity()  # a re-packed / re-loaded model gets new graphs
         key = (tuple(shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in t_steps.tolist()),
                None if te is None else (te.data_ptr(), tuple(te.shape)), str(device), plan_id)
-        cache = net.__dict__.setdefault("_edm_chunk_graphs", {})
+        key = ("edm_chunk",) + key
+        cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
         if ent is None:
             st_lat, st_known, st_out = torch.empty_like(latents), torch.empty_like(known), torch.empty(shape, device=device, dtype=torch.float32)

@@ -64,7 +64,7 @@ class AutoRegressive2DPipeline:
         if not do_edm_style:
             raise NotImplementedError("Only EDM style is supported for now")
         net, sch = self.ar_model, self.scheduler
-        if getattr(net, "use_hip_graph", False) and hasattr(net, "forward_launch_only") and getattr(sch, "launch_only", False):
+        if getattr(net, "use_hip_graph", False) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs") and getattr(sch, "launch_only", False):
             image = self._graph_loop(net, sch, image, known_latents.contiguous(), timestamps, num_inference_steps, batch_size, dev)
             if not return_dict:
                 return (image,)
@@ -92,7 +92,8 @@ class AutoRegressive2DPipeline:
         key = (tuple(image.shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in sch.sigmas.tolist()),
                (c.solver_order, c.prediction_type, c.final_sigmas_type, c.euler_at_final, c.lower_order_final, c.sigma_data),
                tuple(sorted(self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity())
-        cache = net.__dict__.setdefault("_pipeline_loop_graphs", {})
+        key = ("pipeline_loop",) + key
+        cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
 
         def loop(img, kn, tsteps):

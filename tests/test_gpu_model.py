@@ -84,12 +84,13 @@ def test_edm_chunk_graph_is_bitwise_equal_to_eager(tiny_pair):
             res.append(ensemble_AR_sampler(pipe, n, 4, 3, known_latents=known.cuda(), timestamps=torch.tensor([stamp]).cuda(), sampler_type="edm",
                                            device="cuda", **kw).clone())
         outs.setdefault(mode, []).append(res)
+    assert sum(1 for k in g._graphs if k[0] == "edm_chunk") == 2  # one graph per chunk shape: new timestamps / conditioning / noise replay it
     g.enable_hip_graph(False)
+    assert g._graphs == {}
     eager, first, second = outs[False][0], outs[True][0], outs[True][1]
     for a, b, c in zip(eager, first, second):
         assert torch.equal(a, b) and torch.equal(a, c)  # capture pass and pure replays
     assert not torch.equal(eager[0], eager[1])
-    assert len(g.__dict__["_edm_chunk_graphs"]) == 2  # one graph per chunk shape: new timestamps / conditioning / noise replay it
 
 
 def test_pipeline_loop_graph_is_bitwise_equal_to_eager(tiny_pair):
@@ -117,7 +118,12 @@ def test_pipeline_loop_graph_is_bitwise_equal_to_eager(tiny_pair):
     assert not torch.equal(outs[False][0][0], outs[False][0][1])
     (i0, l0, m0), (i1, l1, m1) = states[False][0], states[True][1]
     assert (i0, l0) == (i1, l1) == (5, 2) and all(torch.equal(x, y) for x, y in zip(m0, m1))
-    assert len(g.__dict__["_pipeline_loop_graphs"]) == 1
+    g.enable_hip_graph(True)
+    AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())(batch_size=2, return_seq_len=4, known_latents=synth_known(2).cuda(), timestamps=torch.tensor([2018010100]).cuda(),
+                                                                  num_inference_steps=5)
+    assert sum(1 for k in g._graphs if k[0] == "pipeline_loop") == 1
+    g.enable_hip_graph(False)
+    assert g._graphs == {}
 
 
 def test_checkpoint_folder_loads_into_the_hip_path(tiny_pair, tmp_path):
