@@ -6,6 +6,11 @@ dataloader/ar_dataloder.py:11-18).
 The xarray dataset access of ``roll_out_serial`` is factored behind plain tensors
 (the tensor contract of SURVEY §8 A0); the arithmetic and the ordering of every
 tensor operation follow the reference line by line.
+
+PINNED (tests/test_oracle_reference_pins.py, fixtures from the reference's own code via
+tests/golden/make_golden.py::sampler_fixtures): edm_AR_sampler, AutoRegressive2DPipeline.__call__,
+ensemble_AR_sampler, the latent transforms.  roll_out_serial / decode_latent_ens (xarray-bound in the
+reference) are restatements checked by structure only.
 """
 from __future__ import annotations
 

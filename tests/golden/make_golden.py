@@ -101,6 +101,115 @@ def scoring_fixtures():
     np.savez_compressed(os.path.join(HERE, "scoring_ref.npz"), **out)
 
 
+def _ref_functions(path, names, ns, class_methods=None):
+    """compile the named top-level functions (and, for class_methods = {class: [method, ...]}, those methods as plain functions
+    named <class>_<method>) of a reference file from its syntax tree into the namespace ns - the rest of the file (its
+    third-party imports) is never executed"""
+    import ast
+
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in body} == set(names), (path, names)
+    for cls, methods in (class_methods or {}).items():
+        cdef = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+        for m in cdef.body:
+            if isinstance(m, ast.FunctionDef) and m.name in methods:
+                m.name = f"{cls}_{m.name}"
+                body.append(m)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+class ToyNet:
+    """elementwise stand-in for the noise-prediction model (same call signature, `.config.out_channels`, `.dtype`,
+    `.device`): no matrix product and no transcendental, so the sampler outputs are reproducible bit for bit on any CPU"""
+
+    def __init__(self, channels, device="cpu"):
+        from types import SimpleNamespace
+
+        self.config = SimpleNamespace(out_channels=channels)
+        self.dtype = torch.float32
+        self.device = torch.device(device)
+
+    def __call__(self, x, t, known, time_elapsed=None, return_dict=True):
+        from types import SimpleNamespace
+
+        t = t.reshape(-1, 1, 1, 1, 1).to(x.dtype)
+        ts = 0.0 if time_elapsed is None else (time_elapsed.reshape(-1, 1, 1, 1, 1) % 100).to(x.dtype) * 0.01
+        y = 0.75 * x - 0.25 * x / (1.0 + x.abs()) + 0.5 * known.mean(dim=2, keepdim=True) + 0.0625 * t + ts  # bounded, IEEE-exact ops only
+        return SimpleNamespace(sample=y) if return_dict else (y,)
+
+
+def sampler_fixtures():
+    """Outputs of the reference's OWN sampler / driver / transform / calendar code (compiled from its syntax tree) with the
+    oracle's scheduler and an elementwise toy network plugged in: pins the restated loops (oracle.pipelines) and the calendar
+    embedding (oracle.ar_model) to the reference's arithmetic.  The scheduler class itself is third-party (diffusers) and stays
+    unpinned; here it is the same object on both sides."""
+    import copy
+    import math
+    from datetime import datetime
+    from types import SimpleNamespace
+    from typing import Dict, List, Optional, Tuple, Union
+
+    from einops import repeat
+
+    from oracle.layers import randn_tensor
+    from oracle.scheduler import EDMDPMSolverMultistepScheduler
+
+    R = "/root/reference/ladcast/"
+    typing_ns = {"torch": torch, "np": np, "math": math, "copy": copy, "datetime": datetime, "Optional": Optional, "Union": Union, "List": List,
+                 "Dict": Dict, "Tuple": Tuple}
+    ns = dict(typing_ns, randn_tensor=randn_tensor, repeat=repeat, Fields2DPipelineOutput=lambda fields: SimpleNamespace(fields=fields))
+    _ref_functions(R + "pipelines/edm_sampler.py", ["edm_AR_sampler"], ns)
+    _ref_functions(R + "pipelines/utils.py", ["ensemble_AR_sampler"], ns)
+    _ref_functions(R + "pipelines/pipeline_AR.py", [], ns, class_methods={"AutoRegressive2DPipeline": ["__call__"]})
+    emb = _ref_functions(R + "models/embeddings.py", ["convert_int_to_datetime", "compute_year_progress", "timestamp_tensor_to_time_elapsed",
+                                                      "get_year_sincos_embedding"], dict(typing_ns))
+    tr = _ref_functions(R + "dataloader/utils.py", ["normalize_transform_3D", "inverse_normalize_transform_3D", "get_transform_3D", "get_inv_transform_3D"],
+                        dict(typing_ns))
+
+    out = {}
+    C, H, W = 6, 5, 8
+    net = ToyNet(C)
+    g = torch.Generator().manual_seed(21)
+    known1 = torch.randn(1, C, 1, H, W, generator=g) * 0.5
+    known3 = torch.randn(3, C, 2, H, W, generator=g) * 0.5
+    out["known1"], out["known3"] = known1.numpy(), known3.numpy()
+    ts = torch.tensor([2018010100])
+
+    class RefPipe:  # the attributes AutoRegressive2DPipeline.__call__ and ensemble_AR_sampler read
+        def __init__(self):
+            self.ar_model, self.scheduler, self.scheduler_step_kwargs, self._execution_device = net, EDMDPMSolverMultistepScheduler(), {}, torch.device("cpu")
+
+        def __call__(self, **kw):
+            return ns["AutoRegressive2DPipeline___call__"](self, **kw)
+
+    gens = lambda n: [torch.Generator("cpu").manual_seed(k) for k in range(n)]  # noqa: E731
+    out["edm_n5"] = ns["edm_AR_sampler"](net, EDMDPMSolverMultistepScheduler(), batch_size=3, return_seq_len=2, num_inference_steps=5, known_latents=known3,
+                                         timestamps=ts, generator=gens(3)).numpy()
+    out["edm_n1"] = ns["edm_AR_sampler"](net, EDMDPMSolverMultistepScheduler(), batch_size=1, return_seq_len=4, num_inference_steps=1, known_latents=known1,
+                                         timestamps=None, generator=gens(1)).numpy()
+    out["pipe_n6"] = RefPipe()(batch_size=3, return_seq_len=2, known_latents=known3, timestamps=ts, generator=gens(3), num_inference_steps=6, return_dict=False)[0].numpy()
+    out["pipe_n20"] = RefPipe()(batch_size=1, return_seq_len=1, known_latents=known1, timestamps=ts, generator=gens(1), num_inference_steps=20).fields.numpy()
+    out["ens_edm"] = ns["ensemble_AR_sampler"](RefPipe(), 5, 3, 4, known_latents=known1, timestamps=ts, batch_size=2, sampler_type="edm").numpy()
+    out["ens_pipe"] = ns["ensemble_AR_sampler"](RefPipe(), 4, 2, 4, known_latents=known1, timestamps=ts, batch_size=3, sampler_type="pipeline").numpy()
+
+    stamps = torch.tensor([2018010100, 2018063012, 2020022906, 2019123118, 2020123118])
+    out["stamps"] = stamps.numpy()
+    out["year_progress"] = emb["timestamp_tensor_to_time_elapsed"](stamps).numpy()
+    out["year_emb_256"] = emb["get_year_sincos_embedding"](stamps, 256).numpy()
+    out["year_emb_10"] = emb["get_year_sincos_embedding"](stamps[:2], 10, max_period=100).numpy()
+
+    x = torch.randn(C, 3, H, W, generator=g) * 3 + 1
+    mean, std = (torch.randn(C, generator=g)).tolist(), (torch.rand(C, generator=g) + 0.3).tolist()
+    out["tr_x"], out["tr_mean"], out["tr_std"] = x.numpy(), np.array(mean, dtype=np.float64), np.array(std, dtype=np.float64)
+    args = {"mean": mean, "std": std, "target_std": 0.5}
+    out["tr_fwd"] = tr["get_transform_3D"]("normalize", args)(x).numpy()
+    out["tr_inv"] = tr["get_inv_transform_3D"]("normalize", args)(x).numpy()
+    out["tr_fwd_nots"] = tr["get_transform_3D"]("normalize", {"mean": mean, "std": std})(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "sampler_ref.npz"), **out)
+
+
 def oracle_pins():
     from tests.synth import tiny_ar_config, tiny_dcae_config, make_ar, make_dcae, synth_known, synth_field
 
@@ -136,5 +245,6 @@ def oracle_pins():
 if __name__ == "__main__":
     sphere_conv_fixtures()
     scoring_fixtures()
+    sampler_fixtures()
     oracle_pins()
     print("wrote", sorted(os.listdir(HERE)))
