@@ -2,7 +2,8 @@
 (models/LaDCast_3D_model.py:64-1071, models/embeddings.py:38-59,252-327,422-520).
 
 Module / parameter names equal the reference's so state dicts interchange.
-The diffusers layer pieces come from ``oracle.layers`` (PARITY UNPINNED).
+The diffusers layer pieces come from ``oracle.layers`` (PARITY UNPINNED); every forward in THIS file is PINNED to the reference's
+own forward code (tests/test_oracle_reference_pins.py::test_transformer_forward_equals_the_reference_forward_code).
 """
 from __future__ import annotations
 

@@ -3,7 +3,8 @@ for the shipped configuration (configs/DC_AE_84_pretrain.yaml:1-48): no timestep
 conditioning (``temb_channels=None``), ``rms_norm``, pixel-(un)shuffle sampling.
 
 Parameter names equal the reference's.  RMSNorm comes from
-``oracle.layers`` (PARITY UNPINNED); SphereConv2d from ``oracle.sphere_conv`` (PINNED).
+``oracle.layers`` (PARITY UNPINNED); SphereConv2d from ``oracle.sphere_conv`` (PINNED); every forward in THIS file is PINNED to the
+reference's own forward code (tests/test_oracle_reference_pins.py::test_dcae_forward_equals_the_reference_forward_code).
 """
 from __future__ import annotations
 

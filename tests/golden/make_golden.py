@@ -210,6 +210,259 @@ def sampler_fixtures():
     np.savez_compressed(os.path.join(HERE, "sampler_ref.npz"), **out)
 
 
+def _ref_classes(path, names, ns):
+    """compile the named top-level classes of a reference file from its syntax tree into ns (only classes whose definition
+    needs nothing but torch and what ns already holds)"""
+    import ast
+
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert {n.name for n in body} == set(names), (path, names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def piece_inputs():
+    """seeded inputs of the reference-owned building blocks (shared by the generator and tests/test_oracle_reference_pins.py)"""
+    g = torch.Generator().manual_seed(31)
+    return {
+        "down_x": torch.randn(2, 8, 6, 8, generator=g), "up_x": torch.randn(2, 16, 3, 4, generator=g), "proj_x": torch.randn(2, 96, 6, 8, generator=g),
+        "attn_x": torch.randn(2, 64, 6, 8, generator=g), "patch_x": torch.randn(2, 12, 3, 5, 6, generator=g), "dec_z": torch.randn(2, 4, 3, 2, 3, generator=g),
+    }
+
+
+def piece_modules():
+    """the oracle's modules for those blocks with seeded weights (torch CPU RNG: the same numbers on every machine)"""
+    from oracle import ar_model as OM
+    from oracle import dcae as OD
+
+    torch.manual_seed(77)
+    m = {
+        "down": OD.DCDownBlock2d(8, 16), "up": OD.DCUpBlock2d(16, 8), "proj": OD.SanaMultiscaleAttentionProjection(32, 1, 5),
+        "attn": OD.SanaMultiscaleLinearAttention(64, 64, attention_head_dim=32, kernel_sizes=(5,)), "patch": OM.HunyuanVideoPatchEmbed((1, 1, 1), 12, 40),
+    }
+    with torch.no_grad():
+        m["attn"].norm_out.weight.uniform_(0.5, 1.5)
+        m["attn"].norm_out.bias.uniform_(-0.5, 0.5)
+    return {k: v.eval() for k, v in m.items()}
+
+
+class ToyDecoder:
+    """decode(z) -> object with .sample; elementwise + a channel repeat (for decode_latent_ens)"""
+
+    device = torch.device("cpu")
+
+    def decode(self, z):
+        from types import SimpleNamespace
+
+        return SimpleNamespace(sample=(z * 1.5 - 0.25).repeat_interleave(2, dim=1))
+
+
+def piece_fixtures():
+    """Outputs of the reference's own building-block classes that need nothing but torch and the (importable) SphereConv2d -
+    DCDownBlock2d, DCUpBlock2d, SanaMultiscaleAttentionProjection (models/DCAE.py:67-93,447-536), the ReLU linear-attention processor
+    SanaMultiscaleAttnProcessor2_0 + apply_linear_attention (models/DCAE.py:158-178,200-267) run on the oracle's parameter container,
+    HunyuanVideoPatchEmbed (models/embeddings.py:38-59), decode_latent_ens (pipelines/utils.py:51-80) - on seeded weights."""
+    import types
+    from typing import Optional, Tuple, Union
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from einops import rearrange
+
+    sys.path.insert(0, "/root/reference")
+    from ladcast.models.sphere_conv import SphereConv2d
+
+    R = "/root/reference/ladcast/"
+    ns = {"torch": torch, "nn": nn, "F": F, "Optional": Optional, "Tuple": Tuple, "Union": Union, "SphereConv2d": SphereConv2d,
+          "SanaMultiscaleLinearAttention": object}
+    _ref_classes(R + "models/DCAE.py", ["DCDownBlock2d", "DCUpBlock2d", "SanaMultiscaleAttentionProjection", "SanaMultiscaleAttnProcessor2_0"], ns)
+    _ref_functions(R + "models/DCAE.py", [], ns, class_methods={"SanaMultiscaleLinearAttention": ["apply_linear_attention"]})
+    emb = _ref_classes(R + "models/embeddings.py", ["HunyuanVideoPatchEmbed"], {"torch": torch, "nn": nn, "Union": Union, "Tuple": Tuple})
+    tr = _ref_functions(R + "dataloader/utils.py", ["inverse_normalize_transform_3D"], {"torch": torch})
+    pu = _ref_functions(R + "pipelines/utils.py", ["decode_latent_ens"], {"torch": torch, "Optional": Optional, "rearrange": rearrange,
+                                                                         "inverse_normalize_transform_3D": tr["inverse_normalize_transform_3D"]})
+    x, om = piece_inputs(), piece_modules()
+    out = {}
+    with torch.no_grad():
+        ref = ns["DCDownBlock2d"](8, 16, downsample=True, shortcut=True)
+        ref.load_state_dict(om["down"].state_dict(), strict=True)
+        out["down"] = ref(x["down_x"]).numpy()
+        ref = ns["DCUpBlock2d"](16, 8, interpolate=False, shortcut=True)
+        ref.load_state_dict(om["up"].state_dict(), strict=True)
+        out["up"] = ref(x["up_x"]).numpy()
+        ref = ns["SanaMultiscaleAttentionProjection"](32, 1, 5)
+        ref.load_state_dict(om["proj"].state_dict(), strict=True)
+        out["proj"] = ref(x["proj_x"]).numpy()
+        # the reference's processor + linear-attention method on the oracle's parameter container (the reference's own container
+        # class cannot be constructed: its norm comes from diffusers.get_normalization)
+        hybrid = om["attn"]
+        hybrid.norm_type, hybrid.nonlinearity = "rms_norm", nn.ReLU()
+        hybrid.apply_linear_attention = types.MethodType(ns["SanaMultiscaleLinearAttention_apply_linear_attention"], hybrid)
+        out["attn"] = ns["SanaMultiscaleAttnProcessor2_0"]()(hybrid, x["attn_x"]).numpy()
+        ref = emb["HunyuanVideoPatchEmbed"]((1, 1, 1), 12, 40)
+        ref.load_state_dict(om["patch"].state_dict(), strict=True)
+        out["patch"] = ref(x["patch_x"]).numpy()
+        mean, std = torch.linspace(-1, 1, 8), torch.linspace(0.5, 2, 8)
+        out["dec_all"] = pu["decode_latent_ens"](ToyDecoder(), x["dec_z"], mean, std).numpy()
+        out["dec_first"] = pu["decode_latent_ens"](ToyDecoder(), x["dec_z"], None, None, extract_first=1).numpy()
+    np.savez_compressed(os.path.join(HERE, "pieces_ref.npz"), **out)
+
+
+def dcae_forward_fixtures():
+    """The reference's own forward code of every DCAE class it defines - ResBlock, GLUMBConv, EfficientViTBlock, SanaMultiscaleLinearAttention
+    (+ processor, apply_linear_attention), DCDownBlock2d, DCUpBlock2d, Encoder, Decoder (models/DCAE.py:93-732) - bound onto the oracle's tiny
+    autoencoder (same attribute names, seeded weights).  The leaves it calls are torch modules, the oracle's RMSNorm (third-party in the
+    reference, unpinned) and the pinned SphereConv2d.  Flags the reference sets in its constructors are set here from the shipped config
+    (configs/DC_AE_84_pretrain.yaml: rms_norm, silu, pixel_(un)shuffle, shortcuts on)."""
+    import types
+    from typing import Optional, Tuple, Union
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from oracle import dcae as OD
+    from tests.synth import make_dcae, synth_field, tiny_dcae_config
+
+    R = "/root/reference/ladcast/models/DCAE.py"
+    ns = {"torch": torch, "nn": nn, "F": F, "Optional": Optional, "Tuple": Tuple, "Union": Union, "SanaMultiscaleLinearAttention": object}
+    _ref_classes(R, ["SanaMultiscaleAttnProcessor2_0"], ns)
+    methods = {"SanaMultiscaleLinearAttention": ["apply_linear_attention", "forward"], "GLUMBConv": ["forward"], "ResBlock": ["forward"],
+               "EfficientViTBlock": ["forward"], "DCDownBlock2d": ["forward"], "DCUpBlock2d": ["forward"], "Encoder": ["forward"], "Decoder": ["forward"]}
+    _ref_functions(R, [], ns, class_methods=methods)
+
+    ae = make_dcae(tiny_dcae_config())
+    shims = {
+        OD.SanaMultiscaleLinearAttention: dict(norm_type="rms_norm", nonlinearity=nn.ReLU(), norm_in=None, time_emb_porj=None,
+                                               processor=ns["SanaMultiscaleAttnProcessor2_0"]()),
+        OD.GLUMBConv: dict(nonlinearity=nn.SiLU(), norm_type="rms_norm", residual_connection=True),
+        OD.ResBlock: dict(norm_type="rms_norm", time_emb_porj=None),
+        OD.EfficientViTBlock: {}, OD.DCDownBlock2d: dict(downsample=True), OD.DCUpBlock2d: dict(interpolate=False),
+        OD.Encoder: dict(out_shortcut=True), OD.Decoder: dict(in_shortcut=True, conv_act=nn.ReLU()),
+    }
+    bound = 0
+    for mod in ae.modules():
+        for cls, attrs in shims.items():
+            if type(mod) is cls:
+                for k, v in attrs.items():
+                    object.__setattr__(mod, k, v)  # plain attributes (not registered sub-modules: the state dict stays the oracle's)
+                for meth in methods[cls.__name__]:
+                    object.__setattr__(mod, meth, types.MethodType(ns[f"{cls.__name__}_{meth}"], mod))
+                bound += 1
+    assert bound >= 12, bound
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        z = ae.encoder(torch.cat([f, st.expand(2, -1, -1, -1)], dim=1))  # AutoencoderDC.encode's cat (models/DCAE.py:988-989) then Encoder.forward
+        y = ae.decoder(z)
+    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy())
+
+
+def _strip_inner_imports(fn_node):
+    """drop `from ... import ...` statements inside a function body (the processor imports apply_rotary_emb at call time); the names
+    come from the namespace instead"""
+    import ast
+
+    class T(ast.NodeTransformer):
+        def visit_ImportFrom(self, node):
+            return ast.Pass()
+
+    return ast.fix_missing_locations(T().visit(fn_node))
+
+
+def ar_forward_fixtures():
+    """The reference's own forward code of every class it defines on the transformer path - LaDCastAttnProcessor2_0.__call__, HunyuanVideoAdaNorm,
+    the three token-refiner classes, LaDCastSingleTransformerBlock, LaDCastTransformerBlock, LaDCastTransformer3DModel.forward
+    (models/LaDCast_3D_model.py:64-566,833-1071), LaDCastRotaryPosEmbed_from_grid (models/embeddings.py:252-327) and get_year_sincos_embedding -
+    bound onto the oracle's tiny model (same attribute names, seeded weights).  The leaves they call are the oracle's restatements of the
+    diffusers layers (Attention container, AdaLayerNorm*, FeedForward, embeddings, apply_rotary_emb, get_1d_rotary_pos_embed: third-party,
+    unpinned) and torch.  What this pins is everything the reference itself wrote: token order, stream concatenation, which rotary table goes
+    to which rows, the gating / residual wiring, the un-patchify permutation."""
+    import ast
+    import logging
+    import types
+    import warnings
+    from numbers import Number
+    from types import SimpleNamespace
+    from typing import Any, Dict, List, Optional, Tuple, Union
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from oracle import ar_model as OM
+    from oracle import layers as OL
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    R = "/root/reference/ladcast/models/"
+    typing_ns = {"torch": torch, "nn": nn, "F": F, "np": np, "warnings": warnings, "Number": Number, "Optional": Optional, "Tuple": Tuple, "Union": Union,
+                 "List": List, "Dict": Dict, "Any": Any, "math": __import__("math"), "datetime": __import__("datetime").datetime}
+    emb = _ref_functions(R + "embeddings.py", ["convert_int_to_datetime", "compute_year_progress", "timestamp_tensor_to_time_elapsed",
+                                               "get_year_sincos_embedding"], dict(typing_ns))
+    rope_ns = dict(typing_ns, get_1d_rotary_pos_embed=lambda dim, pos, theta, use_real=True: OL.get_1d_rotary_pos_embed(dim, pos, theta))
+    _ref_classes(R + "embeddings.py", ["LaDCastRotaryPosEmbed_from_grid"], rope_ns)
+
+    ns = dict(typing_ns, Attention=object, AttentionProcessor=object, apply_rotary_emb=OL.apply_rotary_emb, USE_PEFT_BACKEND=False,
+              logger=logging.getLogger("ladcast_ref"), Transformer2DModelOutput=lambda sample: SimpleNamespace(sample=sample),
+              get_year_sincos_embedding=emb["get_year_sincos_embedding"], get_1d_rotary_pos_embed=rope_ns["get_1d_rotary_pos_embed"],
+              is_torch_version=lambda *a: True, scale_lora_layers=None, unscale_lora_layers=None)
+    tree = ast.parse(open(R + "LaDCast_3D_model.py").read())
+    wanted = {"LaDCastAttnProcessor2_0": ["__call__"], "HunyuanVideoAdaNorm": ["forward"], "LaDCastIndividualTokenRefinerBlock": ["forward"],
+              "LaDCastIndividualTokenRefiner": ["forward"], "LaDCastTokenRefiner": ["forward"], "LaDCastSingleTransformerBlock": ["forward"],
+              "LaDCastTransformerBlock": ["forward"], "LaDCastTransformer3DModel": ["forward"]}
+    body = []
+    for cdef in tree.body:
+        if isinstance(cdef, ast.ClassDef) and cdef.name in wanted:
+            for m in cdef.body:
+                if isinstance(m, ast.FunctionDef) and m.name in wanted[cdef.name]:
+                    m = _strip_inner_imports(m)
+                    m.name = f"{cdef.name}_{m.name}"
+                    body.append(m)
+    assert len(body) == 8
+    exec(compile(ast.Module(body=body, type_ignores=[]), R + "LaDCast_3D_model.py", "exec"), ns)
+
+    cfg = tiny_ar_config()
+    model = make_ar(cfg)
+
+    class RefProcessor:
+        __call__ = ns["LaDCastAttnProcessor2_0___call__"]
+
+    bind = {OM.HunyuanVideoAdaNorm: ("HunyuanVideoAdaNorm", dict(nonlinearity=nn.SiLU())), OM.RefinerBlock: ("LaDCastIndividualTokenRefinerBlock", {}),
+            OM.IndividualTokenRefiner: ("LaDCastIndividualTokenRefiner", {}), OM.TokenRefiner: ("LaDCastTokenRefiner", {}),
+            OM.SingleBlock: ("LaDCastSingleTransformerBlock", dict(act_mlp=nn.GELU(approximate="tanh"))), OM.DualBlock: ("LaDCastTransformerBlock", {})}
+    n_bound = 0
+    for mod in model.modules():
+        if isinstance(mod, OL.Attention):
+            object.__setattr__(mod, "processor", RefProcessor())
+            n_bound += 1
+        for cls, (ref_name, attrs) in bind.items():
+            if type(mod) is cls:
+                for k, v in attrs.items():
+                    object.__setattr__(mod, k, v)
+                object.__setattr__(mod, "forward", types.MethodType(ns[f"{ref_name}_forward"], mod))
+                n_bound += 1
+    c = model.config
+    Rope = rope_ns["LaDCastRotaryPosEmbed_from_grid"]
+    for k, v in dict(scale_attn_by_lat=False, gradient_checkpointing=False,
+                     rope=Rope(rope_dim_list=c.rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size], theta=c.rope_theta),
+                     cond_rope=Rope(rope_dim_list=c.conditioning_tensor_rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size],
+                                    theta=c.rope_theta)).items():
+        object.__setattr__(model, k, v)
+    object.__setattr__(model, "forward", types.MethodType(ns["LaDCastTransformer3DModel_forward"], model))
+    assert n_bound >= 9, n_bound
+
+    out = {}
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, (B, Rr, Bt, stamp) in {"a": (2, 4, 1, 2018010100), "b": (1, 1, 1, 2019063012), "c": (3, 2, 3, None)}.items():
+            x = torch.randn(B, 84, Rr, 15, 30, generator=torch.Generator().manual_seed(3))
+            known = synth_known(B)
+            t = torch.linspace(-1.2, 1.0, Bt)
+            te = None if stamp is None else torch.tensor([stamp])
+            y = model(x, t, known, time_elapsed=te).sample.double().flatten()
+            out[name] = y[::7].float().numpy()  # every 7th value + the norm: small fixture, still sensitive to any wiring change
+            out[name + "_norm"] = np.array(y.norm().item())
+    np.savez_compressed(os.path.join(HERE, "ar_forward_ref.npz"), **out)
+
+
 def oracle_pins():
     from tests.synth import tiny_ar_config, tiny_dcae_config, make_ar, make_dcae, synth_known, synth_field
 
@@ -246,5 +499,8 @@ if __name__ == "__main__":
     sphere_conv_fixtures()
     scoring_fixtures()
     sampler_fixtures()
+    piece_fixtures()
+    dcae_forward_fixtures()
+    ar_forward_fixtures()
     oracle_pins()
     print("wrote", sorted(os.listdir(HERE)))

@@ -69,3 +69,64 @@ def test_calendar_embedding_and_transforms_equal_the_reference_code(golden_dir):
     assert torch.equal(OP.get_transform_3D("normalize", args)(x), z["tr_fwd"])
     assert torch.equal(OP.get_inv_transform_3D("normalize", args)(x), z["tr_inv"])
     assert torch.equal(OP.get_transform_3D("normalize", {"mean": mean, "std": std})(x), z["tr_fwd_nots"])
+
+
+def test_building_blocks_equal_the_reference_classes(golden_dir):
+    """DCDownBlock2d / DCUpBlock2d / SanaMultiscaleAttentionProjection / the ReLU linear-attention processor / HunyuanVideoPatchEmbed /
+    decode_latent_ens: the oracle's classes against outputs of the reference's own class code on the same seeded weights
+    (tests/golden/pieces_ref.npz; the reference classes loaded the oracle's state dicts with strict=True, so the parameter names
+    agree too).  Convolutions and matmuls on the CPU: 1e-6."""
+    from tests.golden.make_golden import ToyDecoder, piece_inputs, piece_modules
+
+    z = np.load(f"{golden_dir}/pieces_ref.npz")
+    x, m = piece_inputs(), piece_modules()
+
+    def close(got, name):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape
+        return ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
+
+    with torch.no_grad():
+        assert close(m["down"](x["down_x"]), "down")
+        assert close(m["up"](x["up_x"]), "up")
+        assert close(m["proj"](x["proj_x"]), "proj")
+        assert close(m["attn"](x["attn_x"]), "attn")
+        assert close(m["patch"](x["patch_x"]), "patch")
+        mean, std = torch.linspace(-1, 1, 8), torch.linspace(0.5, 2, 8)
+        assert torch.equal(OP.decode_latent_ens(ToyDecoder(), x["dec_z"], mean, std), torch.from_numpy(z["dec_all"]))
+        assert torch.equal(OP.decode_latent_ens(ToyDecoder(), x["dec_z"], None, None, extract_first=1), torch.from_numpy(z["dec_first"]))
+
+
+def test_transformer_forward_equals_the_reference_forward_code(golden_dir):
+    """tests/golden/ar_forward_ref.npz: the tiny model's output when every forward the reference wrote itself (attention processor, AdaNorm,
+    token refiner, single / dual blocks, the model's forward, the RoPE grid module, the calendar embedding) is the reference's code bound onto
+    the oracle's parameter containers (make_golden.py::ar_forward_fixtures).  The pure oracle must reproduce it: 1e-6 (CPU matmul)."""
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    m = make_ar(tiny_ar_config())
+    with torch.no_grad():
+        for name, (B, R, Bt, stamp) in {"a": (2, 4, 1, 2018010100), "b": (1, 1, 1, 2019063012), "c": (3, 2, 3, None)}.items():
+            x = torch.randn(B, 84, R, 15, 30, generator=torch.Generator().manual_seed(3))
+            te = None if stamp is None else torch.tensor([stamp])
+            y = m(x, torch.linspace(-1.2, 1.0, Bt), synth_known(B), time_elapsed=te).sample.double().flatten()
+            want = torch.from_numpy(z[name]).double()
+            assert ((y[::7] - want).norm() / want.norm()).item() < 1e-6
+            assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < 1e-6
+
+
+def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
+    """tests/golden/dcae_forward_ref.npz: the tiny autoencoder's latent and reconstruction when the forward of every DCAE class the reference
+    defines (ResBlock, GLUMBConv, EfficientViTBlock, the linear-attention container + processor, DCDown/UpBlock2d, Encoder, Decoder) is the
+    reference's code bound onto the oracle's parameter containers (make_golden.py::dcae_forward_fixtures)."""
+    from tests.synth import make_dcae, synth_field, tiny_dcae_config
+
+    z = np.load(f"{golden_dir}/dcae_forward_ref.npz")
+    ae = make_dcae(tiny_dcae_config())
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        lat = ae.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        rec = ae.decode(lat, return_static=True).sample
+    for got, name in ((lat, "z"), (rec, "y")):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
