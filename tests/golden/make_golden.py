@@ -115,6 +115,7 @@ def _ref_functions(path, names, ns, class_methods=None):
         for m in cdef.body:
             if isinstance(m, ast.FunctionDef) and m.name in methods:
                 m.name = f"{cls}_{m.name}"
+                m.decorator_list = [d for d in m.decorator_list if "apply_forward_hook" not in ast.unparse(d)]  # accelerate offload hook: a no-op here
                 body.append(m)
     exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
     return ns
@@ -311,7 +312,8 @@ def piece_fixtures():
 
 def dcae_forward_fixtures():
     """The reference's own forward code of every DCAE class it defines - ResBlock, GLUMBConv, EfficientViTBlock, SanaMultiscaleLinearAttention
-    (+ processor, apply_linear_attention), DCDownBlock2d, DCUpBlock2d, Encoder, Decoder (models/DCAE.py:93-732) - bound onto the oracle's tiny
+    (+ processor, apply_linear_attention), DCDownBlock2d, DCUpBlock2d, Encoder, Decoder, AutoencoderDC.encode / decode / forward
+    (models/DCAE.py:93-732,948-1087) - bound onto the oracle's tiny
     autoencoder (same attribute names, seeded weights).  The leaves it calls are torch modules, the oracle's RMSNorm (third-party in the
     reference, unpinned) and the pinned SphereConv2d.  Flags the reference sets in its constructors are set here from the shipped config
     (configs/DC_AE_84_pretrain.yaml: rms_norm, silu, pixel_(un)shuffle, shortcuts on)."""
@@ -328,7 +330,12 @@ def dcae_forward_fixtures():
     ns = {"torch": torch, "nn": nn, "F": F, "Optional": Optional, "Tuple": Tuple, "Union": Union, "SanaMultiscaleLinearAttention": object}
     _ref_classes(R, ["SanaMultiscaleAttnProcessor2_0"], ns)
     methods = {"SanaMultiscaleLinearAttention": ["apply_linear_attention", "forward"], "GLUMBConv": ["forward"], "ResBlock": ["forward"],
-               "EfficientViTBlock": ["forward"], "DCDownBlock2d": ["forward"], "DCUpBlock2d": ["forward"], "Encoder": ["forward"], "Decoder": ["forward"]}
+               "EfficientViTBlock": ["forward"], "DCDownBlock2d": ["forward"], "DCUpBlock2d": ["forward"], "Encoder": ["forward"], "Decoder": ["forward"],
+               "AutoencoderDC": ["_encode", "encode", "_decode", "decode", "forward"]}
+    from types import SimpleNamespace
+
+    ns["EncoderOutput"] = lambda latent: SimpleNamespace(latent=latent)
+    ns["DecoderOutput"] = lambda sample: SimpleNamespace(sample=sample)
     _ref_functions(R, [], ns, class_methods=methods)
 
     ae = make_dcae(tiny_dcae_config())
@@ -338,7 +345,7 @@ def dcae_forward_fixtures():
         OD.GLUMBConv: dict(nonlinearity=nn.SiLU(), norm_type="rms_norm", residual_connection=True),
         OD.ResBlock: dict(norm_type="rms_norm", time_emb_porj=None),
         OD.EfficientViTBlock: {}, OD.DCDownBlock2d: dict(downsample=True), OD.DCUpBlock2d: dict(interpolate=False),
-        OD.Encoder: dict(out_shortcut=True), OD.Decoder: dict(in_shortcut=True, conv_act=nn.ReLU()),
+        OD.Encoder: dict(out_shortcut=True), OD.Decoder: dict(in_shortcut=True, conv_act=nn.ReLU()), OD.AutoencoderDC: {},
     }
     bound = 0
     for mod in ae.modules():
@@ -351,10 +358,13 @@ def dcae_forward_fixtures():
                 bound += 1
     assert bound >= 12, bound
     f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
-    with torch.no_grad():
-        z = ae.encoder(torch.cat([f, st.expand(2, -1, -1, -1)], dim=1))  # AutoencoderDC.encode's cat (models/DCAE.py:988-989) then Encoder.forward
-        y = ae.decoder(z)
-    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy())
+    with torch.no_grad():  # AutoencoderDC.encode / decode / forward are the reference's too (models/DCAE.py:948-1087)
+        z = ae.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        y = ae.decode(z, return_static=True).sample
+        y_nostatic = ae.decode(z, return_dict=False)[0]
+        full = ae.forward(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).sample
+    assert y_nostatic.shape[1] == y.shape[1] - 5 and torch.equal(full, y_nostatic)
+    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy(), y_nostatic=y_nostatic.numpy())
 
 
 def _strip_inner_imports(fn_node):

@@ -127,6 +127,7 @@ def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
     with torch.no_grad():
         lat = ae.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
         rec = ae.decode(lat, return_static=True).sample
-    for got, name in ((lat, "z"), (rec, "y")):
+        plain = ae.decode(lat, return_dict=False)[0]  # static channels stripped (models/DCAE.py:1050-1052)
+    for got, name in ((lat, "z"), (rec, "y"), (plain, "y_nostatic")):
         want = torch.from_numpy(z[name])
         assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
