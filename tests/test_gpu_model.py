@@ -347,3 +347,50 @@ def test_end_to_end_rollout_with_dcae_matches_oracle():
     got3 = roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()),
                            normalization_param_dict={"mean": fmu, "std": fsd}, encdec_model=gae, **kw)
     assert rel_l2(got3[:, :, :, 1:], want[:, :, :, 1:]) < TOL
+
+
+def test_driver_counterpart_writes_the_reference_file_layout(tmp_path):
+    """`ladcast_amd.evaluate.pred_rollout.run_rollout` (the tensor-level counterpart of evaluate/pred_rollout.py) - prepared
+    inputs -> encode -> rollout -> `latent_YYYYMMDDHH.npy` per initial time holding (ens, 84, 1 + steps, 15, 30) with slot 0 = the un-normalised
+    IC latent; values vs the oracle's roll_out_serial on the same prepared inputs."""
+    from datetime import datetime
+
+    from ladcast_amd.evaluate.pred_rollout import build_static_conditioning, fill_sst_nan, load_latent_transform_args, run_rollout
+    from ladcast_amd.models import AutoencoderDC
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, list_latent_files, load_latent_npy
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from oracle.dcae import CONFIG_DCAE_84
+    from tests.synth import make_dcae, synth_field
+
+    ae_cfg = dict(CONFIG_DCAE_84, encoder_block_out_channels=(84, 84, 84, 168), decoder_block_out_channels=(84, 84, 84, 168),
+                  encoder_layers_per_block=(1, 1, 1, 1), decoder_layers_per_block=(1, 1, 1, 1))
+    oae = make_dcae(ae_cfg)
+    gae = AutoencoderDC.from_config(ae_cfg)
+    gae.load_state_dict(oae.state_dict(), strict=True)
+    gae = gae.cuda().eval()
+    cfg = tiny_ar_config(heads=2, layers=1, single=1, refiner=1)
+    oar = make_ar(cfg)
+    gar = to_hip(oar, cfg)
+    g_ = torch.Generator().manual_seed(12)
+    static = build_static_conditioning(torch.rand(121, 240, generator=g_), torch.randn(4, 121, 240, generator=g_) * 50 + 100)
+    assert static.shape == (5, 120, 240)
+    fields = {}
+    for k, t in enumerate([datetime(2018, 1, 1, 0), datetime(2018, 1, 3, 12)]):
+        f = synth_field(84, 1, 120, 240, seed=20 + k)
+        f[82, :, ::7, ::5] = float("nan")  # land points of the SST channel
+        fields[t] = fill_sst_nan(f)
+        assert not torch.isnan(fields[t]).any() and (fields[t][82, 0, ::7, ::5] == -2).all()
+    targs = load_latent_transform_args({"mean": (torch.randn(84, generator=g_) * 0.2).tolist(), "std": (torch.rand(84, generator=g_) + 0.5).tolist()})
+    assert targs["target_std"] == 0.5
+    kw = dict(ensemble_size=3, num_inference_steps=2, return_seq_len=2, total_lead_time_hour=18, sampler_type="edm")
+    got = run_rollout(lambda t: fields[t], list(fields), AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()), gae, targs,
+                      static_conditioning_tensor=static, output=str(tmp_path), **kw)
+    files = list_latent_files(str(tmp_path))
+    assert [n for n, _ in files] == ["2018010100", "2018010312"]
+    for (name, path), t, mine in zip(files, fields, got):
+        arr, stamp = load_latent_npy(path)
+        assert stamp == int(name) and arr.shape == (3, 84, 4, 15, 30) and torch.equal(arr, mine.cpu())
+        want = OP.roll_out_serial(lambda _t: fields[t], [t], OP.AutoRegressive2DPipeline(oar, OracleScheduler()), encdec_model=oae, encdec_model_type="ae",
+                                  static_tensor4encdec=static, latent_transform_args=targs, return_latent=True, **kw)[0]
+        assert rel_l2(arr, want) < TOL
+        assert rel_l2(arr[:, :, 0], want[:, :, 0]) < 2e-5  # slot 0: the encoded, un-normalised initial condition

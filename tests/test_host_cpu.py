@@ -137,3 +137,28 @@ def test_latent_npy_conventions(tmp_path):
     assert [s for s, _ in list_latent_files(str(tmp_path))] == ["2018010100", "2018010312", "2018010500"]
     with pytest.raises(ValueError):
         save_latent_npy(res[0], stamps, str(tmp_path))
+
+
+def test_driver_input_preparation_follows_the_reference():
+    """static fields: south-pole row dropped, land-sea mask first, per-channel z-score with the UNBIASED std (evaluate/pred_rollout.py:246-291);
+    SST NaNs -> -2 in place (dataloader/utils.py:396-400); latent statistics get target_std 0.5 (pred_rollout.py:221-226)"""
+    from ladcast_amd.evaluate.pred_rollout import build_static_conditioning, crop_south_pole, fill_sst_nan, load_latent_transform_args, run_rollout
+
+    g = torch.Generator().manual_seed(4)
+    lsm, oro = torch.rand(121, 240, generator=g), torch.randn(4, 121, 240, generator=g) * 30 + 7
+    st = build_static_conditioning(lsm, oro)
+    raw = torch.cat([lsm[1:].unsqueeze(0), oro[:, 1:]], dim=0)  # the reference's statements, spelled out
+    want = (raw - raw.mean(dim=(1, 2), keepdim=True)) / raw.std(dim=(1, 2), keepdim=True)
+    assert st.shape == (5, 120, 240) and torch.equal(st, want)
+    assert abs(st[0].std().item() - 1) < 1e-6 and abs(st[0].std(unbiased=False).item() - 1) > 1e-6
+    assert torch.equal(build_static_conditioning(None, oro), want_only := (raw[1:] - raw[1:].mean(dim=(1, 2), keepdim=True)) / raw[1:].std(dim=(1, 2), keepdim=True)) and want_only.shape[0] == 4
+    assert build_static_conditioning() is None and crop_south_pole(lsm).shape == (120, 240)
+    f = torch.randn(84, 2, 6, 8, generator=g)
+    f[82, 1, 2, 3] = float("nan")
+    f[5, 0, 0, 0] = float("nan")
+    out = fill_sst_nan(f)
+    assert out is f and f[82, 1, 2, 3] == -2 and torch.isnan(f[5, 0, 0, 0])  # only the SST channel is filled
+    args = load_latent_transform_args({"mean": [0.0], "std": [1.0]})
+    assert args == {"mean": [0.0], "std": [1.0], "target_std": 0.5}
+    with pytest.raises(ValueError):
+        run_rollout(None, [], None, None, args, total_lead_time_hour=7, step_size_hour=6)
