@@ -45,3 +45,47 @@ def test_product_samplers_reproduce_the_reference_code(golden_dir):
     assert _rel(got, z["ens_edm"]) < 1e-6
     got = ensemble_AR_sampler(pipe, 4, 2, 4, known_latents=known1, timestamps=ts, batch_size=3, sampler_type="pipeline", device="cuda")
     assert _rel(got, z["ens_pipe"]) < 1e-6
+
+
+def test_product_transformer_reproduces_the_reference_forward_code(golden_dir):
+    """tests/golden/ar_forward_ref.npz holds the tiny model's outputs computed by the REFERENCE's forward code (every class it defines, bound onto
+    seeded parameter containers - make_golden.py::ar_forward_fixtures).  The HIP model with the same weights, fp32 and split-bf16 arithmetic,
+    against those numbers directly (no oracle in between): the fp32 budget of the north star, 1e-4; measured ~3e-6 / ~5e-6."""
+    from ladcast_amd.models import LaDCastTransformer3DModel
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    cfg = tiny_ar_config()
+    m = LaDCastTransformer3DModel.from_config(cfg)
+    m.load_state_dict(make_ar(cfg).state_dict(), strict=True)
+    m = m.cuda().eval()
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5)):
+        m.set_gemm_precision(prec)
+        for name, (B, R, Bt, stamp) in {"a": (2, 4, 1, 2018010100), "b": (1, 1, 1, 2019063012), "c": (3, 2, 3, None)}.items():
+            x = torch.randn(B, 84, R, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+            te = None if stamp is None else torch.tensor([stamp]).cuda()
+            y = m(x, torch.linspace(-1.2, 1.0, Bt).cuda(), synth_known(B).cuda(), time_elapsed=te).sample.double().flatten().cpu()
+            want = torch.from_numpy(z[name]).double()
+            assert ((y[::7] - want).norm() / want.norm()).item() < tol, (prec, name)
+            assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < tol
+
+
+def test_product_dcae_reproduces_the_reference_forward_code(golden_dir):
+    """the same for the autoencoder: tests/golden/dcae_forward_ref.npz (reference forward code of every DCAE class incl. AutoencoderDC.encode /
+    decode) vs the HIP autoencoder with the same seeded weights"""
+    from ladcast_amd.models import AutoencoderDC
+    from tests.synth import make_dcae, synth_field, tiny_dcae_config
+
+    z = np.load(f"{golden_dir}/dcae_forward_ref.npz")
+    cfg = tiny_dcae_config()
+    g = AutoencoderDC.from_config(cfg)
+    g.load_state_dict(make_dcae(cfg).state_dict(), strict=True)
+    g = g.cuda().eval()
+    f, st = synth_field(2, 8, 48, 64).cuda(), synth_field(1, 5, 48, 64, seed=1).cuda()
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5)):
+        g.set_gemm_precision(prec)
+        lat = g.encode(f, static_conditioning_tensor=st).latent
+        zz = torch.from_numpy(z["z"]).cuda()
+        rec = g.decode(zz, return_static=True).sample
+        plain = g.decode(zz).sample
+        assert _rel(lat, torch.from_numpy(z["z"])) < tol and _rel(rec, torch.from_numpy(z["y"])) < tol and _rel(plain, torch.from_numpy(z["y_nostatic"])) < tol
