@@ -91,7 +91,8 @@ def run_rollout(
     """One ``roll_out_serial`` call per initial time with the reference CLI's fixed arguments (``encdec_model_type="ae"``,
     ``latent_transform="normalize"``, ``return_tensor=True``; pred_rollout.py:367-390), the ensemble shared between the ranks of the
     default process group when there is one.  ``save_as_latent``: rank 0 writes ``<output>/latent_YYYYMMDDHH.npy`` holding
-    ``(ens, 84, 1 + steps, 15, 30)`` (:420-430).  Returns the per-initial-time tensors ``(ens, C, 1 + steps, h, w)`` (on every rank)."""
+    ``(ens, 84, 1 + steps, 15, 30)`` (:420-430).  Returns the per-initial-time tensors ``(ens, C, 1 + steps, h, w)`` (on every rank).
+    ``device``: where the per-rank result block lives for the gather - pass this rank's GPU with the nccl (RCCL) backend."""
     if total_lead_time_hour % step_size_hour:
         raise ValueError("total_lead_time_hour must be divisible by step_size_hour")  # pipelines/utils.py:305-306
     import torch.distributed as dist
