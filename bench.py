@@ -320,10 +320,13 @@ def main():
     timer = KernelTimer()
     fence()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         step()
+        marks.append(time.perf_counter())  # every step returns host tensors, i.e. is complete here: no extra synchronisation
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
     other_sampler = None
     if not args.no_kernel_timers and rank == 0 and world == 1:
         # Secondary number (not `value`): the same workload with the reference's other sampler -- BASELINE's metric says
@@ -400,7 +403,7 @@ def main():
                                         "2*FETCH+WRITE KiB); served mostly by the 256 MiB Infinity Cache: panels are re-read per XCD")
         line = {
             "metric": "ensemble-member-steps/sec", "value": round(value, 4), "unit": "member-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3(split-fp32 operands, f32 accumulate; softmax/norms f32, sampler state f64)" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {

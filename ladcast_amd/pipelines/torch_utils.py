@@ -9,6 +9,11 @@ import torch
 
 
 def randn_tensor(shape, generator=None, device=None, dtype=None):
+    with few_host_threads():
+        return _randn_tensor(shape, generator, device, dtype)
+
+
+def _randn_tensor(shape, generator=None, device=None, dtype=None):
     device = torch.device(device) if device is not None else torch.device("cpu")
     batch = shape[0]
     if isinstance(generator, list) and len(generator) == 1:
@@ -19,3 +24,25 @@ def randn_tensor(shape, generator=None, device=None, dtype=None):
         return torch.cat(parts, dim=0).to(device)
     rand_device = generator.device if generator is not None else device
     return torch.randn(tuple(shape), generator=generator, device=rand_device, dtype=dtype).to(device)
+
+
+class few_host_threads:
+    """Context manager for the host-side glue of the rollout (noise draws, small CPU tensor writes): run it on at most `limit` intra-op
+    threads.  Those tensors hold ~10^5 elements; torch would still wake its whole OpenMP pool (128 threads on a 2 x 64-core host) for each of
+    them, and on a busy host - or with one process per GPU, 8 pools on one box - that wake-up costs 50-100 ms at random (measured: chunk
+    times of 144 / 245 / 144 / 203 ms with the default pool, 144.5 +- 0.5 ms with 4 threads).  Values do not depend on the thread count."""
+
+    def __init__(self, limit: int = 4):
+        self.limit = limit
+        self.saved = None
+
+    def __enter__(self):
+        self.saved = torch.get_num_threads()
+        if self.saved > self.limit:
+            torch.set_num_threads(self.limit)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None and torch.get_num_threads() != self.saved:
+            torch.set_num_threads(self.saved)
+        return False

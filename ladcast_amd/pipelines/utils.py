@@ -12,6 +12,7 @@ would have had in the single-process run -- the result does not depend on the pa
 from __future__ import annotations
 
 import copy
+import functools
 import math
 from dataclasses import dataclass
 from datetime import datetime, timedelta
@@ -22,6 +23,7 @@ import torch
 
 from .. import hip
 from .edm_sampler import edm_AR_sampler
+from .torch_utils import few_host_threads
 
 
 @dataclass
@@ -84,6 +86,18 @@ def get_inv_transform_3D(transform, transform_args):
     raise NotImplementedError(f"Transform: {transform} not implemented.")
 
 
+def _host_glue(fn):
+    """run the host side of an entry point on a few intra-op threads (torch_utils.few_host_threads: the tensors are tiny, the default
+    128-thread pool only adds wake-up stalls)"""
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with few_host_threads():
+            return fn(*args, **kwargs)
+
+    return wrapper
+
+
 @torch.no_grad()
 def decode_latent_ens(encdec_model, latents, mean_tensor=None, std_tensor=None, extract_first=None):
     """latents (B, C, T, H, W) -> decoded fields (B, C', T', H', W') (pipelines/utils.py:51-80)."""
@@ -99,6 +113,7 @@ def decode_latent_ens(encdec_model, latents, mean_tensor=None, std_tensor=None, 
     return y
 
 
+@_host_glue
 @torch.no_grad()
 def ensemble_AR_sampler(
     pipeline,
@@ -156,6 +171,7 @@ def ensemble_AR_sampler(
     return samples
 
 
+@_host_glue
 @torch.no_grad()
 def roll_out_serial(
     input_fields: Callable[[datetime], torch.Tensor],
