@@ -11,6 +11,13 @@ reference module):  python tests/golden/make_golden.py
   which is not installed, and none of these six functions uses it: their
   definitions are taken from the reference file's syntax tree at generation
   time and executed as they stand (nothing of the file is copied into the repo).
+* sampler_ref.npz, pieces_ref.npz, ar_forward_ref.npz, dcae_forward_ref.npz -- outputs of
+  the REFERENCE's own sampler / driver / transform / calendar functions, of its torch-only
+  classes, and of every forward method it defines for the transformer and the DCAE, compiled
+  the same way (definitions from the syntax tree; the files' diffusers / xarray imports are
+  never executed) and run with the oracle's scheduler / leaf layers / seeded parameter
+  containers: see sampler_fixtures, piece_fixtures, ar_forward_fixtures,
+  dcae_forward_fixtures and tests/test_oracle_reference_pins.py.
 * oracle_pins.npz       -- outputs of THIS repo's oracle on seeded synthetic
   inputs (regression pins; they are not reference outputs -- the reference's
   diffusers-dependent path cannot be imported here, see oracle/__init__.py).
