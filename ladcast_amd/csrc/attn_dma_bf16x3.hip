@@ -442,7 +442,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
         const float m4 = max3f(sc[12], sc[13], sc[14]);
         m0 = max3f(m0, m1, m2); m3 = max3f(m3, m4, sc[15]); m0 = fmaxf(m0, m3);
         m0 = xor32_max(m0);
-        m_new = fmaxf(m_run, m0);
+        // lazy running max: it only moves when the tile's max exceeds it by more than 2^8 (scores are in log2 units), so exp2(s - m)
+        // stays <= 256 and the 64-multiply rescale of O below really is rare; with the exact max some of a wave's 32 queries move it
+        // in nearly every tile.  Softmax does not depend on which reference value is subtracted.
+        m_new = (m0 - m_run > 8.0f) ? m0 : m_run;
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         asm volatile("" : "+v"(m_new), "+v"(alpha));
       }
