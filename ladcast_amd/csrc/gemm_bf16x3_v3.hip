@@ -623,7 +623,8 @@ int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* wo
   }
   // half-height tiles while 256-row tiles would not fill the chip twice over (both heights run 8 waves here, so the
   // half-height tile costs no MFMA efficiency, only twice the W traffic per FLOP); LDC_BF16X3_BM forces one
-  bool small = tiles256 < 400;  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
+  static const char* const force_thr = getenv("LDC_BF16X3_SMALL_TILES");  // measurement aid, read once: the cross-over below
+  bool small = tiles256 < (force_thr ? atoll(force_thr) : 400);  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
   static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
   if (force_bm) small = (atoi(force_bm) == 128);
   return small ? launch_v3<128>(problems, n, workspace, workspace_bytes, stream)
