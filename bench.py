@@ -205,6 +205,26 @@ def cpu_baseline(cfg_name, R, n_forwards):
     return dt
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process has touched no GPU API (importing torch
+    does not), so it starts N fresh rank processes through `python -m torch.distributed.run` as a CHILD, waits, and exits
+    with its code - never an exec from a process that has initialised the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")  # torchrun's default of 1 would throttle nothing here but the noise draws
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        print(f"bench.py: the {n}-rank launch exited with code {rc}", file=sys.stderr)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,16 +249,18 @@ def main():
                     "encode / decode timing (BASELINE configs[0], secondary)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="token-stream GEMM arithmetic: exact fp32 MFMA, or split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="after the K timed steps keep stepping until this many seconds of "
+                    "back-to-back chunks have run and report that window as `sustained` (clock under sustained load); 0 = skip")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     if args.workload == "dcae":
         return dcae_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     dev_index = local_rank % torch.cuda.device_count() if args.share_gpus else local_rank
     torch.cuda.set_device(dev_index)
@@ -327,6 +349,26 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    # Sustained window (not `value`): keep running back-to-back chunks until >= --sustained-seconds have passed, so the number
+    # reflects the clock the chip holds under sustained load; the step count is fixed up front so every rank runs the same.
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(1, int(-(-args.sustained_seconds // (elapsed / args.steps))))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        sustained = dict(steps=n_sus, seconds=round(dt, 3), ms_per_step=round(1e3 * dt / n_sus, 3), value=round(m * world * lead * n_sus / dt, 4))
     other_sampler = None
     if not args.no_kernel_timers and rank == 0 and world == 1:
         # Secondary number (not `value`): the same workload with the reference's other sampler -- BASELINE's metric says
@@ -349,24 +391,52 @@ def main():
         torch.cuda.synchronize()
         other_sampler = dict(sampler=alt, forwards_per_step=(-(-lead // R)) * (args.solver_steps if alt == "pipeline" else 2 * args.solver_steps - 1),
                              value=round(m * lead * 2 / (time.perf_counter() - t1), 4), unit="member-steps/s", steps=2)
-    instrumented_ms = None
-    if not args.no_kernel_timers and rank == 0:
-        # Kernel-level numbers for `roofline`: ONE more step of the same workload, right after the timed region, with a
-        # HIP-event pair around every GEMM / attention call on the stream they are launched on.  It runs eagerly (events
-        # cannot bracket nodes of a replayed hipGraph) and stays out of `value`, so the headline is not perturbed.
+
+    def instrumented_step():
+        """Kernel-level numbers for `roofline`: ONE more step of the same workload, right after the timed region, with a
+        HIP-event pair around every GEMM / attention call on the stream they are launched on.  It runs eagerly (events
+        cannot bracket nodes of a replayed hipGraph) and stays out of `value`, so the headline is not perturbed."""
         model.enable_hip_graph(False)
+        timer.clear()
         timer.install(hip)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step_local()
         torch.cuda.synchronize()
-        instrumented_ms = 1e3 * (time.perf_counter() - t1)
+        ms = 1e3 * (time.perf_counter() - t1)
         timer.uninstall()
         model.enable_hip_graph(not args.no_graph)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        return ms, timer.summary()
+
+    instrumented_ms, ks = None, {}
+    if not args.no_kernel_timers and rank == 0:
+        instrumented_ms, ks = instrumented_step()
+    # The same workload in the exact-fp32 mode (fp32-input MFMA everywhere), beside the headline: value, ms per step and the
+    # dominant GEMM kernel against the 157.3 TFLOP/s fp32 matrix peak.  Single-GPU runs only (no collective inside).
+    fp32_mode = None
+    if args.precision != "fp32" and not args.no_kernel_timers and world == 1 and not args.decode:
+        model.set_gemm_precision("fp32")
+        step_local()  # set-up: weight plan + graph capture of the fp32 chunk
+        torch.cuda.synchronize()
+        n32 = 3
+        t1 = time.perf_counter()
+        for _ in range(n32):
+            step_local()
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        _, ks32 = instrumented_step()
+        g32 = [n for n in ks32 if n.startswith("gemm_")]
+        d32 = max(g32, key=lambda n: ks32[n]["total_ms"]) if g32 else None
+        fp32_mode = dict(value=round(m * lead * n32 / dt32, 4), unit="member-steps/s", steps=n32, ms_per_step=round(1e3 * dt32 / n32, 3), dtype="f32")
+        if d32:
+            k = ks32[d32]
+            fp32_mode["roofline"] = dict(bound="mfma", kernel=d32, achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                         frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), launches=k["launches"], avg_launch_us=round(k["avg_us"], 2))
+        if "attn_fwd_f32_kernel" in ks32:
+            k = ks32["attn_fwd_f32_kernel"]
+            fp32_mode["attention_kernel"] = dict(kernel="attn_fwd_f32_kernel", achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS,
+                                                 frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_us=round(k["avg_us"], 2))
+        model.set_gemm_precision(args.precision)
 
     if rank == 0:
         chunks = -(-lead // R)
@@ -374,7 +444,6 @@ def main():
         gflops, aflops = model_flops_per_forward(cfg, R)
         total_members = m * world
         value = total_members * lead * args.steps / elapsed
-        ks = timer.summary()
         roof = None
         split = args.precision == "bf16x3"
         gemm_names = [n for n in ks if n.startswith("gemm_")]
@@ -383,15 +452,20 @@ def main():
             k = ks[dom]
             kname = dom
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-            traffic = None
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+                    ent = json.load(open(pmc)).get(kname, {})
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = ("profiles/pmc_summary.json (committed rocprofv3 --pmc passes of this command, build "
+                                          f"{ent.get('build', 'see profiles/README.md')}); not re-measured in this run")
                 except Exception:
                     traffic = None
             roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s",
-                        frac=round(k["tflops"] / peak, 4), traffic=traffic, launches=k["launches"], avg_launch_us=round(k["avg_us"], 2),
+                        frac=round(k["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_source, launches=k["launches"],
+                        avg_launch_us=round(k["avg_us"], 2),
                         flops_per_launch=k["work_per_launch"],
                         note="one launch = one grouped stream-K GEMM call; achieved = ALGORITHMIC 2*M*N*K summed over the call's problems / "
                              "HIP-event time of the call, averaged over one instrumented step run right after the timed region (see instrumented_ms_per_step)."
@@ -415,6 +489,11 @@ def main():
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
             "other_sampler": other_sampler,
+            "sustained": sustained,
+            "fp32_mode": fp32_mode,
+            "ranks": {"world_size": world if dist is None else dist.get_world_size(), "backend": "none" if dist is None else args.backend,
+                      "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and args.backend == "nccl") else None,
+                      "visible_gpus": torch.cuda.device_count()},
             "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
             "roofline": roof,
         }

@@ -4,10 +4,12 @@ that script does between "inputs are tensors" and "``latent_YYYYMMDDHH.npy`` is 
 (:347-400) and the saved layout (:420-430).  The zarr / xarray reading of the reference stays with the caller
 (``input_fields`` is a callable returning the normalised IC field), as for ``roll_out_serial``.
 
-Work split: the reference gives each rank whole initial times (``accelerator.split_between_processes``, :358) and gathers
-result tensors; here every rank takes its share of the ensemble MEMBERS of each initial time (``roll_out_sharded``: results
-are partition-invariant because member k is always seeded with k) - the same files come out, and 8 GPUs cooperate on one
-forecast instead of idling when there are fewer initial times than ranks.
+Work split: the reference takes ``batch_size`` (default: the number of ranks) initial times at a time and deals whole initial
+times to ranks (``accelerator.split_between_processes``, :336-358), then gathers result tensors.  Here the same batches are cut
+in two dimensions: the ``n_init x ensemble_size`` (initial time, member) items of a batch go to ranks in contiguous, balanced
+blocks (``pipelines/distributed.py::shard_work``; results are partition-invariant because member k is always seeded with k) -
+the same files come out, 8 GPUs cooperate on one forecast instead of idling when there are fewer initial times than ranks, and
+the README's 20 members on 8 ranks balance exactly whenever a batch holds an even number of initial times.
 """
 from __future__ import annotations
 
@@ -86,29 +88,36 @@ def run_rollout(
     save_as_latent: bool = True,
     noise_level: float = 0,
     device: Optional[torch.device] = None,
+    batch_size: Optional[int] = None,
     **roll_out_kwargs,
 ) -> List[torch.Tensor]:
     """One ``roll_out_serial`` call per initial time with the reference CLI's fixed arguments (``encdec_model_type="ae"``,
     ``latent_transform="normalize"``, ``return_tensor=True``; pred_rollout.py:367-390), the ensemble shared between the ranks of the
     default process group when there is one.  ``save_as_latent``: rank 0 writes ``<output>/latent_YYYYMMDDHH.npy`` holding
     ``(ens, 84, 1 + steps, 15, 30)`` (:420-430).  Returns the per-initial-time tensors ``(ens, C, 1 + steps, h, w)`` (on every rank).
-    ``device``: where the per-rank result block lives for the gather - pass this rank's GPU with the nccl (RCCL) backend."""
+    ``device``: where the per-rank result block lives for the gather - pass this rank's GPU with the nccl (RCCL) backend.
+    ``batch_size``: initial times per sharded batch (default: the number of ranks, as pred_rollout.py:336-338)."""
     if total_lead_time_hour % step_size_hour:
         raise ValueError("total_lead_time_hour must be divisible by step_size_hour")  # pipelines/utils.py:305-306
     import torch.distributed as dist
 
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    active = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if active else 0
+    if batch_size is None:
+        batch_size = dist.get_world_size() if active else 1
+    init_times = list(init_times)
     results = []
-    for t in init_times:
+    for b0 in range(0, len(init_times), batch_size):
+        batch = init_times[b0 : b0 + batch_size]
         full = roll_out_sharded(
-            roll_out_serial, ensemble_size=ensemble_size, device=device, input_fields=input_fields, pred_timestamp=[t], pipeline=pipeline,
+            roll_out_serial, ensemble_size=ensemble_size, device=device, input_fields=input_fields, pred_timestamp=batch, pipeline=pipeline,
             normalization_param_dict=normalization_param_dict, num_inference_steps=num_inference_steps, return_seq_len=return_seq_len,
             encdec_model=encdec_model, encdec_model_type="ae", static_tensor4encdec=static_conditioning_tensor, latent_transform="normalize",
             latent_transform_args=latent_transform_args, total_lead_time_hour=total_lead_time_hour, step_size_hour=step_size_hour,
             sampler_type=sampler_type, input_seq_len=input_seq_len, return_tensor=True, return_latent=save_as_latent, noise_level=noise_level,
             **roll_out_kwargs,
-        )  # (1, ens, C, 1 + steps, h, w)
+        )  # (len(batch), ens, C, 1 + steps, h, w)
         if output is not None and save_as_latent and rank == 0:
-            save_latent_npy(full, [t], output)
-        results.append(full[0])
+            save_latent_npy(full, batch, output)
+        results.extend(full[i] for i in range(len(batch)))
     return results

@@ -227,6 +227,7 @@ def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False
 
 
 _score_ws = {}
+_score_keep = []
 
 
 def ensemble_scores(forecast, truth, clim, lat_weight, out, *, M, C, H, W, member_stride, channel_stride, truth_channel_stride,
@@ -236,6 +237,8 @@ def ensemble_scores(forecast, truth, clim, lat_weight, out, *, M, C, H, W, membe
     need = int(lib.ldc_ensemble_scores_workspace_bytes(C, H, W))
     key = (str(forecast.device), torch.cuda.current_stream(forecast.device).cuda_stream)
     if key not in _score_ws or _score_ws[key].numel() * 4 < need:
+        if key in _score_ws:
+            _score_keep.append(_score_ws[key])  # a captured hipGraph may still point at the smaller one (as _rla_keep)
         _score_ws[key] = torch.empty(need // 4 + 1, device=forecast.device, dtype=torch.float32)
     ws = _score_ws[key]
     _check(lib.ldc_ensemble_scores(_p(forecast), member_stride, channel_stride, _p(truth), truth_channel_stride, _p(clim),

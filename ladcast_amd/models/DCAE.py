@@ -203,6 +203,7 @@ class AutoencoderDC(ModelMixin):
         self.static_channels = static_channels
         self.requires_grad_(False)
         self._plan = None
+        self._plan_gen = 0  # bumped on every plan rebuild: key of the graphs that captured pointers into it
         self.gemm_precision = "fp32"
         self.use_hip_graph = False
         self._graphs = {}
@@ -219,7 +220,7 @@ class AutoencoderDC(ModelMixin):
 
     def _graphed(self, key, fn, inputs):
         """fn(*static inputs) -> output tensor, kernel launches only on the current stream"""
-        key = key + (id(self._plan), self.gemm_precision)
+        key = key + (self._plan_gen, self.gemm_precision)  # generation counter, not id(): a rebuilt dict may reuse a freed id
         ent = self._graphs.get(key)
         if ent is None:
             dev = self.device
@@ -253,6 +254,7 @@ class AutoencoderDC(ModelMixin):
         if precision != self.gemm_precision:
             self.gemm_precision = precision
             self._plan = None
+            self._graphs = {}  # captured graphs hold raw pointers into the old packed weights
         return self
 
     def enable_tiling(self, *a, **k):
@@ -301,6 +303,7 @@ class AutoencoderDC(ModelMixin):
                 if split:
                     plan[id(mod.to_out)] = pack_dense_weight_bf16x3(mod.to_out.weight[:, :, None, None])
         self._plan = plan
+        self._plan_gen += 1
 
     # -- NHWC building blocks ---------------------------------------------------------------------
     def _conv(self, x, B, H, W, conv, act=hip.ACT_NONE, R=None, ldx=None):

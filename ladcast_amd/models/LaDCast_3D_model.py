@@ -251,6 +251,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         self.proj_out = nn.Linear(d, out_channels)
         self.requires_grad_(False)
         self._plan = None
+        self._plan_gen = 0  # bumped on every plan rebuild (plan_identity): graphs captured outside the model key on it
         self._ws = {}
         self._rope = {}
         self._te_cache = None
@@ -380,6 +381,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 wp[:, : w.shape[1]] = w
                 plan.packed[id(w)] = hip.pack_weight_bf16x2(wp)
         self._plan = plan
+        self._plan_gen += 1
 
     # -- cached tables -----------------------------------------------------------------------
     def _rope_tables(self, r, t_in, h, w, dev):
@@ -521,9 +523,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 sk.copy_(conditioning_tensors)
                 # warm-up and capture on ONE side stream: per-stream workspaces (stream-K counters, attention operands)
                 # are created and initialised by the warm-up, so no allocation / memset ends up inside the graph
-                if self._capture_stream is None:
-                    self._capture_stream = torch.cuda.Stream(device=dev)
-                self._capture_stream.wait_stream(torch.cuda.current_stream(dev))
+                self.capture_stream().wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(self._capture_stream):
                     self._forward_device(sx, st, sk, te)
                 torch.cuda.synchronize()
@@ -558,7 +558,14 @@ class LaDCastTransformer3DModel(ModelMixin):
         captured outside the model"""
         if self._plan is None:
             self._build_plan()
-        return id(self._plan)
+        return self._plan_gen
+
+    def capture_stream(self):
+        """the ONE side stream every graph of this model is captured on (per-stream workspaces - stream-K counters, attention
+        operands, scoring scratch - are keyed by stream: one stream = one set, however many graphs are captured)"""
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        return self._capture_stream
 
     @torch.no_grad()
     def forward_launch_only(self, hidden_states, timestep, conditioning_tensors, te):

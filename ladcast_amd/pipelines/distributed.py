@@ -1,24 +1,34 @@
 """Multi-GPU sharding of the rollout: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
 
-The path shards over ensemble MEMBERS (and initial times), never over lead time: members are
-independent given the shared IC latent, member k is always seeded with k
-(pipelines/utils.py:703-706), and lead-time chunks of one member are a sequential chain
-(:563).  So there is no data-path collective; the only exchange is the reference's own
+The path shards over (initial time x ensemble MEMBER) work items, never over lead time: members
+are independent given the shared IC latent, member k is always seeded with k
+(pipelines/utils.py:703-706), and lead-time chunks of one member are a sequential chain (:563).
+So there is no data-path collective; the only exchange is the reference's own
 ``accelerator.gather(result_tensor)`` at the end (evaluate/pred_rollout.py:398-400), done here
 as ONE all_gather of the per-rank result block.  On an 8-GPU xGMI mesh that is a 12 MB-per-rank
 message over direct links -- never on the critical path, no ring/tree tuning needed.
+
+Work split.  The reference deals whole initial times to ranks
+(``accelerator.split_between_processes``, evaluate/pred_rollout.py:349-358): with fewer initial
+times than ranks GPUs idle, and a 20-member forecast never uses more than one GPU.  Here the
+``n_init * ensemble_size`` items of a batch of initial times, in time-major order, are cut into
+``world`` contiguous blocks whose sizes differ by at most one (``shard_work``): 1 initial time x 20
+members on 8 ranks is 2/3/2/3/2/3/2/3 (nothing better exists), 2 initial times x 20 members is 5 items
+everywhere, and ``ensemble_size < world`` leaves ``world - n_items`` ranks without work - they launch
+nothing and only join the gather.  Results do not depend on the partition.
 
 The helpers are device-agnostic (they only move tensors), so the N>1 logic is exercised on CPU
 with the gloo backend in ``tests/test_distributed_cpu.py``.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
+# -- 1-D: members of one initial time (bench.py's weak-scaling layout) ------------------------------
 def shard_members(ensemble_size: int, rank: int, world_size: int) -> List[int]:
     """Round-robin member ownership: rank r computes members {k : k mod world_size == r}."""
     return list(range(rank, ensemble_size, world_size))
@@ -28,14 +38,19 @@ def members_per_rank(ensemble_size: int, world_size: int) -> List[int]:
     return [len(range(r, ensemble_size, world_size)) for r in range(world_size)]
 
 
+def _active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_members(local: torch.Tensor, ensemble_size: int, member_dim: int = 0, group=None) -> torch.Tensor:
     """All-gather the per-rank member blocks and restore global member order.
 
     ``local``: this rank's members (in ``shard_members`` order) along ``member_dim``.  Ranks may own
-    different member counts (ensemble_size not divisible by world size): blocks are padded to the
-    largest count for the collective and trimmed afterwards.  Returns the full ensemble on every rank.
+    different member counts (ensemble_size not divisible by world size, or fewer members than ranks):
+    blocks are padded to the largest count for the collective and trimmed afterwards.  Returns the full
+    ensemble on every rank.
     """
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active(group):
         assert local.shape[member_dim] == ensemble_size
         return local
     world = dist.get_world_size(group)
@@ -57,17 +72,75 @@ def gather_members(local: torch.Tensor, ensemble_size: int, member_dim: int = 0,
     return out.movedim(0, member_dim)
 
 
-def roll_out_sharded(roll_out_fn, ensemble_size: int, group=None, device: Optional[torch.device] = None, **kwargs) -> torch.Tensor:
-    """Run ``roll_out_fn`` (``roll_out_serial``-compatible) on this rank's members and gather.
+# -- 2-D: (initial time x member) items ---------------------------------------------------------------
+def work_bounds(n_items: int, world_size: int) -> List[int]:
+    """block boundaries: rank r owns items [b[r], b[r+1]); sizes differ by at most one, larger blocks spread evenly"""
+    return [(r * n_items) // world_size for r in range(world_size + 1)]
 
-    The rollout output is ``(n_init, ens_local, C, 1+steps, h, w)``; the gathered result is
-    ``(n_init, ensemble_size, ...)`` on every rank, identical to the single-process output.
-    """
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    ids = shard_members(ensemble_size, rank, world)
-    out = roll_out_fn(ensemble_size=len(ids), member_ids=ids, **kwargs)
-    if device is not None:
-        out = out.to(device)
-    full = gather_members(out, ensemble_size, member_dim=1, group=group)
-    return full
+
+def shard_work(n_init: int, ensemble_size: int, rank: int, world_size: int) -> List[Tuple[int, List[int]]]:
+    """This rank's items as ``[(init index, [member ids]), ...]`` (time-major item order, contiguous block)."""
+    b = work_bounds(n_init * ensemble_size, world_size)
+    groups: List[Tuple[int, List[int]]] = []
+    for i in range(b[rank], b[rank + 1]):
+        t, k = divmod(i, ensemble_size)
+        if groups and groups[-1][0] == t:
+            groups[-1][1].append(k)
+        else:
+            groups.append((t, [k]))
+    return groups
+
+
+def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, group=None, device=None) -> torch.Tensor:
+    """``local``: this rank's items ``(n_local, *item_shape)`` in ``shard_work`` order (``None`` / 0 rows for a rank without
+    work) -> ``(n_init, ensemble_size, *item_shape)`` on every rank.  One small all_reduce tells empty ranks the item shape,
+    one all_gather moves the (padded) blocks."""
+    if not _active(group):
+        assert local is not None and local.shape[0] == n_init * ensemble_size
+        return local.reshape(n_init, ensemble_size, *local.shape[1:])
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    b = work_bounds(n_init * ensemble_size, world)
+    mine = b[rank + 1] - b[rank]
+    if (0 if local is None else local.shape[0]) != mine:
+        raise ValueError("local block does not hold this rank's work items")
+    if device is None:
+        device = local.device if local is not None else torch.device("cpu")
+    meta = torch.zeros(8, dtype=torch.int64, device=device)  # item ndim + dims (<= 7), agreed by MAX over ranks
+    if mine:
+        shp = tuple(local.shape[1:])
+        meta[0] = len(shp)
+        meta[1 : 1 + len(shp)] = torch.tensor(shp, dtype=torch.int64)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+    meta = meta.tolist()
+    item = tuple(int(v) for v in meta[1 : 1 + int(meta[0])])
+    cmax = max(b[r + 1] - b[r] for r in range(world))
+    x = torch.zeros((cmax,) + item, dtype=torch.float32, device=device)
+    if mine:
+        x[:mine] = local.to(device)
+    bufs = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(bufs, x, group=group)
+    out = torch.cat([bufs[r][: b[r + 1] - b[r]] for r in range(world)], dim=0)
+    return out.reshape(n_init, ensemble_size, *item)
+
+
+def roll_out_sharded(roll_out_fn, ensemble_size: int, pred_timestamp: Sequence, group=None, device: Optional[torch.device] = None,
+                     **kwargs) -> torch.Tensor:
+    """Run ``roll_out_fn`` (``roll_out_serial``-compatible) on this rank's (initial time, member) items and gather.
+
+    One call per initial time this rank touches, with ``ensemble_size = len(ids)`` and ``member_ids = ids``; its output is
+    ``(1, len(ids), C, 1+steps, h, w)``.  Returns ``(n_init, ensemble_size, C, 1+steps, h, w)`` on every rank, identical to the
+    single-process output.  A rank without items launches nothing.  ``device``: where the blocks live for the collective
+    (this rank's GPU with the nccl = RCCL backend; the host with gloo)."""
+    if kwargs.get("return_ensemble_mean"):
+        raise ValueError("return_ensemble_mean needs every member on one rank; gather the members and average instead")
+    rank = dist.get_rank(group) if _active(group) else 0
+    world = dist.get_world_size(group) if _active(group) else 1
+    n_init = len(pred_timestamp)
+    blocks = []
+    for t, ids in shard_work(n_init, ensemble_size, rank, world):
+        o = roll_out_fn(ensemble_size=len(ids), member_ids=ids, pred_timestamp=[pred_timestamp[t]], **kwargs)
+        blocks.append(o[0])
+    local = torch.cat(blocks, dim=0) if blocks else None
+    if local is not None and device is not None:
+        local = local.to(device)
+    return gather_work(local, n_init, ensemble_size, group=group, device=device)

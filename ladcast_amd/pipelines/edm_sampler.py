@@ -75,7 +75,7 @@ def edm_AR_sampler(
             st_lat.copy_(latents)
             st_known.copy_(known)
             cn = c_noise.clone()
-            side = torch.cuda.Stream(device=device)
+            side = net.capture_stream() if hasattr(net, "capture_stream") else torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):  # warm-up on the capture stream: per-stream workspaces are created here
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps)

@@ -108,7 +108,7 @@ class AutoRegressive2DPipeline:
             st_img.copy_(image)
             st_known.copy_(known)
             tsteps = [t.to(dev).expand(batch_size).contiguous() for t in sch.timesteps]  # what the eager loop feeds the model
-            side = torch.cuda.Stream(device=dev)
+            side = net.capture_stream() if hasattr(net, "capture_stream") else torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):  # warm-up on the capture stream (per-stream workspaces)
                 loop(st_img, st_known, tsteps)

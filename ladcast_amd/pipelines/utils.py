@@ -47,6 +47,8 @@ def convert_datetime_to_int(dt) -> int:
 def _chan_affine(x, mean, std, target_std, inverse):
     """x: (C, T, H, W) or (B, C, T, H, W) contiguous fp32 device tensor."""
     x = x.contiguous()
+    if x.numel() == 0:  # a rank that owns no members: nothing to launch
+        return torch.empty_like(x)
     dev = x.device
     mean = torch.as_tensor(mean, dtype=torch.float32).to(dev)
     std = torch.as_tensor(std, dtype=torch.float32).to(dev)
@@ -198,6 +200,7 @@ def roll_out_serial(
     noise_level: Optional[float] = 0,
     member_ids: Optional[Sequence[int]] = None,
     known_latents_override: Optional[torch.Tensor] = None,
+    raw_input_fields: Optional[Callable[[datetime], torch.Tensor]] = None,
     **_ignored,  # e.g. log_pred_interval_hour, which the reference CLI passes (evaluate/pred_rollout.py:384, Q2)
 ) -> torch.Tensor:
     """Tensor mode of pipelines/utils.py:249-661.
@@ -205,9 +208,16 @@ def roll_out_serial(
     ``normalization_param_dict``: ``{"mean": (C,), "std": (C,)}`` field statistics (the reference derives
     them from its JSON via ``precompute_mean_std``, :315-317); only used to de-normalise decoded fields.
     Returns ``(n_init, ens, C, 1+steps, h, w)`` fp32 on the host, NaN-initialised (:413-440); slot 0 is
-    the un-normalised IC latent when ``return_latent`` (:486-492) and stays NaN otherwise (the raw
-    field lives in the caller's dataset, not here).  ``known_latents_override`` (extension for
-    latent-only benchmarks): a ``(C, T_in, h, w)`` un-normalised IC latent used instead of encoding.
+    the un-normalised IC latent when ``return_latent`` (:486-492), otherwise the RAW (un-normalised) IC
+    field at t0 as the reference writes it (:462-468): ``raw_input_fields(t0)`` -> ``(C, H, W)`` or
+    ``(C, T, H, W)`` (last frame used) when given - the reference's un-normalised dataset read - else the
+    normalised field de-normalised with ``normalization_param_dict`` (equal up to one fp32 rounding), else
+    NaN.  ``input_fields(t0)`` must return all ``input_seq_len`` frames ``(C, input_seq_len, H, W)``, oldest
+    first (:452-461).  ``known_latents_override`` (extension for latent-only benchmarks): a
+    ``(C, T_in, h, w)`` un-normalised IC latent used instead of encoding.  ``ensemble_size == 0`` (a rank
+    without members) returns the ``(n_init, 0, ...)``-shaped tensor without launching kernels when the
+    shape is known without encoding (``known_latents_override``), and is otherwise handled by the caller
+    (``pipelines/distributed.py``).
     """
     if not return_tensor:
         raise NotImplementedError("xarray output is out of scope; use return_tensor=True")
@@ -232,6 +242,8 @@ def roll_out_serial(
             field_hw = None
         else:
             field = input_fields(t0)  # (C, T_in, H, W) normalised
+            if field.dim() != 4 or field.shape[1] != input_seq_len:
+                raise ValueError(f"input_fields must return (C, input_seq_len={input_seq_len}, H, W), got {tuple(field.shape)}")
             enc = encdec_model.encode(
                 field.permute(1, 0, 2, 3).to(encdec_model.device),
                 static_conditioning_tensor=static_tensor4encdec.unsqueeze(0).to(encdec_model.device),
@@ -250,6 +262,19 @@ def roll_out_serial(
             out = torch.full(shape, float("nan"), dtype=torch.float32, device="cpu")
         if return_latent:
             out[pi, :, :, 0] = known[:, -1].to("cpu").unsqueeze(0).expand(return_size, -1, -1, -1)
+        elif field_hw is not None:  # raw IC field in slot 0 (:462-468)
+            raw = None
+            if raw_input_fields is not None:
+                raw = torch.as_tensor(raw_input_fields(t0), dtype=torch.float32).to("cpu")
+                raw = raw[:, -1] if raw.dim() == 4 else raw
+            elif mean_tensor is not None:
+                m_ = torch.as_tensor(mean_tensor, dtype=torch.float32).to("cpu")[:, None, None]
+                s_ = torch.as_tensor(std_tensor, dtype=torch.float32).to("cpu")[:, None, None]
+                raw = field[:, -1].to("cpu", torch.float32) * s_ + m_
+            if raw is not None:
+                out[pi, :, :, 0] = raw.unsqueeze(0).expand(return_size, -1, -1, -1)
+        if ensemble_size == 0:
+            continue
         known = fwd(known.contiguous())
         if noise_level and noise_level > 0:
             lstd = torch.tensor(latent_transform_args["std"], dtype=torch.float32, device=known.device)[:, None, None, None]

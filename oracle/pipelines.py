@@ -260,6 +260,7 @@ def roll_out_serial(
     return_latent: bool = False,
     noise_level: float = 0,
     member_ids: Optional[Sequence[int]] = None,
+    raw_input_fields: Optional[Callable[[datetime], torch.Tensor]] = None,
     **_ignored,
 ):
     """Tensor mode (``return_tensor=True``) of pipelines/utils.py:249-661.
@@ -267,8 +268,9 @@ def roll_out_serial(
     ``input_fields(t)`` returns the *normalised* ``(C, T_in, H, W)`` field tensor the
     reference gets from ``xarr_to_tensor(ds.sel(time=...), mean, std)`` (:457-461).
     Output: ``(n_init, ens, C, 1+steps, h, w)`` fp32 on CPU, NaN-initialised (:413-440);
-    slot 0 = un-normalised IC latent (return_latent) -- the decoded-mode slot 0 needs
-    the raw field and is left NaN here.  Unknown kwargs (``log_pred_interval_hour``,
+    slot 0 = un-normalised IC latent (return_latent); in decoded mode slot 0 is the RAW IC field
+    ``xarr_to_tensor(ds.sel(time=[t0]))[:, -1]`` (:462-468) = ``raw_input_fields(t0)`` ``(C, H, W)`` when that
+    callable is given, NaN otherwise.  Unknown kwargs (``log_pred_interval_hour``,
     evaluate/pred_rollout.py:384) are accepted and ignored."""
     if total_lead_time_hour % step_size_hour != 0:
         raise ValueError("total_lead_time_hour must be divisible by step_size_hour.")
@@ -298,6 +300,8 @@ def roll_out_serial(
             out = torch.full(shape, float("nan"), dtype=torch.float32, device="cpu")
         if return_latent:
             out[pi, :, :, 0] = known.clone()[:, -1].unsqueeze(0).expand(ensemble_size, -1, -1, -1)
+        elif raw_input_fields is not None:
+            out[pi, :, :, 0] = raw_input_fields(t0).unsqueeze(0).expand(ensemble_size, -1, -1, -1)
         known = fwd(known)
         if noise_level > 0:
             lstd = torch.tensor(latent_transform_args["std"], dtype=torch.float32).to(known.device)[:, None, None, None]

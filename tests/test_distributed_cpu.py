@@ -60,3 +60,90 @@ def test_two_rank_sharded_ensemble_equals_single_process(tmp_path):
     want = OP.ensemble_AR_sampler(pipe, ens, 2, 2, known_latents=synth_known(1), timestamps=torch.tensor([2018010100]), sampler_type="edm")
     assert got.shape == want.shape
     assert ((got - want).norm() / want.norm()).item() < 1e-5  # batch-size dependent BLAS blocking only
+
+
+# -- 2-D (initial time x member) sharding: evaluate/pred_rollout.py:349-358 re-cut so that ens < world and 20 members / 8 ranks work ----
+from ladcast_amd.pipelines.distributed import gather_work, roll_out_sharded, shard_work, work_bounds  # noqa: E402
+
+
+def test_work_sharding_bookkeeping():
+    assert work_bounds(20, 8) == [0, 2, 5, 7, 10, 12, 15, 17, 20]
+    sizes = lambda n, e, w: [sum(len(ids) for _, ids in shard_work(n, e, r, w)) for r in range(w)]  # noqa: E731
+    assert sizes(1, 20, 8) == [2, 3, 2, 3, 2, 3, 2, 3]
+    assert sizes(2, 20, 8) == [5] * 8  # the README's 20 members on 8 ranks balance exactly over two initial times
+    assert sizes(1, 1, 8) == [0, 0, 0, 0, 0, 0, 0, 1]  # ens < world: seven ranks without work
+    assert sizes(8, 16, 8) == [16] * 8  # cfg 3 with one initial time per rank == the reference's own split
+    assert shard_work(2, 3, 1, 2) == [(1, [0, 1, 2])] and shard_work(2, 3, 0, 2) == [(0, [0, 1, 2])]
+    assert shard_work(3, 3, 0, 2) == [(0, [0, 1, 2]), (1, [0])] and shard_work(3, 3, 1, 2) == [(1, [1, 2]), (2, [0, 1, 2])]
+    for n, e, w in ((1, 1, 2), (3, 5, 4), (2, 20, 8), (5, 3, 8)):
+        items = sum(([(t, k) for k in ids] for r in range(w) for t, ids in shard_work(n, e, r, w)), [])
+        assert items == [(t, k) for t in range(n) for k in range(e)]  # every item once, time-major order
+    x = torch.arange(24.0).reshape(6, 4)
+    assert torch.equal(gather_work(x, 2, 3), x.reshape(2, 3, 4))  # no process group: a reshape
+
+
+def _fake_rollout(ensemble_size, member_ids, pred_timestamp, calls=None, **kw):
+    """roll_out_serial's tensor contract with a closed-form value per (initial time, member, lead step): (1, ens, C, 1+steps, h, w)"""
+    assert len(pred_timestamp) == 1 and len(member_ids) == ensemble_size > 0
+    if calls is not None:
+        calls.append((pred_timestamp[0], list(member_ids)))
+    out = torch.empty(1, ensemble_size, 2, 3, 2, 2)
+    for j, k in enumerate(member_ids):
+        out[0, j] = 1000.0 * pred_timestamp[0] + 10.0 * k + torch.arange(24.0).reshape(2, 3, 2, 2) / 100.0
+    return out
+
+
+def _worker_2d(rank, world, port, cases, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for n_init, ens in cases:
+        calls = []
+        full = roll_out_sharded(_fake_rollout, ensemble_size=ens, pred_timestamp=list(range(1, n_init + 1)), calls=calls)
+        res.append((full, calls))
+    torch.save(res, f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_2d_sharding_incl_empty_rank(tmp_path):
+    """ens < world (one rank owns nothing: it must not launch and must not hang the gather), a non-divisible case, and an even one"""
+    cases = [(1, 1), (3, 3), (2, 2), (1, 5)]
+    path = str(tmp_path / "res")
+    mp.spawn(_worker_2d, args=(2, _free_port(), cases, path), nprocs=2, join=True)
+    r0, r1 = torch.load(path + ".0"), torch.load(path + ".1")
+    for (n_init, ens), (f0, c0), (f1, c1) in zip(cases, r0, r1):
+        want = torch.cat([_fake_rollout(ens, list(range(ens)), [t]) for t in range(1, n_init + 1)], dim=0)
+        assert f0.shape == want.shape == (n_init, ens, 2, 3, 2, 2)
+        assert torch.equal(f0, want) and torch.equal(f1, want)  # every rank holds the single-process result
+        done = sorted((t, k) for t, ids in c0 + c1 for k in ids)
+        assert done == [(t, k) for t in range(1, n_init + 1) for k in range(ens)]  # each item computed exactly once
+    assert r0[0][1] == [] and r1[0][1] == [(1, [0])]  # case (1, 1): rank 0 had no work
+
+
+def test_run_rollout_batches_and_files(tmp_path):
+    """run_rollout without a process group: batches of initial times, one latent_YYYYMMDDHH.npy per initial time, reference layout"""
+    from datetime import datetime
+    import numpy as np
+    from ladcast_amd.evaluate import pred_rollout as PR
+
+    times = [datetime(2018, 1, d, 0) for d in (1, 2, 3)]
+    seen = []
+
+    def fake(ensemble_size, member_ids, pred_timestamp, **kw):
+        seen.append((pred_timestamp[0], list(member_ids), kw["return_latent"], kw["latent_transform"], kw["encdec_model_type"]))
+        return _fake_rollout(ensemble_size, member_ids, [pred_timestamp[0].day])
+
+    orig = PR.roll_out_serial
+    PR.roll_out_serial = fake
+    try:
+        res = PR.run_rollout(None, times, pipeline=None, encdec_model=None, latent_transform_args={}, output=str(tmp_path), ensemble_size=2,
+                             total_lead_time_hour=12, batch_size=2)
+    finally:
+        PR.roll_out_serial = orig
+    assert [s[:2] for s in seen] == [(t, [0, 1]) for t in times] and all(s[2:] == (True, "normalize", "ae") for s in seen)
+    assert len(res) == 3 and res[1].shape == (2, 2, 3, 2, 2)
+    for t, r in zip(times, res):
+        f = np.load(os.path.join(str(tmp_path), t.strftime("latent_%Y%m%d%H.npy")))
+        assert np.array_equal(f, r.numpy())

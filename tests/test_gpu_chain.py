@@ -1,0 +1,177 @@
+"""Full-size CHAIN parity (VERDICT r01 "What's weak" 2): error growth over chained forwards is the hard part of this path
+(sigma 80 -> 0.002, c_in down to 0.0125, 39 network evaluations per chunk, chunk output feeding the next chunk), and the
+split-bf16 mode is exactly where it would show.  These tests run BASELINE's literal workloads against the CPU oracle on the
+GPU box and PRINT the error curves (run with -s to see them; the driver's log keeps them).
+
+Budget (north star): rel-L2 <= 1e-4 per sampler chunk / rollout for the fp32 and bf16x3 modes.
+"""
+import time
+from datetime import datetime
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pipelines as OP  # noqa: E402
+from oracle.ar_model import CONFIG_375M  # noqa: E402
+from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler  # noqa: E402
+from tests.synth import make_ar, rel_l2, synth_known, tiny_ar_config  # noqa: E402
+
+TOL = 1e-4
+
+
+def to_hip(oracle_model, cfg):
+    from ladcast_amd.models import LaDCastTransformer3DModel
+
+    m = LaDCastTransformer3DModel.from_config(cfg)
+    m.load_state_dict(oracle_model.state_dict(), strict=True)
+    return m.to("cuda").eval()
+
+
+class Rec:
+    """records the input state and the output of every network evaluation of a sampler run (eager launches only: it hides
+    the model's hipGraph surface on purpose)"""
+
+    _HIDE = ("use_hip_graph", "forward_launch_only", "_graphs", "capture_stream")
+
+    def __init__(self, net):
+        self._net, self.ins, self.outs = net, [], []
+
+    def __getattr__(self, k):
+        if k in Rec._HIDE:
+            raise AttributeError(k)
+        return getattr(self._net, k)
+
+    def __call__(self, x, *a, **kw):
+        o = self._net(x, *a, **kw)
+        y = o[0] if isinstance(o, tuple) else o.sample
+        self.ins.append(x.detach().float().cpu().clone())
+        self.outs.append(y.detach().float().cpu().clone())
+        return o
+
+
+def _curve(a, b):
+    return [rel_l2(x, y) for x, y in zip(a, b)]
+
+
+def _fmt(c):
+    return " ".join(f"{v:.1e}" for v in c)
+
+
+def test_full_375m_chunk_matches_oracle():
+    """BASELINE configs[1], literally: 375M, 1 member, 20 solver steps, one R = 4 chunk - the 39-forward Heun sampler (`edm`) and
+    the 20-forward DPM-Solver++(2M) loop (`pipeline`), exact-fp32 and split-bf16 arithmetic, against the CPU oracle; the
+    per-evaluation error of the network INPUT (state drift) and OUTPUT is printed."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o = make_ar(dict(CONFIG_375M))
+    g = to_hip(o, dict(CONFIG_375M))
+    known, ts = synth_known(1), torch.tensor([2018010100])
+    for sampler, n_fwd in (("edm", 39), ("pipeline", 20)):
+        ro = Rec(o)
+        t0 = time.perf_counter()
+        want = OP.ensemble_AR_sampler(OP.AutoRegressive2DPipeline(ro, OracleScheduler()), 1, 4, 20, known_latents=known, timestamps=ts, sampler_type=sampler)
+        t_cpu = time.perf_counter() - t0
+        assert len(ro.outs) == n_fwd
+        for mode in ("fp32", "bf16x3"):
+            g.set_gemm_precision(mode)
+            rg = Rec(g)
+            got = ensemble_AR_sampler(AutoRegressive2DPipeline(rg, EDMDPMSolverMultistepScheduler()), 1, 4, 20, known_latents=known.cuda(),
+                                      timestamps=ts.cuda(), sampler_type=sampler, device="cuda")
+            assert len(rg.outs) == n_fwd
+            e_in, e_out, e = _curve(rg.ins, ro.ins), _curve(rg.outs, ro.outs), rel_l2(got.cpu(), want)
+            print(f"\n375M {sampler} chunk ({n_fwd} forwards, oracle {t_cpu:.0f} s) [{mode}]: sample rel-L2 {e:.2e}")
+            print(f"  network-input  error per evaluation: {_fmt(e_in)}")
+            print(f"  network-output error per evaluation: {_fmt(e_out)}")
+            assert e < TOL, (sampler, mode, e)
+            assert max(e_in) < TOL and max(e_out) < TOL, (sampler, mode, max(e_in), max(e_out))
+            # the graph-replayed chunk (what bench.py times) gives the same sample bit for bit
+            g.enable_hip_graph(True)
+            got_g = ensemble_AR_sampler(AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), 1, 4, 20, known_latents=known.cuda(),
+                                        timestamps=ts.cuda(), sampler_type=sampler, device="cuda")
+            g.enable_hip_graph(False)
+            assert torch.equal(got_g, got), (sampler, mode)
+        g.set_gemm_precision("fp32")
+
+
+def test_ten_chunk_chain_bf16x3_error_growth():
+    """BASELINE configs[2]'s share of one GPU in shape: 2 members x 40 lead steps = 10 chained chunks of R = 4 (20 Heun steps each,
+    390 forwards per member), tiny widths so the CPU oracle finishes in about a minute.  Each chunk starts from the previous
+    chunk's last frame, so arithmetic differences are fed back ten times.  Stated bound: every chunk's frames stay within 1e-4
+    rel-L2 of the oracle and the error does not grow faster than linearly in the chunk index (chunk c <= (c + 1) x 3e-5)."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    cfg = tiny_ar_config(heads=2, layers=1, single=1, refiner=1)
+    o = make_ar(cfg)
+    g = to_hip(o, cfg)
+    g_ = torch.Generator().manual_seed(9)
+    mu, sd = torch.randn(84, generator=g_) * 0.2, torch.rand(84, generator=g_) + 0.5
+    targs = {"mean": mu.tolist(), "std": sd.tolist(), "target_std": 0.5}
+    ic = synth_known(1)[0] * 2 * sd[:, None, None, None] + mu[:, None, None, None]
+
+    class FakeAE:
+        device = torch.device("cpu")
+        config = type("c", (), dict(latent_channels=84, out_channels=89, static_channels=5))
+
+        def encode(self, x, static_conditioning_tensor=None):
+            return type("o", (), dict(latent=ic.permute(1, 0, 2, 3)))
+
+    t0 = [datetime(2018, 1, 1, 0)]
+    kw = dict(ensemble_size=2, num_inference_steps=20, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=240, sampler_type="edm",
+              return_latent=True)
+    tc = time.perf_counter()
+    want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
+                              static_tensor4encdec=torch.zeros(5, 120, 240), **kw)
+    tc = time.perf_counter() - tc
+    assert want.shape == (1, 2, 84, 41, 15, 30)
+    for mode in ("bf16x3", "fp32"):
+        g.set_gemm_precision(mode).enable_hip_graph(True)
+        got = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **kw)
+        g.enable_hip_graph(False)
+        assert got.shape == want.shape and not torch.isnan(got).any()
+        per_chunk = [rel_l2(got[:, :, :, 1 + 4 * c : 5 + 4 * c], want[:, :, :, 1 + 4 * c : 5 + 4 * c]) for c in range(10)]
+        print(f"\n10-chunk chain, 2 members x 40 lead steps (oracle {tc:.0f} s) [{mode}] per-chunk rel-L2: {_fmt(per_chunk)}")
+        assert max(per_chunk) < TOL, (mode, per_chunk)
+        for c, e in enumerate(per_chunk):
+            assert e <= (c + 1) * 3e-5, (mode, c, e)
+    g.set_gemm_precision("fp32")
+
+
+def test_1_6b_heun_step_truncated_chunk():
+    """BASELINE configs[3] in shape: the 1.6B model, 10 lead steps at R = 4 means the LAST chunk is truncated; here 6 lead steps =
+    one full chunk + one chunk cut to 2 frames, one Heun step pair per chunk (num_inference_steps = 2: 3 forwards), both modes."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from oracle.ar_model import CONFIG_1_6B
+
+    o = make_ar(dict(CONFIG_1_6B))
+    g = to_hip(o, dict(CONFIG_1_6B))
+    targs = {"mean": [0.1] * 84, "std": [1.3] * 84, "target_std": 0.5}
+    ic = synth_known(1)[0] * 2.6 + 0.1
+
+    class FakeAE:
+        device = torch.device("cpu")
+        config = type("c", (), dict(latent_channels=84, out_channels=89, static_channels=5))
+
+        def encode(self, x, static_conditioning_tensor=None):
+            return type("o", (), dict(latent=ic.permute(1, 0, 2, 3)))
+
+    t0 = [datetime(2018, 1, 1, 0)]
+    kw = dict(ensemble_size=1, num_inference_steps=2, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=36, sampler_type="edm",
+              return_latent=True)
+    tc = time.perf_counter()
+    want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
+                              static_tensor4encdec=torch.zeros(5, 120, 240), **kw)
+    tc = time.perf_counter() - tc
+    del o
+    assert want.shape == (1, 1, 84, 7, 15, 30) and not torch.isnan(want).any()
+    for mode in ("fp32", "bf16x3"):
+        g.set_gemm_precision(mode)
+        got = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **kw)
+        assert got.shape == want.shape and not torch.isnan(got).any()
+        e1, e2 = rel_l2(got[:, :, :, 1:5], want[:, :, :, 1:5]), rel_l2(got[:, :, :, 5:7], want[:, :, :, 5:7])
+        print(f"\n1.6B, 6 lead steps = chunk + truncated chunk, 3 forwards each (oracle {tc:.0f} s) [{mode}]: rel-L2 {e1:.2e} / {e2:.2e}")
+        assert e1 < TOL and e2 < TOL, (mode, e1, e2)

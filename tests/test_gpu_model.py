@@ -334,12 +334,18 @@ def test_end_to_end_rollout_with_dcae_matches_oracle():
     t0 = [datetime(2018, 1, 1, 0)]
     kw = dict(ensemble_size=2, num_inference_steps=2, return_seq_len=2, static_tensor4encdec=static, latent_transform_args=targs,
               total_lead_time_hour=18, sampler_type="edm", return_latent=False, encdec_model_type="ae")
+    raw = field[:, -1] * fsd[:, None, None] + fmu[:, None, None]  # the un-normalised IC field the reference reads from its dataset
     want = OP.roll_out_serial(lambda t: field, t0, OP.AutoRegressive2DPipeline(oar, OracleScheduler()), mean_tensor=fmu, std_tensor=fsd,
-                              encdec_model=oae, **kw)
+                              encdec_model=oae, raw_input_fields=lambda t: raw, **kw)
     got = roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()),
                           normalization_param_dict={"mean": fmu, "std": fsd}, encdec_model=gae, **kw)
     assert got.shape == want.shape == (1, 2, 84, 4, 120, 240)
-    assert torch.isnan(got[:, :, :, 0]).all() and torch.isnan(want[:, :, :, 0]).all()  # slot 0 = raw field, owned by the caller
+    assert torch.equal(got[:, :, :, 0], want[:, :, :, 0])  # slot 0 = raw IC field (pipelines/utils.py:462-468), here de-normalised from the input
+    got_raw = roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()), encdec_model=gae,
+                              raw_input_fields=lambda t: raw + 1.0, **dict(kw, total_lead_time_hour=6))
+    assert torch.equal(got_raw[0, 1, :, 0], raw + 1.0)  # an explicit raw-field callable wins; without statistics decoded fields stay normalised
+    with pytest.raises(ValueError):  # input_seq_len frames are the caller's job and are checked
+        roll_out_serial(lambda t: field, t0, AutoRegressive2DPipeline(gar, EDMDPMSolverMultistepScheduler()), encdec_model=gae, input_seq_len=2, **kw)
     assert rel_l2(got[:, :, :, 1:], want[:, :, :, 1:]) < TOL
     # everything on the bf16 matrix cores: AR GEMMs / attention and the DCAE convs in split-bf16 mode, same 1e-4 budget
     gae.set_gemm_precision("bf16x3")
