@@ -69,6 +69,12 @@ typedef struct ldc_gemm_desc {
  *   LDC_GEMM_C_SPLIT  C is written in that format (after bias / activation / gate / residual). */
 #define LDC_GEMM_A_SPLIT 1
 #define LDC_GEMM_C_SPLIT 2
+/*   LDC_GEMM_BF16_1TERM  single-term bf16 contraction Ah.Wh (fp32 accumulate): the "bf16" mixed-precision mode
+ *                     (BASELINE configs[4] "fp16/bf16 mixed"; what torch.autocast(bfloat16) does to an nn.Linear's
+ *                     operands, the reference's fp32 islands - models/LaDCast_3D_model.py:953, models/DCAE.py:162,180 -
+ *                     never reach a GEMM here).  Needs LDC_GEMM_A_SPLIT; all problems of one call must agree.
+ *                     ~2e-3 rel-L2 per model forward instead of ~4e-6. */
+#define LDC_GEMM_BF16_1TERM 4
 int ldc_sizeof_gemm_desc(void);
 int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const float* gate,
                       const float* R, float* C, const ldc_gemm_desc* d, void* stream);
@@ -166,7 +172,11 @@ int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, 
                          const float* cos1, const float* sin1, float eps, void* packed, void* stream);
 int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
                                int out_split, void* stream);
-/* out_split != 0: O is written in the split activation format of LDC_GEMM_A_SPLIT (ldo, o_bs multiples of 8). */
+/* `out_split` is a bit set: LDC_ATTN_OUT_SPLIT = O is written in the split activation format of LDC_GEMM_A_SPLIT (ldo, o_bs
+ * multiples of 8); LDC_ATTN_BF16_1TERM = single-term bf16 products (Qh.Kh, Ph.Vh; fp32 scores, softmax and accumulation):
+ * the attention of the "bf16" mixed-precision mode (see LDC_GEMM_BF16_1TERM). */
+#define LDC_ATTN_OUT_SPLIT 1
+#define LDC_ATTN_BF16_1TERM 2
 
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),

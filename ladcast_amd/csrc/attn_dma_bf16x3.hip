@@ -253,31 +253,52 @@ __device__ __forceinline__ float xor32_add(float x) {
 // fragment addresses are lane base + immediate: K step st at 32 st (+256 for lo); V pair J = 4 tt + dd at
 // 32 dd rows x 144 B + 32 tt (+64 for lo)
 #define LDC_DS_READ_I(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// TERMS = 3: split-bf16 products (lo.hi + hi.lo + hi.hi); TERMS = 1 (the single-term "bf16" mixed-precision mode): hi.hi only -
+// the lo halves of the tile images are staged but never read, P is rounded to bf16 once
 #define LDC_RD_K(FH, FL, ST)                                                     \
   {                                                                              \
     LDC_DS_READ_I(FH, ka, 32 * (ST));                                            \
-    LDC_DS_READ_I(FL, ka, 32 * (ST) + 256);                                      \
+    if constexpr (TERMS == 3) LDC_DS_READ_I(FL, ka, 32 * (ST) + 256);            \
   }
 #define LDC_RD_V(FH, FL, J)                                                      \
   {                                                                              \
     LDC_DS_READ_I(FH, va, ((J) & 3) * (32 * VPITCH) + 32 * ((J) >> 2));          \
-    LDC_DS_READ_I(FL, va, ((J) & 3) * (32 * VPITCH) + 32 * ((J) >> 2) + 64);     \
+    if constexpr (TERMS == 3) LDC_DS_READ_I(FL, va, ((J) & 3) * (32 * VPITCH) + 32 * ((J) >> 2) + 64); \
   }
-#define LDC_W6(FH, FL) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(FH), "+v"(FL))
-#define LDC_WN(N, FH, FL) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FH), "+v"(FL))
+// wait until at most 3 / 2 / 1 / 0 fragment (pairs) are outstanding
+#define LDC_W6(FH, FL)                                                           \
+  if constexpr (TERMS == 3) {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(FH), "+v"(FL));                   \
+  } else {                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(FH));                             \
+  }
+#define LDC_WN(N, FH, FL)                                                        \
+  if constexpr (TERMS == 3) {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FH), "+v"(FL));              \
+  } else if constexpr (N == 4) {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(FH));                             \
+  } else if constexpr (N == 2) {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(FH));                             \
+  } else {                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FH));                             \
+  }
 // one pair of probabilities -> hi / lo bf16 pair I of the P fragment (6 VALU, anchored where it is written)
 #define LDC_SPLIT_PAIR(PH, PL, I, A, B)                                          \
   {                                                                              \
     unsigned u_ = pack_pair(A, B);                                               \
     asm volatile("" : "+v"(u_));                                                 \
     PH[I] = static_cast<int>(u_);                                                \
-    const float t0_ = __uint_as_float(u_ << 16), t1_ = __uint_as_float(u_ & 0xffff0000u); \
-    unsigned l_ = pack_pair((A) - t0_, (B) - t1_);                               \
-    asm volatile("" : "+v"(l_));                                                 \
-    PL[I] = static_cast<int>(l_);                                                \
+    if constexpr (TERMS == 3) {                                                  \
+      const float t0_ = __uint_as_float(u_ << 16), t1_ = __uint_as_float(u_ & 0xffff0000u); \
+      unsigned l_ = pack_pair((A) - t0_, (B) - t1_);                             \
+      asm volatile("" : "+v"(l_));                                               \
+      PL[I] = static_cast<int>(l_);                                              \
+    }                                                                            \
   }
+// an MFMA of a lo term: only in the split mode
+#define LDC_MFX(DST, A, B, C) if constexpr (TERMS == 3) { DST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0); }
 
-template <int NGRP>
+template <int NGRP, int TERMS>
 __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;  // key-range group 0 / 1 (wave-uniform)
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       qh[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
-      ql[s] = *reinterpret_cast<const bf16x8*>(qp + 256 + 32 * s);
+      if constexpr (TERMS == 3) ql[s] = *reinterpret_cast<const bf16x8*>(qp + 256 + 32 * s);
     }
   }
 
@@ -356,6 +377,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
   const unsigned k_row = l31 * KPITCH + 16 * half;
   const unsigned v_row = 2 * KTILE_B + l31 * VPITCH + 16 * half;
   i32x4v fh0, fl0, fh1, fl1, fh2, fl2, fh3, fl3;    // four fragment pairs in flight
+  if constexpr (TERMS == 1) fl0 = fl1 = fl2 = fl3 = i32x4v{0, 0, 0, 0};  // never loaded in the single-term mode
 
   // ---- prologue: S of the group's first tile ----
   f32x16 sA, sB;
@@ -372,9 +394,13 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
     LDC_RD_K(fh2, fl2, 2)
     LDC_RD_K(fh3, fl3, 3)
 #define LDC_QK(FH, FL, ST, C)                                                                               \
-  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), qh[ST], C, 0, 0, 0);         \
-  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ql[ST], sx, 0, 0, 0);        \
-  sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], sx, 0, 0, 0);
+  if constexpr (TERMS == 3) {                                                                               \
+    sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FL), qh[ST], C, 0, 0, 0);       \
+    sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), ql[ST], sx, 0, 0, 0);      \
+    sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], sx, 0, 0, 0);      \
+  } else {                                                                                                  \
+    sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FH), qh[ST], C, 0, 0, 0);       \
+  }
     LDC_W6(fh0, fl0);
     LDC_QK(fh0, fl0, 0, zero16)
     LDC_RD_K(fh0, fl0, 4)
@@ -431,6 +457,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
     float m_new, alpha;
     float r0, r1, r2, r3, r4, r5, r6, r7;
     i32x4v ph0, pl0, ph1, pl1;
+    if constexpr (TERMS == 1) pl0 = pl1 = i32x4v{0, 0, 0, 0};
       // ---- phase A: S_next = K_{t+1} . Q^T (24 MFMAs) with the softmax of S_cur in the MFMA gaps ----
       LDC_RD_K(fh0, fl0, 0)
       LDC_RD_K(fh1, fl1, 1)
@@ -451,21 +478,21 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       }
       LDC_SB;
       LDC_W6(fh0, fl0); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), qh[0], zero16, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl0), qh[0], zero16) LDC_SB;
       sc[0] = __builtin_amdgcn_exp2f(sc[0] - m_new); sc[1] = __builtin_amdgcn_exp2f(sc[1] - m_new); asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), ql[0], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh0), ql[0], sx) LDC_SB;
       sc[2] = __builtin_amdgcn_exp2f(sc[2] - m_new); sc[3] = __builtin_amdgcn_exp2f(sc[3] - m_new); asm volatile("" : "+v"(sc[2]), "+v"(sc[3]));
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), qh[0], sx, 0, 0, 0); LDC_SB;
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), qh[0], TERMS == 3 ? sx : zero16, 0, 0, 0); LDC_SB;
       LDC_RD_K(fh0, fl0, 4)
       sc[4] = __builtin_amdgcn_exp2f(sc[4] - m_new); sc[5] = __builtin_amdgcn_exp2f(sc[5] - m_new); asm volatile("" : "+v"(sc[4]), "+v"(sc[5]));
       LDC_SB;
       LDC_W6(fh1, fl1); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), qh[1], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl1), qh[1], sx) LDC_SB;
       sc[6] = __builtin_amdgcn_exp2f(sc[6] - m_new); sc[7] = __builtin_amdgcn_exp2f(sc[7] - m_new); asm volatile("" : "+v"(sc[6]), "+v"(sc[7]));
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), ql[1], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh1), ql[1], sx) LDC_SB;
       sc[8] = __builtin_amdgcn_exp2f(sc[8] - m_new); sc[9] = __builtin_amdgcn_exp2f(sc[9] - m_new); asm volatile("" : "+v"(sc[8]), "+v"(sc[9]));
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), qh[1], sx, 0, 0, 0); LDC_SB;
@@ -473,10 +500,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       sc[10] = __builtin_amdgcn_exp2f(sc[10] - m_new); sc[11] = __builtin_amdgcn_exp2f(sc[11] - m_new); asm volatile("" : "+v"(sc[10]), "+v"(sc[11]));
       LDC_SB;
       LDC_W6(fh2, fl2); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), qh[2], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl2), qh[2], sx) LDC_SB;
       sc[12] = __builtin_amdgcn_exp2f(sc[12] - m_new); sc[13] = __builtin_amdgcn_exp2f(sc[13] - m_new); asm volatile("" : "+v"(sc[12]), "+v"(sc[13]));
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), ql[2], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh2), ql[2], sx) LDC_SB;
       sc[14] = __builtin_amdgcn_exp2f(sc[14] - m_new); sc[15] = __builtin_amdgcn_exp2f(sc[15] - m_new); asm volatile("" : "+v"(sc[14]), "+v"(sc[15]));
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), qh[2], sx, 0, 0, 0); LDC_SB;
@@ -484,10 +511,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       r0 = sc[0] + sc[1]; r1 = sc[2] + sc[3]; r2 = sc[4] + sc[5]; r3 = sc[6] + sc[7]; asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
       LDC_SB;
       LDC_W6(fh3, fl3); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), qh[3], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl3), qh[3], sx) LDC_SB;
       r4 = sc[8] + sc[9]; r5 = sc[10] + sc[11]; r6 = sc[12] + sc[13]; r7 = sc[14] + sc[15]; asm volatile("" : "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), ql[3], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh3), ql[3], sx) LDC_SB;
       r0 += r1; r2 += r3; r4 += r5; r6 += r7; asm volatile("" : "+v"(r0), "+v"(r2), "+v"(r4), "+v"(r6));
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), qh[3], sx, 0, 0, 0); LDC_SB;
@@ -495,10 +522,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       r0 += r2; r4 += r6; r0 += r4; r0 = xor32_add(r0); l_run = l_run * alpha + r0; m_run = m_new; asm volatile("" : "+v"(l_run));
       LDC_SB;
       LDC_W6(fh0, fl0); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), qh[4], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl0), qh[4], sx) LDC_SB;
       LDC_SPLIT_PAIR(ph0, pl0, 0, sc[0], sc[1])
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), ql[4], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh0), ql[4], sx) LDC_SB;
       LDC_SPLIT_PAIR(ph0, pl0, 1, sc[2], sc[3])
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), qh[4], sx, 0, 0, 0); LDC_SB;
@@ -506,10 +533,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       LDC_SPLIT_PAIR(ph0, pl0, 2, sc[4], sc[5])
       LDC_SB;
       LDC_W6(fh1, fl1); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), qh[5], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl1), qh[5], sx) LDC_SB;
       LDC_SPLIT_PAIR(ph0, pl0, 3, sc[6], sc[7])
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), ql[5], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh1), ql[5], sx) LDC_SB;
       if (kq) dma_k(0);
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), qh[5], sx, 0, 0, 0); LDC_SB;
@@ -517,10 +544,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       if (kq) dma_k(1);
       LDC_SB;
       LDC_W6(fh2, fl2); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), qh[6], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl2), qh[6], sx) LDC_SB;
       if (kq) dma_k(2);
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), ql[6], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh2), ql[6], sx) LDC_SB;
       if (kq) dma_k(3);
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), qh[6], sx, 0, 0, 0); LDC_SB;
@@ -528,10 +555,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       if (vq) dma_v(0);
       LDC_SB;
       LDC_W6(fh3, fl3); LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), qh[7], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fl3), qh[7], sx) LDC_SB;
       if (vq) dma_v(1);
       LDC_SB;
-      sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), ql[7], sx, 0, 0, 0); LDC_SB;
+      LDC_MFX(sx, __builtin_bit_cast(bf16x8, fh3), ql[7], sx) LDC_SB;
       if (vq) dma_v(2);
       LDC_SB;
       sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), qh[7], sx, 0, 0, 0); LDC_SB;
@@ -548,66 +575,66 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_packed
       LDC_SB;
       // ---- phase B: O^T += V_t^T . P^T (24 MFMAs); the second half of P is split in the gaps of the first ----
       LDC_W6(fh0, fl0); LDC_SB;
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph0), o[0], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[0], __builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph0), o[0]) LDC_SB;
       LDC_SPLIT_PAIR(ph1, pl1, 0, sc[8], sc[9])
       LDC_SB;
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl0), o[0], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[0], __builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl0), o[0]) LDC_SB;
       LDC_SB;
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, ph0), o[0], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh0, fl0, 4)
       LDC_SPLIT_PAIR(ph1, pl1, 1, sc[10], sc[11])
       LDC_SB;
       LDC_W6(fh1, fl1); LDC_SB;
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph0), o[1], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[1], __builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph0), o[1]) LDC_SB;
       LDC_SB;
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl0), o[1], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[1], __builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl0), o[1]) LDC_SB;
       LDC_SPLIT_PAIR(ph1, pl1, 2, sc[12], sc[13])
       LDC_SB;
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, ph0), o[1], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh1, fl1, 5)
       LDC_SB;
       LDC_W6(fh2, fl2); LDC_SB;
-      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph0), o[2], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[2], __builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph0), o[2]) LDC_SB;
       LDC_SPLIT_PAIR(ph1, pl1, 3, sc[14], sc[15])
       LDC_SB;
-      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl0), o[2], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[2], __builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl0), o[2]) LDC_SB;
       LDC_SB;
       o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, ph0), o[2], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh2, fl2, 6)
       LDC_SB;
       LDC_W6(fh3, fl3); LDC_SB;
-      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph0), o[3], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[3], __builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph0), o[3]) LDC_SB;
       LDC_SB;
-      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl0), o[3], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[3], __builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl0), o[3]) LDC_SB;
       LDC_SB;
       o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, ph0), o[3], 0, 0, 0); LDC_SB;
       LDC_RD_V(fh3, fl3, 7)
       LDC_SB;
       LDC_W6(fh0, fl0); LDC_SB;
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph1), o[0], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[0], __builtin_bit_cast(bf16x8, fl0), __builtin_bit_cast(bf16x8, ph1), o[0]) LDC_SB;
       LDC_SB;
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl1), o[0], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[0], __builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, pl1), o[0]) LDC_SB;
       LDC_SB;
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh0), __builtin_bit_cast(bf16x8, ph1), o[0], 0, 0, 0); LDC_SB;
       LDC_SB;
       LDC_WN(4, fh1, fl1); LDC_SB;
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph1), o[1], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[1], __builtin_bit_cast(bf16x8, fl1), __builtin_bit_cast(bf16x8, ph1), o[1]) LDC_SB;
       LDC_SB;
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl1), o[1], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[1], __builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, pl1), o[1]) LDC_SB;
       LDC_SB;
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh1), __builtin_bit_cast(bf16x8, ph1), o[1], 0, 0, 0); LDC_SB;
       LDC_SB;
       LDC_WN(2, fh2, fl2); LDC_SB;
-      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph1), o[2], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[2], __builtin_bit_cast(bf16x8, fl2), __builtin_bit_cast(bf16x8, ph1), o[2]) LDC_SB;
       LDC_SB;
-      o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl1), o[2], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[2], __builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, pl1), o[2]) LDC_SB;
       LDC_SB;
       o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh2), __builtin_bit_cast(bf16x8, ph1), o[2], 0, 0, 0); LDC_SB;
       LDC_SB;
       LDC_WN(0, fh3, fl3); LDC_SB;
-      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph1), o[3], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[3], __builtin_bit_cast(bf16x8, fl3), __builtin_bit_cast(bf16x8, ph1), o[3]) LDC_SB;
       LDC_SB;
-      o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl1), o[3], 0, 0, 0); LDC_SB;
+      LDC_MFX(o[3], __builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, pl1), o[3]) LDC_SB;
       LDC_SB;
       o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh3), __builtin_bit_cast(bf16x8, ph1), o[3], 0, 0, 0); LDC_SB;
       LDC_SB;
@@ -724,6 +751,8 @@ extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, i
   if (out_split && ((ldo & 7) || (o_bs & 7) || (reinterpret_cast<unsigned long long>(O) & 31ull))) return LDC_ERR_ALIGN;
   if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   AttnArgs p{};
+  const bool one_term = (out_split & LDC_ATTN_BF16_1TERM) != 0;
+  out_split &= LDC_ATTN_OUT_SPLIT;
   p.out_split = out_split ? 1 : 0;
   p.nt = ldc_cdiv(S, KT);
   const long long tiles = static_cast<long long>(B) * H * p.nt;
@@ -735,18 +764,25 @@ extern "C" int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, i
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1, 3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<1, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_packed_kernel<2, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
     return true;
   }();
   (void)attr_set;
   const long long nwg = static_cast<long long>(p.nq) * H * B;
-  if (nwg <= 256) {
-    hipLaunchKernelGGL(attn_fwd_packed_kernel<2>, grid, dim3(512), 2 * GROUP_LDS, static_cast<hipStream_t>(stream), p);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (one_term) {
+    if (nwg <= 256) hipLaunchKernelGGL((attn_fwd_packed_kernel<2, 1>), grid, dim3(512), 2 * GROUP_LDS, st, p);
+    else hipLaunchKernelGGL((attn_fwd_packed_kernel<1, 1>), grid, dim3(256), GROUP_LDS, st, p);
   } else {
-    hipLaunchKernelGGL(attn_fwd_packed_kernel<1>, grid, dim3(256), GROUP_LDS, static_cast<hipStream_t>(stream), p);
+    if (nwg <= 256) hipLaunchKernelGGL((attn_fwd_packed_kernel<2, 3>), grid, dim3(512), 2 * GROUP_LDS, st, p);
+    else hipLaunchKernelGGL((attn_fwd_packed_kernel<1, 3>), grid, dim3(256), GROUP_LDS, st, p);
   }
   return ldc_launch_status();
 }

@@ -168,7 +168,9 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 #define LDC_STAMP_CLK(i)
 #endif
 
-template <int BM>
+// TERMS = 3: split-bf16 contraction Ah.Wh + Ah.Wl + Al.Wh; TERMS = 1 (LDC_GEMM_BF16_1TERM, the "bf16" mixed-precision mode):
+// Ah.Wh only - the same operand images, the lo chunks are staged but never read (a third of the MFMAs, half the fragment reads)
+template <int BM, int TERMS>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
   constexpr int NACC = RT * 8;                 // accumulators (f32x4) per lane
@@ -273,21 +275,26 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 
     i32x4v wh0, wl0, wh1, wl1, wh2, wl2, wh3, wl3;           // W fragment window: 4 column tiles
     i32x4v ah0[RT], al0[RT], ah1[RT], al1[RT];               // A fragments of the current / next k-step
+    if constexpr (TERMS == 1) {  // the lo registers are never loaded: give the asm constraints below a defined value
+      wl0 = wl1 = wl2 = wl3 = i32x4v{0, 0, 0, 0};
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) al0[rt] = al1[rt] = i32x4v{0, 0, 0, 0};
+    }
 
 #define LDC_SB __builtin_amdgcn_sched_barrier(0)
     // SBH / SBL: lane base (hi / lo chunk) + stage offset; the tile offset is an immediate
 #define LDC_RD_W(WH, WL, SBH, SBL, CT)                                           \
   {                                                                              \
     LDC_DS_READ(WH, SBH, (CT) * (16 * ROW_B));                                   \
-    LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));                                   \
+    if constexpr (TERMS == 3) LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));         \
   }
 #define LDC_RD_A(AH, AL, SBH, SBL)                                               \
   {                                                                              \
     LDC_DS_READ(AH[0], SBH, 0);                                                  \
-    LDC_DS_READ(AL[0], SBL, 0);                                                  \
+    if constexpr (TERMS == 3) LDC_DS_READ(AL[0], SBL, 0);                        \
     if constexpr (RT == 2) {                                                     \
       LDC_DS_READ(AH[RT - 1], SBH, 16 * ROW_B);                                  \
-      LDC_DS_READ(AL[RT - 1], SBL, 16 * ROW_B);                                  \
+      if constexpr (TERMS == 3) LDC_DS_READ(AL[RT - 1], SBL, 16 * ROW_B);        \
     }                                                                            \
   }
 #define LDC_MM(ACC, WF, AF)                                                                                  \
@@ -296,7 +303,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     // the 3 RT MFMAs of column tile CT with A fragments (AH, AL); with two row tiles their accumulation chains alternate
 #define LDC_CT(CT, WH, WL, AH, AL)                                               \
   {                                                                              \
-    if constexpr (RT == 2) {                                                     \
+    if constexpr (TERMS == 1) {                                                  \
+      LDC_MM(acc[(CT)], WH, AH[0])                                               \
+      if constexpr (RT == 2) {                                                   \
+        LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])                                    \
+      }                                                                          \
+    } else if constexpr (RT == 2) {                                              \
       LDC_MM(acc[(CT)], WH, AL[0])                                               \
       LDC_MM(acc[8 + (CT)], WH, AL[RT - 1])                                      \
       LDC_MM(acc[(CT)], WL, AH[0])                                               \
@@ -314,7 +326,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #else
 #define LDC_KSTEP_BARRIER __builtin_amdgcn_s_barrier();
 #endif
-#define LDC_WAIT(N, X, Y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X), "+v"(Y)); LDC_SB;
+    // wait until the fragment window holds at most 3 column tiles of outstanding reads (6 reads with lo chunks, 3 without)
+#define LDC_WAIT(N, X, Y)                                                        \
+  if constexpr (TERMS == 3) {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(X), "+v"(Y));                     \
+  } else {                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(X), "+v"(Y));                     \
+  }                                                                              \
+  LDC_SB;
     // one k-step: (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt+1
 #define LDC_KSTEP(AH, AL, AHN, ALN)                                                                          \
   {                                                                                                          \
@@ -326,10 +345,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     constexpr bool dma2 = true; /* second half of k-step kt+2's DMAs (clamped past the end) */             \
     constexpr bool dma3 = true; /* first half of k-step kt+3's (into stage st, free behind barrier(kt+1)) */ \
     /* W(kt, 0..3) were issued in the order 0, 1, 2, 3 and nothing after them except A(kt) before them */    \
-    if constexpr (RT == 2) {                                                                                 \
+    if constexpr (RT == 2 && TERMS == 3) {                                                                   \
       asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
-    } else {                                                                                                 \
+    } else if constexpr (TERMS == 3) {                                                                       \
       asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                 \
+    } else if constexpr (RT == 2) {                                                                          \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(wh0));                            \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(AH[0]), "+v"(wh0));                                         \
     }                                                                                                        \
     LDC_SB;                                                                                                  \
     LDC_CT(0, wh0, wl0, AH, AL)                                                                              \
@@ -488,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   LDC_STAMP(15)
 }
 
-template <int BM>
+template <int BM, int TERMS>
 int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
@@ -598,12 +621,12 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
   a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM, TERMS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(gemm_bf16x3_v3_kernel<BM>, dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<BM, TERMS>), dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
   return ldc_launch_status();
 }
 
@@ -619,6 +642,7 @@ int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* wo
     const ldc_gemm_desc& d = problems[i].d;
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return LDC_ERR_ARG;
     if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
+    if (((d.flags ^ problems[0].d.flags) & LDC_GEMM_BF16_1TERM) != 0) return LDC_ERR_ARG;  // one arithmetic per launch
     tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
   }
   // half-height tiles while 256-row tiles would not fill the chip twice over (both heights run 8 waves here, so the
@@ -627,6 +651,9 @@ int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* wo
   bool small = tiles256 < (force_thr ? atoll(force_thr) : 400);  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
   static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
   if (force_bm) small = (atoi(force_bm) == 128);
-  return small ? launch_v3<128>(problems, n, workspace, workspace_bytes, stream)
-               : launch_v3<256>(problems, n, workspace, workspace_bytes, stream);
+  if (problems[0].d.flags & LDC_GEMM_BF16_1TERM)
+    return small ? launch_v3<128, 1>(problems, n, workspace, workspace_bytes, stream)
+                 : launch_v3<256, 1>(problems, n, workspace, workspace_bytes, stream);
+  return small ? launch_v3<128, 3>(problems, n, workspace, workspace_bytes, stream)
+               : launch_v3<256, 3>(problems, n, workspace, workspace_bytes, stream);
 }

@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
-GEMM_A_SPLIT, GEMM_C_SPLIT = 1, 2
+GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
+ATTN_OUT_SPLIT, ATTN_BF16_1TERM = 1, 2
 
 
 class GemmDesc(Structure):
@@ -260,9 +261,11 @@ def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None
                                     *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
 
 
-def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False):
+def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False, one_term=False):
+    """one_term: single-term bf16 products (the "bf16" mixed-precision mode) instead of the split-bf16 three"""
     _dev(packed, O)
-    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, 1 if out_split else 0, _stream()),
+    flags = (ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
+    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, flags, _stream()),
            "ldc_attn_fwd_packed_bf16x3")
 
 

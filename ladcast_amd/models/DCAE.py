@@ -249,8 +249,13 @@ class AutoencoderDC(ModelMixin):
         """'fp32' (default): every conv on the exact-fp32 matrix cores; 'bf16x3': the dense 3x3 SphereConv2d layers
         (75 % of the FLOPs) as split-bf16 implicit GEMMs (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~4e-6 per layer) --
         1x1 convs, depthwise convs, norms and the linear attention stay fp32."""
+        if precision == "bf16":
+            # the mixed-precision mode of the AR transformer (one bf16 MFMA per product): the conv kernels have no single-term
+            # body yet, so the DCAE share of a mixed-precision run is computed with the split-bf16 convs - tighter, not looser,
+            # than asked; the reference's fp32 islands (ReLU linear attention, models/DCAE.py:162,180) are fp32 in every mode
+            precision = "bf16x3"
         if precision not in ("fp32", "bf16x3"):
-            raise ValueError("gemm precision must be 'fp32' or 'bf16x3'")
+            raise ValueError("gemm precision must be 'fp32', 'bf16x3' or 'bf16'")
         if precision != self.gemm_precision:
             self.gemm_precision = precision
             self._plan = None

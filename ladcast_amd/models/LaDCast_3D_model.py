@@ -274,9 +274,16 @@ class LaDCastTransformer3DModel(ModelMixin):
         """"fp32": exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  "bf16x3": split-bf16 error-compensated
         contraction on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32 accumulate), ~4e-6 rel-L2 per
         forward vs fp32 -- see DESIGN.md section 4.  Applies to the token-stream GEMMs and both attention
-        contractions; softmax, norms, RoPE, modulation vectors and the sampler state stay fp32 / fp64."""
-        if mode not in ("fp32", "bf16x3"):
-            raise ValueError("gemm precision must be 'fp32' or 'bf16x3'")
+        contractions; softmax, norms, RoPE, modulation vectors and the sampler state stay fp32 / fp64.
+        "bf16": the mixed-precision mode of BASELINE configs[4] ("fp16/bf16 mixed") - the same kernels and operand images
+        with the lo terms skipped: ONE bf16 MFMA per product (operands rounded to bf16, fp32 accumulate), what
+        ``torch.autocast(bfloat16)`` does to the reference's Linears and SDPA.  Everything the reference keeps in fp32 under
+        autocast stays fp32 here as in the other modes (conditioning embedding ``temb``, models/LaDCast_3D_model.py:953; all
+        (B, D)-vector Linears; norms, softmax statistics, RoPE, residual stream, fp64 sampler state) - and the GEMM outputs
+        are NOT rounded to bf16, so the mode is strictly tighter than autocast.  Tolerance: ~2e-3 rel-L2 per forward vs the
+        fp32 oracle (tests/test_gpu_model.py::test_bf16_single_term_mode)."""
+        if mode not in ("fp32", "bf16x3", "bf16"):
+            raise ValueError("gemm precision must be 'fp32', 'bf16x3' or 'bf16'")
         if mode != self.gemm_precision:
             self.gemm_precision = mode
             self._plan = None
@@ -361,7 +368,8 @@ class LaDCastTransformer3DModel(ModelMixin):
             plan.mod_off[id(m)] = off
             off += m.weight.shape[0]
         # split-bf16 mode: every token-stream GEMM weight gets a pre-split [N][K/8][hi|lo] copy (same bytes as fp32)
-        plan.split = self.gemm_precision == "bf16x3"
+        plan.split = self.gemm_precision in ("bf16x3", "bf16")  # both run on the split operand images
+        plan.one_term = self.gemm_precision == "bf16"
         plan.packed = {}
         if plan.split:
             ws = [e.wqkv for e in plan.attn.values()] + [e.wqkv_c for e in plan.attn.values() if hasattr(e, "wqkv_c")]
@@ -456,7 +464,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         k = qkv[:, row0:, D : 2 * D]
         v = qkv[:, row0:, 2 * D : 3 * D]
         segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
-        if self.gemm_precision == "bf16x3":
+        if self.gemm_precision in ("bf16x3", "bf16"):
             if ws.apack is None:
                 ws.apack = torch.empty(hip.attn_packed_bytes(B, full, H) // 4, device=qkv.device, dtype=torch.float32)
             if any(sg_[1][0].eps != segs[0][1][0].eps or sg_[1][1].eps != segs[0][1][0].eps for sg_ in segs):
@@ -465,7 +473,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             sg.append((None, None, None, None))
             hip.attn_pack(q, k, v, ws.apack, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, split_row=segs[0][0],
                           seg0=sg[0], seg1=sg[1], eps=segs[0][1][0].eps)
-            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs, out_split=out_split)
+            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs, out_split=out_split, one_term=self.gemm_precision == "bf16")
             return
         r0 = row0
         for rows, (nq, nk, c, s_) in segs:
@@ -605,7 +613,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         # split-bf16 mode: activations that only feed GEMMs (LayerNorm outputs, attention outputs, MLP hidden states)
         # are written ONCE in the split format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT / _C_SPLIT); the
         # buffers, strides and column offsets are the same as in fp32 mode
-        AS = hip.GEMM_A_SPLIT if split else 0
+        AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
         CS = hip.GEMM_C_SPLIT if split else 0
 
         def G(A, W, C, **kw):  # weight in the format of the active precision mode

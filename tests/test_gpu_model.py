@@ -400,3 +400,49 @@ def test_driver_counterpart_writes_the_reference_file_layout(tmp_path):
                                   static_tensor4encdec=static, latent_transform_args=targs, return_latent=True, **kw)[0]
         assert rel_l2(arr, want) < TOL
         assert rel_l2(arr[:, :, 0], want[:, :, 0]) < 2e-5  # slot 0: the encoded, un-normalised initial condition
+
+
+def test_bf16_single_term_mode(tiny_pair):
+    """BASELINE configs[4] ("fp16/bf16 mixed"): `set_gemm_precision("bf16")` = one bf16 MFMA per product in the token-stream GEMMs and
+    both attention contractions, everything the reference pins to fp32 under autocast left in fp32 (temb: LaDCast_3D_model.py:953;
+    norms, softmax statistics, residual stream, fp64 sampler state).  STATED TOLERANCE vs the fp32 oracle: 5e-3 rel-L2 per forward,
+    2e-2 per 20-step Heun chunk (bf16 has 8 significand bits: 2^-9 = 2e-3 per rounding); the 1e-4 budget does not apply to this mode."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o, g = tiny_pair
+    g.set_gemm_precision("bf16")
+    try:
+        x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+        known, ts = synth_known(1), torch.tensor([2018010100])
+        with torch.no_grad():
+            want = o(x, torch.tensor([0.3]), known.expand(2, -1, -1, -1, -1), time_elapsed=ts).sample
+        got = g(x.cuda(), torch.tensor([0.3]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
+        e_fwd = rel_l2(got.cpu(), want)
+        opipe = OP.AutoRegressive2DPipeline(o, OracleScheduler())
+        want = OP.ensemble_AR_sampler(opipe, 2, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm")
+        gpipe = AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())
+        got = ensemble_AR_sampler(gpipe, 2, 4, 20, known_latents=known.cuda(), timestamps=ts.cuda(), sampler_type="edm", device="cuda")
+        e_chunk = rel_l2(got.cpu(), want)
+        g.enable_hip_graph(True)
+        got_g = ensemble_AR_sampler(gpipe, 2, 4, 20, known_latents=known.cuda(), timestamps=ts.cuda(), sampler_type="edm", device="cuda")
+        g.enable_hip_graph(False)
+        print(f"\nbf16 (single-term): tiny forward rel-L2 {e_fwd:.2e}, 20-step Heun chunk rel-L2 {e_chunk:.2e}")
+        assert 1e-5 < e_fwd < 5e-3, e_fwd  # lower bound: the mode is really on
+        assert e_chunk < 2e-2, e_chunk
+        assert torch.equal(got_g, got)
+    finally:
+        g.set_gemm_precision("fp32")
+
+
+def test_full_375m_forward_bf16_single_term():
+    o = make_ar(dict(CONFIG_375M))
+    g = to_hip(o, dict(CONFIG_375M)).set_gemm_precision("bf16")
+    x = torch.randn(1, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+    known, ts = synth_known(1), torch.tensor([2018010100])
+    with torch.no_grad():
+        want = o(x, torch.tensor([0.3]), known, time_elapsed=ts).sample
+    got = g(x.cuda(), torch.tensor([0.3]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
+    e = rel_l2(got.cpu(), want)
+    print(f"\n375M bf16 (single-term) forward rel-L2 {e:.2e}")
+    assert 1e-5 < e < 5e-3, e

@@ -621,3 +621,54 @@ def test_sampler_state_kernels_are_bit_exact(hip):
     m0 = c_skip * smp + c_out * Fm
     want = a * smp - b * m0 - (0.5 * b) * (inv_r0 * (m0 - m1))
     assert torch.equal(x0.cpu(), m0) and torch.equal(prev.cpu(), want)
+
+
+# -- single-term bf16 mode (LDC_GEMM_BF16_1TERM / LDC_ATTN_BF16_1TERM; BASELINE configs[4] "fp16/bf16 mixed") -------------------
+@pytest.mark.parametrize("M,N,K,batch", [(2250, 1536, 1536, 1), (450, 4608, 1536, 2), (2250, 1536, 7680, 1), (300, 264, 160, 1), (5000, 6144, 1536, 1),
+                                         (1, 8, 32, 1), (1800, 84, 1536, 1)])
+def test_gemm_bf16_single_term(hip, M, N, K, batch):
+    """C = bf16(A) . bf16(W)^T with fp32 accumulation: bit-level statement of the mode - against the fp64 product of the
+    ROUNDED operands only the accumulation order differs (1e-5); against the unrounded product it is bf16-accurate (stated
+    tolerance 6e-3: two operands with 2^-9 relative rounding each, averaged over K)."""
+    A, W, b = rnd(batch, M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
+    Ap = hip.pack_weight_bf16x2(dev(A).reshape(batch * M, K))
+    Wp = hip.pack_weight_bf16x2(dev(W))
+    C = torch.empty(batch, M, N, device="cuda")
+    f1 = hip.GEMM_A_SPLIT | hip.GEMM_BF16_1TERM
+    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b), flags=f1)], split_bf16=True)
+    want_r = A.bfloat16().double() @ W.bfloat16().double().T + b.double()
+    assert rel(C, want_r) < 1e-5
+    e = rel(C, A.double() @ W.double().T + b.double())
+    assert 1e-4 < e < 6e-3, e  # it really is the single-term product, not the compensated one
+    # the split-bf16 contraction on the same images for comparison
+    C3 = torch.empty_like(C)
+    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C3, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b), flags=hip.GEMM_A_SPLIT)], split_bf16=True)
+    assert rel(C3, A.double() @ W.double().T + b.double()) < 1e-5
+    with pytest.raises(RuntimeError):  # one arithmetic per launch
+        hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, flags=f1),
+                          hip.gemm_problem(Ap, Wp, C3, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, flags=hip.GEMM_A_SPLIT)], split_bf16=True)
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 97, 2)])
+def test_attention_packed_bf16_single_term(hip, B, S, H):
+    """Qh.Kh^T scores (fp32), fp32 softmax, bf16(P).Vh: vs fp64 SDPA on the bf16-ROUNDED q, k, v the remaining difference is the
+    rounding of P (2^-9 relative per probability, averaged by the sum: stated 3e-3); vs SDPA on the raw operands 1e-2."""
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 4.0
+    d_qkv = dev(qkv)
+    pk = _packed(hip, B, S, H)
+    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_pack(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, split_row=S)
+    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64), one_term=True)
+    scale = 0.08838834764831845 * 1.4426950408889634  # the pack pass folds log2(e)/sqrt(128) into q BEFORE the rounding
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2) for t in qkv.split(D, dim=-1)]
+    qr = ((q * scale).bfloat16().double() / scale)
+    want_r = F.scaled_dot_product_attention(qr, k.bfloat16().double(), v.bfloat16().double()).transpose(1, 2).reshape(B, S, D)
+    want = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(out[:, :, :D]).all() and torch.isnan(out[:, :, D:]).all()
+    assert rel(out[:, :, :D], want_r) < 3e-3
+    assert rel(out[:, :, :D], want) < 1e-2
+    out3 = torch.empty_like(out)
+    hip.attn_fwd_packed(pk, out3, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64))
+    assert rel(out3[:, :, :D], want) < 2e-5  # the same images still serve the split mode
