@@ -47,6 +47,7 @@ struct DevProblem {
   float* C;
   ldc_gemm_desc d;
   int tm, tn, kt;
+  int rm;       // tile order: super-rows of rm row tiles, inside a super-row column panel by column panel (launch_v3)
   long long unit0;
   long long tile0;
   int vec4;     // epilogue may use 16-byte accesses
@@ -225,10 +226,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
     const long long left = u_end - u;
     const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
-    const int bm = tile % P.tm;  // row tile fastest: consecutive tiles share one W column panel
-    const int bnb = tile / P.tm;
-    const int bn = bnb % P.tn;
-    const int b = bnb / P.tn;
+    // tile order (speed only): batch, then super-rows of rm row tiles, then column panels, row tile fastest.  An XCD owns a
+    // contiguous run of units, i.e. about rm row panels x (tiles per XCD / rm) column panels: with rm = tm (one super-row)
+    // every XCD streams ALL of A and 1/8 of W; a squarer block fetches fewer bytes through the fabric (launch_v3 picks rm)
+    const int per_b = P.tm * P.tn;
+    const int b = tile / per_b;
+    const int t_in = tile - b * per_b;
+    const int strip = P.rm * P.tn;
+    const int sr = t_in / strip;
+    const int r_in = t_in - sr * strip;
+    const int h_sr = (P.tm - sr * P.rm) < P.rm ? (P.tm - sr * P.rm) : P.rm;
+    const int bn = r_in / h_sr;
+    const int bm = sr * P.rm + (r_in - bn * h_sr);
     const int M = P.d.M, N = P.d.N, K = P.d.K;
     const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
     const int lda = P.d.lda;
@@ -557,6 +566,27 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
     P.kt = d.K / BK;
     P.unit0 = U;
     P.tile0 = tiles;
+    {
+      // super-row height: an XCD's share is ~T8 = tiles / 8 consecutive tiles = rm row panels x T8 / rm column panels; per k-step
+      // it pulls rm * BM + (T8 / rm) * BN operand rows through the fabric -> minimum at rm = sqrt(T8 * BN / BM); super-rows of
+      // (nearly) equal height.  Only when the activation panel is what the one-super-row order over-fetches (every XCD streams all
+      // of A): measured (tools/gemm_rm_ab.py, profiles/r02_c_gemm_tile_order_ab.log) 2250 x 1536 x 7680 -3.4 % time / -31 % fabric
+      // bytes and 18000 x 1536 x 7680 -10 %, but +3 % on 2250 x 4608 / 10752 x 1536, whose 14 MB A panel stays cached anyway.
+      // LDC_BF16X3_RM (measurement aid, read per call): force it; 0 = one super-row
+      P.rm = P.tm;
+      if (static_cast<double>(d.batch) * d.M * d.K * 4.0 >= 48e6) {
+        const double t8 = static_cast<double>(d.batch) * P.tm * P.tn / 8.0;
+        const double want = sqrt(t8 * BN / BM);
+        int nsr = static_cast<int>(P.tm / (want > 1.0 ? want : 1.0) + 0.5);
+        if (nsr < 1) nsr = 1;
+        if (nsr > P.tm) nsr = P.tm;
+        P.rm = ldc_cdiv(P.tm, nsr);
+      }
+      if (const char* e = getenv("LDC_BF16X3_RM")) {
+        const int f = atoi(e);
+        if (f >= 0) P.rm = (f == 0 || f > P.tm) ? P.tm : f;
+      }
+    }
     const long long t = static_cast<long long>(d.batch) * P.tm * P.tn;
     tiles += t;
     U += t * P.kt;

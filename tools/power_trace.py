@@ -37,10 +37,21 @@ class Sampler(threading.Thread):
     def __init__(self):
         super().__init__(daemon=True)
         self.nodes = {}
+        # the box is a slice of a multi-GPU node: every card is in sysfs, only one is ours -> match the PCI address of HIP device 0
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}".lower()
+        except Exception:
+            pass
+        self.pci = want
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            if want is not None and want not in os.path.realpath(card).lower():
+                continue
             hw = sorted(glob.glob(card + "/hwmon/hwmon*"))
             if not hw:
                 continue
+            self.card = card
             for name in ("power1_average", "power1_input", "power1_cap", "freq1_input", "temp1_input"):
                 p = os.path.join(hw[0], name)
                 if _read(p) is not None:
@@ -106,7 +117,7 @@ def main():
     import ladcast_amd.hip as hip
 
     smp = Sampler()
-    res = {"mode": MODE, "seconds_per_shape": SECONDS, "period_ms": PERIOD * 1e3, "nodes": smp.nodes, "cli": smp.cli, "device": torch.cuda.get_device_name(0), "shapes": {}}
+    res = {"mode": MODE, "pci": smp.pci, "card": getattr(smp, "card", None), "seconds_per_shape": SECONDS, "period_ms": PERIOD * 1e3, "nodes": smp.nodes, "cli": smp.cli, "device": torch.cuda.get_device_name(0), "shapes": {}}
     smp.start()
     time.sleep(1.0)
     idle = smp.take()
