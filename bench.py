@@ -125,7 +125,8 @@ class KernelTimer:
 
     def install(self, hip):
         self._hip = hip
-        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped, "attn_fwd_packed": hip.attn_fwd_packed}
+        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped, "attn_fwd_packed": hip.attn_fwd_packed,
+                      "gemm_grouped_qkv": hip.gemm_grouped_qkv, "attn_fwd_split": hip.attn_fwd_split}
         timer = self
 
         def gemm_grouped(problems, split_bf16=False):
@@ -166,11 +167,28 @@ class KernelTimer:
             e.record()
             timer.records.setdefault("attn_fwd_packed_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
+        def gemm_grouped_qkv(problems, epilogues):  # QKV projections with the attention-operand epilogue: the same kernel, same FLOPs
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer._orig["gemm_grouped_qkv"](problems, epilogues)
+            e.record()
+            work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
+            timer.records.setdefault("gemm_bf16x3_v3_kernel", []).append((s, e, work))
+
+        def attn_fwd_split(Q, K, V, O, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            timer._orig["attn_fwd_split"](Q, K, V, O, **kw)
+            e.record()
+            timer.records.setdefault("attn_fwd_split_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
+
         hip.gemm, hip.attn_fwd, hip.gemm_grouped, hip.attn_fwd_packed = gemm, attn_fwd, gemm_grouped, attn_fwd_packed
+        hip.gemm_grouped_qkv, hip.attn_fwd_split = gemm_grouped_qkv, attn_fwd_split
 
     def uninstall(self):
         self._hip.gemm, self._hip.attn_fwd, self._hip.gemm_grouped = self._orig["gemm"], self._orig["attn_fwd"], self._orig["gemm_grouped"]
         self._hip.attn_fwd_packed = self._orig["attn_fwd_packed"]
+        self._hip.gemm_grouped_qkv, self._hip.attn_fwd_split = self._orig["gemm_grouped_qkv"], self._orig["attn_fwd_split"]
 
     def clear(self):
         self.records = {}
@@ -502,7 +520,7 @@ def main():
             "roofline": roof,
         }
         for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS), ("attn_fwd_bf16x3_kernel", PEAK_BF16_MFMA_TFLOPS),
-                          ("attn_fwd_packed_kernel", PEAK_BF16_MFMA_TFLOPS)):
+                          ("attn_fwd_packed_kernel", PEAK_BF16_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):
             if an in ks:
                 k = ks[an]
                 line["attention_kernel"] = dict(kernel=an, achieved=round(k["tflops"], 2), peak=apeak, unit="TFLOP/s", frac=round(k["tflops"] / apeak, 4),

@@ -178,6 +178,40 @@ int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H
 #define LDC_ATTN_OUT_SPLIT 1
 #define LDC_ATTN_BF16_1TERM 2
 
+/* Split-bf16 attention on ROW-MAJOR operand rows (third generation; no packed copy of the operands):
+ *   Q, K, V are views into a fused [B][S][3][H][128]-float buffer (row stride ld_qkv, batch stride qkv_bs, in floats) whose
+ *   512 bytes per (token, head) hold, instead of 128 floats,
+ *     q, k: 16 groups of 8 head-dim values, each [hi x8 | lo x8] bf16 (the LDC_GEMM_A_SPLIT format), with the per-head
+ *           RMSNorm + rotary embedding already applied and q multiplied by log2(e) / sqrt(128);
+ *     v   : [hi x128 | lo x128] bf16.
+ *   Producers: the QKV projection itself (ldc_gemm_grouped_bf16x3_qkv below: GEMM epilogue) or, from an fp32 buffer in place,
+ *   ldc_attn_qkv_prepare_split (same segment / weight / table arguments as ldc_attn_pack_bf16x3).
+ *   ldc_attn_fwd_split: O = softmax(q.k^T) v per (batch, head); `flags` as ldc_attn_fwd_packed_bf16x3's `out_split`.
+ * Replaces attn.norm_q/norm_k/norm_added_q/norm_added_k + apply_rotary_emb + F.scaled_dot_product_attention,
+ * models/LaDCast_3D_model.py:103-169,183-203. */
+/* The QKV projection with those operand rows as its OUTPUT: ldc_gemm_grouped_bf16x3 (pre-split activations, K % 32 == 0) whose
+ * epilogue, for every problem i with epi[i].heads > 0 (N = 3 * heads * 128, C = the fused buffer, no act / gate / residual), adds
+ * the bias, applies RMSNorm(128, eps) * wq | wk and the rotary embedding (table row = rope_row0 + m; NULL = none) to the q and k
+ * heads, multiplies q by qscale (0 = log2(e) / sqrt(128)) and writes the split rows - to_q/to_k/to_v (+ add_*_proj), norm_q/k,
+ * apply_rotary_emb of models/LaDCast_3D_model.py:92-169,175-190 in one launch.  Problems with heads == 0 get the ordinary epilogue.
+ * LDC_ERR_UNSUPPORTED: shape not served by that kernel - run the plain GEMM, then ldc_attn_qkv_prepare_split. */
+typedef struct ldc_qkv_epilogue {
+  const float* wq;  /* [128] */
+  const float* wk;  /* [128] */
+  const float* cos; /* [rows][128] */
+  const float* sin;
+  float eps, qscale;
+  int heads, rope_row0;
+} ldc_qkv_epilogue;
+int ldc_sizeof_qkv_epilogue(void);
+int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
+                                long long workspace_bytes, void* stream);
+int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, int S, int H, int ld_qkv, long long qkv_bs, int split_row,
+                               const float* wq0, const float* wk0, const float* cos0, const float* sin0, const float* wq1,
+                               const float* wk1, const float* cos1, const float* sin1, float eps, void* stream);
+int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
+                       long long qkv_bs, int ldo, long long o_bs, int flags, void* stream);
+
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),
  * for token rows [row0, row0+rows) of every batch of a fused QKV buffer.

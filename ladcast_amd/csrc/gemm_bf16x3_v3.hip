@@ -52,6 +52,13 @@ struct DevProblem {
   long long tile0;
   int vec4;     // epilogue may use 16-byte accesses
   int c_split;  // LDC_GEMM_C_SPLIT
+  // QKV projection epilogue (ldc_gemm_grouped_bf16x3_qkv): column tile bn is one head of q (bn < heads), k or v
+  int qkv_heads;  // 0 = ordinary epilogue
+  int rope_row0;
+  const float* qk_w[2];
+  const float* rope_cos;
+  const float* rope_sin;
+  float eps, qscale;
 };
 
 struct SKArgs {
@@ -89,11 +96,98 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_w
 }
 __device__ __forceinline__ int swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
 
+__device__ __forceinline__ float xor16_add(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Epilogue of the fused QKV projection (models/LaDCast_3D_model.py:92-169,175-190): the 128-column tile is exactly one head, so the
+// tile holds whole head rows - a lane has 32 of a row's 128 values (4 per column tile), the lanes 16 / 32 / 48 further the rest.
+// bias -> RMSNorm(128, eps) * weight -> adjacent-pair rotary embedding (q and k heads; same operation order as
+// qk_rmsnorm_rope_kernel) -> q * qscale -> hi / lo split, written as the operand rows of attn_split.hip: q / k in the
+// LDC_GEMM_A_SPLIT group format, v as [hi x128 | lo x128].  This is what attn_pack_kernel did in a separate pass.
+template <int BM>
+__device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
+                                             int lane) {
+  constexpr int RT = BM / 128;
+  const int M = P.d.M;
+  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
+  const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v
+  const int nl = 4 * (lane >> 4);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
+    if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
+    float x[8][4];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const f32x4 av = acc[rt * 8 + ct];
+      x[ct][0] = av[0]; x[ct][1] = av[1]; x[ct][2] = av[2]; x[ct][3] = av[3];
+      if (P.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(P.bias + bn * BN + 16 * ct + nl);
+        x[ct][0] += bv.x; x[ct][1] += bv.y; x[ct][2] += bv.z; x[ct][3] += bv.w;
+      }
+    }
+    unsigned char* row = reinterpret_cast<unsigned char*>(C + static_cast<long long>(m) * P.d.ldc + bn * BN);
+    if (which < 2) {
+      const float* __restrict__ w = P.qk_w[which];
+      if (w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) ss += x[ct][0] * x[ct][0] + x[ct][1] * x[ct][1] + x[ct][2] * x[ct][2] + x[ct][3] * x[ct][3];
+        ss = xor32_add(xor16_add(ss));
+        const float r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + nl);
+          x[ct][0] = x[ct][0] * r * wv.x; x[ct][1] = x[ct][1] * r * wv.y; x[ct][2] = x[ct][2] * r * wv.z; x[ct][3] = x[ct][3] * r * wv.w;
+        }
+      }
+      if (P.rope_cos) {
+        const long long trow = static_cast<long long>(P.rope_row0 + m) * 128 + nl;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + trow + 16 * ct);
+          const float4 s = *reinterpret_cast<const float4*>(P.rope_sin + trow + 16 * ct);
+          const float o0 = x[ct][0] * c.x + (-x[ct][1]) * s.x, o1 = x[ct][1] * c.y + x[ct][0] * s.y;
+          const float o2 = x[ct][2] * c.z + (-x[ct][3]) * s.z, o3 = x[ct][3] * c.w + x[ct][2] * s.w;
+          x[ct][0] = o0; x[ct][1] = o1; x[ct][2] = o2; x[ct][3] = o3;
+        }
+      }
+      if (which == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) { x[ct][0] *= P.qscale; x[ct][1] *= P.qscale; x[ct][2] *= P.qscale; x[ct][3] *= P.qscale; }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const int n = 16 * ct + nl;
+      float r0, r1, r2, r3;
+      const unsigned hx = ldc_split_pair(x[ct][0], x[ct][1], r0, r1), hy = ldc_split_pair(x[ct][2], x[ct][3], r2, r3);
+      const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
+      // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
+      const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+      unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
+                                     : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
+      *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    }
+  }
+}
+
 // acc[rt * 8 + ct]: rows 16 (RT wave + rt) + lane % 16, columns 16 ct + 4 (lane / 16) + (0..3)
 template <int BM>
 __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                               int lane) {
   constexpr int RT = BM / 128;
+  if (P.qkv_heads) {
+    qkv_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+    return;
+  }
   const int M = P.d.M, N = P.d.N;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -521,7 +615,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 }
 
 template <int BM, int TERMS>
-int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace, long long workspace_bytes,
+              void* stream) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
   constexpr int CUS = 256;  // one workgroup per CU
@@ -560,6 +655,22 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
       if (P.c_split && !(v4 && d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_bs % 8 == 0 &&
                          (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
         return LDC_ERR_ALIGN;
+    }
+    if (epi != nullptr && epi[i].heads > 0) {
+      const ldc_qkv_epilogue& e = epi[i];
+      auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
+      if (d.N != 3 * e.heads * BN || d.act != LDC_ACT_NONE || q.gate != nullptr || q.R != nullptr) return LDC_ERR_ARG;
+      if ((e.wq == nullptr) != (e.wk == nullptr) || (e.cos == nullptr) != (e.sin == nullptr) || e.rope_row0 < 0) return LDC_ERR_ARG;
+      if ((d.ldc & 7) || (d.c_bs & 7) || (reinterpret_cast<unsigned long long>(q.C) & 31ull)) return LDC_ERR_ALIGN;
+      if (!al16(e.wq) || !al16(e.wk) || !al16(e.cos) || !al16(e.sin) || (q.bias && !al16(q.bias))) return LDC_ERR_ALIGN;
+      P.qkv_heads = e.heads;
+      P.rope_row0 = e.rope_row0;
+      P.qk_w[0] = e.wq;
+      P.qk_w[1] = e.wk;
+      P.rope_cos = e.cos;
+      P.rope_sin = e.sin;
+      P.eps = e.eps;
+      P.qscale = e.qscale != 0.f ? e.qscale : 0.08838834764831845f * 1.4426950408889634f;
     }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
@@ -663,8 +774,8 @@ int launch_v3(const ldc_gemm_problem* problems, int n, void* workspace, long lon
 }  // namespace
 
 // returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back to gemm_bf16x3_dma.hip)
-int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
-                               void* stream) {
+static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
+                            long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(problems);
   if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
   long long tiles256 = 0;
@@ -682,8 +793,21 @@ int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* wo
   static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
   if (force_bm) small = (atoi(force_bm) == 128);
   if (problems[0].d.flags & LDC_GEMM_BF16_1TERM)
-    return small ? launch_v3<128, 1>(problems, n, workspace, workspace_bytes, stream)
-                 : launch_v3<256, 1>(problems, n, workspace, workspace_bytes, stream);
-  return small ? launch_v3<128, 3>(problems, n, workspace, workspace_bytes, stream)
-               : launch_v3<256, 3>(problems, n, workspace, workspace_bytes, stream);
+    return small ? launch_v3<128, 1>(problems, epi, n, workspace, workspace_bytes, stream)
+                 : launch_v3<256, 1>(problems, epi, n, workspace, workspace_bytes, stream);
+  return small ? launch_v3<128, 3>(problems, epi, n, workspace, workspace_bytes, stream)
+               : launch_v3<256, 3>(problems, epi, n, workspace, workspace_bytes, stream);
+}
+
+int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                               void* stream) {
+  return gemm_v3_dispatch(problems, nullptr, n, workspace, workspace_bytes, stream);
+}
+
+// QKV projection with the attention operand rows as output (include/ladcast_hip.h); only this kernel has that epilogue:
+// LDC_ERR_UNSUPPORTED (K % 32 != 0, fp32 activations) means "run the plain GEMM and ldc_attn_qkv_prepare_split instead"
+extern "C" int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
+                                           long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(epi);
+  return gemm_v3_dispatch(problems, epi, n, workspace, workspace_bytes, stream);
 }

@@ -39,6 +39,11 @@ class GemmProblem(Structure):
 MAX_GROUPED = 4
 
 
+class QkvEpilogue(Structure):  # ldc_qkv_epilogue
+    _fields_ = [("wq", c_void_p), ("wk", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("eps", c_float), ("qscale", c_float),
+                ("heads", c_int), ("rope_row0", c_int)]
+
+
 class LinearSmallProblem(Structure):  # ldc_linear_small_problem
     _fields_ = [("x", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("add", c_void_p), ("y", c_void_p), ("x_rows", c_int), ("add_rows", c_int),
                 ("rows", c_int), ("N", c_int), ("K", c_int), ("act_in", c_int), ("act_out", c_int), ("reserved", c_int)]
@@ -62,6 +67,10 @@ def _load():
         "ldc_gemm_grouped_workspace_init": (I, [P, L, P]),
         "ldc_gemm_grouped": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_gemm_grouped_bf16x3": (I, [POINTER(GemmProblem), I, P, L, P]),
+        "ldc_sizeof_qkv_epilogue": (I, []),
+        "ldc_gemm_grouped_bf16x3_qkv": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
+        "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
+        "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_linear_small_grouped": (I, [POINTER(LinearSmallProblem), I, P]),
@@ -111,6 +120,8 @@ def _load():
         raise RuntimeError("libladcast_hip.so ABI version mismatch")
     if lib.ldc_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc) or lib.ldc_sizeof_gemm_problem() != ctypes.sizeof(GemmProblem):
         raise RuntimeError("ldc_gemm_desc / ldc_gemm_problem layout mismatch between header and binding")
+    if lib.ldc_sizeof_qkv_epilogue() != ctypes.sizeof(QkvEpilogue):
+        raise RuntimeError("ldc_qkv_epilogue layout mismatch between header and binding")
     return lib, sig
 
 
@@ -259,6 +270,39 @@ def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None
         raise ValueError("packed buffer smaller than ldc_attn_packed_bytes")
     _check(lib.ldc_attn_pack_bf16x3(_p(Q), _p(K), _p(V), B, S, H, ld_qkv, qkv_bs, split_row, *[_p(t) for t in seg0],
                                     *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
+
+
+def qkv_epilogue(wq=None, wk=None, cos=None, sin=None, *, eps=1e-7, heads, rope_row0=0, qscale=0.0):
+    """epilogue of one QKV-projection problem of `gemm_grouped_qkv` (ldc_qkv_epilogue); returns (struct, keep-alive tuple)"""
+    _dev(wq, wk, cos, sin)
+    pv = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    return QkvEpilogue(pv(wq), pv(wk), pv(cos), pv(sin), eps, qscale, heads, rope_row0), (wq, wk, cos, sin)
+
+
+def gemm_grouped_qkv(problems, epilogues):
+    """`gemm_grouped(split_bf16=True)` where problem i with a non-None epilogue is a fused QKV projection whose C receives the
+    attention operand rows of `attn_fwd_split` (bias -> per-head RMSNorm -> rotary embedding -> q scale -> hi / lo split)"""
+    n = len(problems)
+    if not 1 <= n <= MAX_GROUPED or len(epilogues) != n:
+        raise ValueError(f"gemm_grouped_qkv takes 1..{MAX_GROUPED} problems and one epilogue (or None) per problem")
+    arr = (GemmProblem * n)(*[p[0] for p in problems])
+    epi = (QkvEpilogue * n)(*[(e[0] if e is not None else QkvEpilogue()) for e in epilogues])
+    ws = _grouped_workspace(problems[0][1][2].device)
+    _check(lib.ldc_gemm_grouped_bf16x3_qkv(arr, epi, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped_bf16x3_qkv")
+
+
+def attn_qkv_prepare_split(Q, K, V, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None, None, None, None), seg1=(None, None, None, None), eps=1e-7):
+    """fp32 q / k / v views of a fused buffer -> the operand rows of `attn_fwd_split`, in place (segN = (wq, wk, cos, sin))"""
+    _dev(Q, K, V, *seg0, *seg1)
+    _check(lib.ldc_attn_qkv_prepare_split(_p(Q), _p(K), _p(V), B, S, H, ld_qkv, qkv_bs, split_row, _p(seg0[0]), _p(seg0[1]), _p(seg0[2]), _p(seg0[3]),
+                                          _p(seg1[0]), _p(seg1[1]), _p(seg1[2]), _p(seg1[3]), eps, _stream()), "ldc_attn_qkv_prepare_split")
+
+
+def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=False, one_term=False):
+    """attention on row-major split-bf16 operand rows (ldc_attn_fwd_split)"""
+    _dev(Q, K, V, O)
+    flags = (ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
+    _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, flags, _stream()), "ldc_attn_fwd_split")
 
 
 def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False, one_term=False):

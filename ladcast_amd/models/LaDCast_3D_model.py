@@ -165,7 +165,6 @@ class _Workspace:
     def __init__(self, dev, B, Bt, Nx, Nc, D, C_in, C_out, n_mod):
         f = dict(device=dev, dtype=torch.float32)
         self.mods = torch.empty(B, n_mod, **f)  # every temb-driven AdaLN modulation vector of one forward
-        self.apack = None  # split-bf16 attention operands (ldc_attn_packed_bytes), allocated on first use
         S = Nx + Nc
         self.h = torch.empty(B, S, D, **f)
         self.nh = torch.empty(B, S, D, **f)
@@ -402,7 +401,9 @@ class LaDCastTransformer3DModel(ModelMixin):
             lon = torch.linspace(self.rope_spatial_grid_start_pos[1], self.rope_spatial_grid_end_pos[1], steps=w, dtype=torch.float32)
             pc, ps = rope_tables_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
             cc, cs = rope_tables_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
-            self._rope[key] = tuple(t.to(dev) for t in (pc, ps, cc, cs))
+            pc, ps, cc, cs = (t.to(dev) for t in (pc, ps, cc, cs))
+            # joint [S][128] tables of the single-stream blocks (pred rows, then cond rows): one table for a fused QKV epilogue
+            self._rope[key] = (pc, ps, cc, cs, torch.cat([pc, cc], dim=0).contiguous(), torch.cat([ps, cs], dim=0).contiguous())
         return self._rope[key]
 
     def _time_elapsed_embedding(self, time_elapsed, dev):
@@ -452,10 +453,10 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt)
 
     def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False):
-        """q/k RMSNorm + RoPE per segment, then attention over token rows [row0, row0 + Sx + Sc) of the fused qkv
-        buffer -> out.  seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the next Sc rows seg_c.
-        fp32 mode: ldc_qk_rmsnorm_rope in place + ldc_attn_fwd; split-bf16 mode: ldc_attn_pack_bf16x3 (norm, RoPE
-        and the hi/lo split in one pass, qkv left untouched) + ldc_attn_fwd_packed_bf16x3."""
+        """Attention over token rows [row0, row0 + Sx + Sc) of the fused qkv buffer -> out.
+        fp32 mode: q/k RMSNorm + RoPE per segment in place (seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the
+        next Sc rows seg_c; ldc_qk_rmsnorm_rope) + ldc_attn_fwd.  Split-bf16 / bf16 modes: the QKV projection's epilogue has already
+        written the normed, rotated, scaled and split operand rows (`_qkv_epi`), so this is ldc_attn_fwd_split alone."""
         D, H = self.inner_dim, self.config.num_attention_heads
         qkv = ws.qkv
         full = qkv.shape[1]
@@ -463,24 +464,23 @@ class LaDCastTransformer3DModel(ModelMixin):
         q = qkv[:, row0:, 0:D]
         k = qkv[:, row0:, D : 2 * D]
         v = qkv[:, row0:, 2 * D : 3 * D]
-        segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
         if self.gemm_precision in ("bf16x3", "bf16"):
-            if ws.apack is None:
-                ws.apack = torch.empty(hip.attn_packed_bytes(B, full, H) // 4, device=qkv.device, dtype=torch.float32)
-            if any(sg_[1][0].eps != segs[0][1][0].eps or sg_[1][1].eps != segs[0][1][0].eps for sg_ in segs):
-                raise NotImplementedError("ldc_attn_pack_bf16x3 takes one RMSNorm eps for q and k of both segments")
-            sg = [(n.weight, m.weight, c, s_) for (_, (n, m, c, s_)) in segs]
-            sg.append((None, None, None, None))
-            hip.attn_pack(q, k, v, ws.apack, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, split_row=segs[0][0],
-                          seg0=sg[0], seg1=sg[1], eps=segs[0][1][0].eps)
-            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs, out_split=out_split, one_term=self.gemm_precision == "bf16")
+            hip.attn_fwd_split(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, out_split=out_split,
+                               one_term=self.gemm_precision == "bf16")
             return
+        segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
         r0 = row0
         for rows, (nq, nk, c, s_) in segs:
             hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
                                 wq=nq.weight, wk=nk.weight, eps=nq.eps, cos=c, sin=s_)
             r0 += rows
         hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, split_bf16=False)
+
+    def _qkv_epi(self, norm_q, norm_k, cos, sin):
+        """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + rotary tables (None = no RoPE)"""
+        if norm_q.eps != norm_k.eps:
+            raise NotImplementedError("the fused QKV epilogue takes one RMSNorm eps for q and k")
+        return hip.qkv_epilogue(norm_q.weight, norm_k.weight, cos, sin, eps=norm_q.eps, heads=self.config.num_attention_heads)
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -601,7 +601,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         if key not in self._ws:
             self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(plan.kx_pad, plan.kc_pad), C_out, plan.mod_w.shape[0])
         ws = self._ws[key]
-        pc, ps, cc, cs = self._rope_tables(R, T_in, Hh, Ww, dev)
+        pc, ps, cc, cs, jc, js = self._rope_tables(R, T_in, Hh, Ww, dev)
         SD = S * D
         h_x, h_c = ws.h[:, :Nx], ws.h[:, Nx:]
         nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
@@ -624,6 +624,13 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         def run1(A, W, C, **kw):
             hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
+
+        def run_qkv(problems, epis):
+            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
+            if split:
+                hip.gemm_grouped_qkv(problems, epis)
+            else:
+                hip.gemm_grouped(problems, split_bf16=False)
 
         if split:
             KX, KC = plan.kx_pad, plan.kc_pad
@@ -657,7 +664,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)
-            run1(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)
+            run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
+                    [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, cc, cs)])
             self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             hip.gate_residual(h_c, ws.att[:, Nx:], ws.mod_a, h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D)
@@ -687,10 +695,10 @@ class LaDCastTransformer3DModel(ModelMixin):
             # norm1 + norm1_context: the two streams are adjacent rows of ws.h -> one launch, two modulation sets
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, split_row=Nx, scale2=mc[:, D:], shift2=mc,
                               mod_bs=NM, mode=0, eps=1e-6, out_split=split)
-            run([
+            run_qkv([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
-            ])
+            ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pc, ps), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)])
             self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
                             (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
@@ -718,11 +726,11 @@ class LaDCastTransformer3DModel(ModelMixin):
             F = blk.proj_mlp.weight.shape[0]
             W5 = D + F
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
-            run([
+            run_qkv([
                 G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
                   flags=AS | CS),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
-            ])
+            ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jc, js)])
             self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
                             (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,

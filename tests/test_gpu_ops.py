@@ -672,3 +672,144 @@ def test_attention_packed_bf16_single_term(hip, B, S, H):
     out3 = torch.empty_like(out)
     hip.attn_fwd_packed(pk, out3, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64))
     assert rel(out3[:, :, :D], want) < 2e-5  # the same images still serve the split mode
+
+
+# -- third-generation attention: row-major split-bf16 operand rows (attn_split.hip) + the fused QKV-projection epilogue ----------------
+def _prep(hip, d_qkv, B, S, H, D, **kw):
+    hip.attn_qkv_prepare_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=d_qkv.shape[1] * 3 * D, **kw)
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 2250, 16), (1, 97, 2),
+                                   (1, 32, 1), (1, 64, 2), (1, 4500, 12)])
+@pytest.mark.parametrize("one_term", [False, True])
+def test_attention_split(hip, B, S, H, one_term):
+    """prepare (no norm / RoPE: scale + split, in place) + attention on the row-major split rows == sdpa on the raw operands; both key-range
+    layouts (one / two wave groups), ragged last tile, single-term mode at its stated tolerance"""
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 4.0
+    d_qkv = dev(qkv)
+    _prep(hip, d_qkv, B, S, H, D, split_row=S)
+    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D + 64,
+                       o_bs=S * (D + 64), one_term=one_term)
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(out[:, :, :D]).all()
+    assert rel(out[:, :, :D], want) < (1e-2 if one_term else 2e-5)
+    assert torch.isnan(out[:, :, D:]).all()
+    # the prepared rows: q / k groups of [hi x8 | lo x8], v as [hi x128 | lo x128]; hi + lo reproduces the operand to 2^-17
+    got = d_qkv.cpu()
+    scale = 0.08838834764831845 * 1.4426950408889634
+    hi, lo = _unsplit(got[..., : 2 * D].reshape(B * S, 2 * D), B * S, 2 * D)
+    assert rel((hi + lo)[:, :D] / scale, qkv[..., :D].reshape(B * S, D)) < 1e-5 and rel((hi + lo)[:, D:], qkv[..., D : 2 * D].reshape(B * S, D)) < 1e-5
+    vw = got[..., 2 * D :].contiguous().view(torch.int16).reshape(B, S, H, 2, 128)
+    vf = (vw.to(torch.int32) << 16).view(torch.float32)
+    assert rel((vf[:, :, :, 0] + vf[:, :, :, 1]).reshape(B, S, D), qkv[..., 2 * D :]) < 1e-5
+
+
+@pytest.mark.parametrize("Nx,Nc,rope1", [(37, 11, False), (1800, 450, True), (64, 0, False), (40, 57, True)])
+def test_attention_split_norm_rope_two_segments(hip, Nx, Nc, rope1):
+    """the stand-alone producer's q/k RMSNorm + RoPE per row segment, against the oracle layers + sdpa (reference
+    models/LaDCast_3D_model.py:103-203); 5 extra token rows in the buffer: batch stride != S * ld"""
+    B, H = 2 if Nx < 100 else 1, 3
+    D, S = H * 128, Nx + Nc
+    qkv = rnd(B, S + 5, 3 * D, seed=1)
+    wq0, wk0, wq1, wk1 = [1 + 0.1 * rnd(128, seed=s_) for s_ in (2, 3, 4, 5)]
+    cos0, sin0 = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
+    cos1, sin1 = L.get_1d_rotary_pos_embed(128, torch.arange(max(Nc, 1)).float() * 0.11 - 3.0, 256.0)
+    d = dev(qkv)
+    out = torch.empty(B, S, D, device="cuda")
+    seg1 = (dev(wq1), dev(wk1), dev(cos1) if rope1 else None, dev(sin1) if rope1 else None)
+    hip.attn_qkv_prepare_split(d[:, :, :D], d[:, :, D : 2 * D], d[:, :, 2 * D :], B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=(S + 5) * 3 * D, split_row=Nx,
+                               seg0=(dev(wq0), dev(wk0), dev(cos0), dev(sin0)), seg1=seg1, eps=1e-7)
+    hip.attn_fwd_split(d[:, :, :D], d[:, :, D : 2 * D], d[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=(S + 5) * 3 * D, ldo=D, o_bs=S * D)
+    assert torch.equal(d[:, S:].cpu(), qkv[:, S:])  # rows past S untouched
+    want = _norm_rope_sdpa(qkv[:, :S], B, S, H, Nx, Nc, (wq0, wk0, wq1, wk1), (cos0, sin0), (cos1, sin1) if rope1 else None)
+    assert rel(out, want) < 2e-5
+
+
+def _norm_rope_sdpa(x, B, S, H, Nx, Nc, ws_, rope0, rope1):
+    D = H * 128
+    norms = []
+    for w in ws_:
+        n = L.RMSNorm(128, 1e-7)
+        n.weight.data = w
+        norms.append(n)
+    with torch.no_grad():
+        x = x.double()
+        qk = []
+        for j in range(2):
+            t = x[:, :, j * D : (j + 1) * D].reshape(B, S, H, 128).transpose(1, 2).float()
+            a = L.apply_rotary_emb(norms[j](t[:, :, :Nx]), rope0)
+            b = norms[2 + j](t[:, :, Nx:])
+            if rope1 is not None and Nc:
+                b = L.apply_rotary_emb(b, rope1)
+            qk.append(torch.cat([a, b], dim=2).double())
+        v = x[:, :, 2 * D :].reshape(B, S, H, 128).transpose(1, 2)
+        return F.scaled_dot_product_attention(qk[0], qk[1], v).transpose(1, 2).reshape(B, S, D)
+
+
+def test_attention_split_rescale_branch_and_split_output(hip):
+    """a key that makes one query's running max jump far past the lazy-max threshold in a late tile (rule 26: force the rare branch), and
+    the LDC_ATTN_OUT_SPLIT output = the hi / lo split of exactly the fp32 output"""
+    S = 200
+    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
+    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0
+    d_qkv = dev(qkv)
+    _prep(hip, d_qkv, 1, S, 1, 128, split_row=S)
+    out = torch.empty(1, S, 128, device="cuda")
+    kw = dict(B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, ldo=128, o_bs=S * 128)
+    hip.attn_fwd_split(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], out, **kw)
+    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
+    assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
+    out2 = torch.empty(1, S, 128, device="cuda")
+    hip.attn_fwd_split(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], out2, out_split=True, **kw)
+    hi, lo = _unsplit(out2.reshape(S, 128), S, 128)
+    want_hi = out.cpu().reshape(S, 128).bfloat16().float()
+    assert torch.equal(hi, want_hi) and torch.equal(lo, (out.cpu().reshape(S, 128) - want_hi).bfloat16().float())
+
+
+@pytest.mark.parametrize("Nx,Nc,H,batch", [(1800, 450, 12, 1), (37, 11, 2, 2), (450, 0, 12, 1), (4500, 0, 3, 1)])
+def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
+    """ldc_gemm_grouped_bf16x3_qkv: the QKV projection (two grouped problems: a RoPE'd stream and a plain one, plus - as in the single
+    blocks - an ordinary GELU problem in the same launch) writes the attention operand rows itself; attention on them == oracle layers
+    (RMSNorm, RoPE) + sdpa on the fp64 projection.  Both tile heights, split tiles (stream-K reduction) included."""
+    D, K = H * 128, 256
+    S = Nx + Nc
+    A = rnd(batch, S, K, seed=1)
+    Wx, Wc = rnd(3 * D, K, seed=2) / math.sqrt(K), rnd(3 * D, K, seed=3) / math.sqrt(K)
+    bx, bc = rnd(3 * D, seed=4) * 0.1, rnd(3 * D, seed=5) * 0.1
+    Wm, bm = rnd(512, K, seed=6) / math.sqrt(K), rnd(512, seed=7)
+    wq0, wk0, wq1, wk1 = [1 + 0.1 * rnd(128, seed=s_) for s_ in (12, 13, 14, 15)]
+    cos0, sin0 = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
+    Ap = hip.pack_weight_bf16x2(dev(A).reshape(batch * S, K)).view(batch, S, K)
+    qkv = torch.full((batch, S, 3 * D), float("nan"), device="cuda")
+    mlp = torch.empty(batch, S, 512, device="cuda")
+    f = hip.GEMM_A_SPLIT
+    probs = [hip.gemm_problem(Ap, hip.pack_weight_bf16x2(dev(Wx)), qkv, M=Nx, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D, bias=dev(bx), flags=f)]
+    epis = [hip.qkv_epilogue(dev(wq0), dev(wk0), dev(cos0), dev(sin0), eps=1e-7, heads=H)]
+    if Nc:
+        probs.append(hip.gemm_problem(Ap[:, Nx:], hip.pack_weight_bf16x2(dev(Wc)), qkv[:, Nx:], M=Nc, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D,
+                                      bias=dev(bc), flags=f))
+        epis.append(hip.qkv_epilogue(dev(wq1), dev(wk1), None, None, eps=1e-7, heads=H))
+    probs.append(hip.gemm_problem(Ap, hip.pack_weight_bf16x2(dev(Wm)), mlp, M=S, N=512, K=K, batch=batch, a_bs=S * K, c_bs=S * 512, bias=dev(bm), act=2, flags=f))
+    epis.append(None)
+    hip.gemm_grouped_qkv(probs, epis)
+    out = torch.empty(batch, S, D, device="cuda")
+    hip.attn_fwd_split(qkv[:, :, :D], qkv[:, :, D : 2 * D], qkv[:, :, 2 * D :], out, B=batch, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D)
+    proj = torch.cat([A[:, :Nx].double() @ Wx.double().T + bx.double(), A[:, Nx:].double() @ Wc.double().T + bc.double()], dim=1)
+    want = _norm_rope_sdpa(proj, batch, S, H, Nx, Nc, (wq0, wk0, wq1, wk1), (cos0, sin0), None)
+    assert rel(out, want) < 2e-5
+    assert rel(mlp, F.gelu(A.double() @ Wm.double().T + bm.double(), approximate="tanh")) < 1e-5  # the ordinary problem of the same launch
+    # against the stand-alone producer on the fp32 projection: the same rows up to the projection's rounding
+    qkv2 = proj.float().cuda().contiguous()
+    seg1 = (dev(wq1), dev(wk1), None, None)
+    hip.attn_qkv_prepare_split(qkv2[:, :, :D], qkv2[:, :, D : 2 * D], qkv2[:, :, 2 * D :], B=batch, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, split_row=Nx,
+                               seg0=(dev(wq0), dev(wk0), dev(cos0), dev(sin0)), seg1=seg1, eps=1e-7)
+    h1, l1 = _unsplit(qkv[..., : 2 * D].reshape(batch * S, 2 * D), batch * S, 2 * D)
+    h2, l2 = _unsplit(qkv2[..., : 2 * D].reshape(batch * S, 2 * D), batch * S, 2 * D)
+    assert rel(h1 + l1, h2 + l2) < 1e-5
+    with pytest.raises(RuntimeError):  # N must be 3 * heads * 128
+        hip.gemm_grouped_qkv(probs[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, None, heads=H + 1)])
