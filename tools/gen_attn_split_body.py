@@ -86,7 +86,7 @@ def generate(terms):
         for i in range(4):  # pair i of the fragment: keys (kt = i >> 1, r = 2 (i & 1), +1)
             kt, r = i >> 1, 2 * (i & 1)
             piecesA.append(f"LDC_SPLIT_PAIR(ph[{qt}], pl[{qt}], {i}, ec[{kt}][{qt}][{r}], ec[{kt}][{qt}][{r + 1}])")
-    dma = [f"if (kq) dma_k({j});" for j in range(4)] + [f"if (vq) dma_v({j});" for j in range(4)]
+    dma = [f"dma_k({j});" for j in range(4)] + [f"dma_v({j});" for j in range(4)]  # unconditional: no branch in the MFMA stream (tile index clamped)
     # phase B: running max (lazy) and exponentials of S_next -> the next iteration's ec / alpha
     piecesB = []
     piecesB.append("if (mask_next) { LDC_MASK_TAIL(sn) }")
@@ -98,8 +98,9 @@ def generate(terms):
         piecesB.append(f"mx[{qt}] = xor32_max(mx[{qt}]); asm volatile(\"\" : \"+v\"(mx[{qt}]));")
     for qt in range(2):
         # lazy running max (scores are in log2 units): it only moves when exceeded by more than 2^8, so the rescale of O is rare;
-        # the last iteration's S_next is computed from a stale stage and must not move it (live_next)
-        piecesB.append(f"m_new[{qt}] = (live_next && mx[{qt}] - m_run[{qt}] > 8.0f) ? mx[{qt}] : m_run[{qt}]; "
+        # the last iteration's S_next is computed from a stale stage and must not move it (lazy_thr = huge there); one compare + one
+        # select per query, no control flow inside the MFMA stream
+        piecesB.append(f"m_new[{qt}] = (mx[{qt}] - m_run[{qt}] > lazy_thr) ? mx[{qt}] : m_run[{qt}]; "
                        f"alpha_n[{qt}] = __builtin_amdgcn_exp2f(m_run[{qt}] - m_new[{qt}]); m_run[{qt}] = m_new[{qt}]; "
                        f"asm volatile(\"\" : \"+v\"(m_new[{qt}]), \"+v\"(alpha_n[{qt}]));")
     for kt in range(2):
