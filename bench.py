@@ -157,8 +157,7 @@ class KernelTimer:
             s.record()
             timer._orig["attn_fwd"](Q, K, V, O, **kw)
             e.record()
-            name = "attn_fwd_bf16x3_kernel" if kw.get("split_bf16") else "attn_fwd_f32_kernel"
-            timer.records.setdefault(name, []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
+            timer.records.setdefault("attn_fwd_f32_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
         def attn_fwd_packed(packed, O, **kw):  # the attention itself; the pack pass (norm + RoPE + split) is not MFMA work
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -519,8 +518,7 @@ def main():
             "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
             "roofline": roof,
         }
-        for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS), ("attn_fwd_bf16x3_kernel", PEAK_BF16_MFMA_TFLOPS),
-                          ("attn_fwd_packed_kernel", PEAK_BF16_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):
+        for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS),                           ("attn_fwd_packed_kernel", PEAK_BF16_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):
             if an in ks:
                 k = ks[an]
                 line["attention_kernel"] = dict(kernel=an, achieved=round(k["tflops"], 2), peak=apeak, unit="TFLOP/s", frac=round(k["tflops"] / apeak, 4),

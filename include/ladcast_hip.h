@@ -34,6 +34,11 @@ extern "C" {
 #define LDC_ERR_UNSUPPORTED (-3)
 
 enum ldc_act { LDC_ACT_NONE = 0, LDC_ACT_SILU = 1, LDC_ACT_GELU_TANH = 2, LDC_ACT_RELU = 3 };
+/* `act_in` of ldc_linear_small / _grouped / _mod only: x holds ONE timestep per row (x_rows floats, any alignment) and the input
+ * row is its 256-wide sinusoidal embedding [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(1e4) k / 128) (K must be 256): diffusers
+ * Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) fused into the TimestepEmbedding's first Linear
+ * (models/LaDCast_3D_model.py:362-364,673); same values as ldc_timestep_embedding. */
+#define LDC_ACT_IN_TIMESTEP_SINCOS 16
 
 int ldc_abi_version(void);
 /* name of the code-object architecture the library was built for ("gfx950") */
@@ -123,6 +128,13 @@ int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bi
                      const float* add, int add_rows, float* y, int rows, int N, int K,
                      int act_in, int act_out, void* stream);
 
+/* ldc_linear_small followed by y = y * (1 + mod[r % mod_rows][n]) + mod[r % mod_rows][N + n] (mod: [mod_rows][2 N]): the
+ * time-elapsed modulation of the conditioning embedding, temb * (1 + scale) + shift (models/LaDCast_3D_model.py:958-969), as the
+ * epilogue of the text embedder's second Linear; bit-identical to ldc_linear_small + ldc_temb_modulate. */
+int ldc_linear_small_mod(const float* x, int x_rows, const float* W, const float* bias, const float* add, int add_rows,
+                         const float* mod, int mod_rows, float* y, int rows, int N, int K, int act_in, int act_out,
+                         void* stream);
+
 /* Up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears (same formula, same per-output arithmetic as
  * ldc_linear_small: results are bit-identical) in ONE launch: the two MLPs of
  * CombinedTimestepTextProjEmbeddings (timestep_embedder / text_embedder, used twice per forward:
@@ -149,11 +161,6 @@ int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, vo
  * ------------------------------------------------------------------------- */
 int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
                  int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
-
-/* Same contract on the bf16 matrix cores with split-bf16 operands (Q.K^T and P.V each evaluated as
- * hi*hi + hi*lo + lo*hi with fp32 accumulation; error ~1e-6 rel-L2 vs ldc_attn_fwd). */
-int ldc_attn_fwd_bf16x3(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
-                        int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
 
 /* Split-bf16 attention in two steps, for callers that also need the q/k RMSNorm + rotary embedding:
  *   ldc_attn_pack_bf16x3     reads Q, K, V (same views as ldc_attn_fwd), applies to q and k the per-head
@@ -255,6 +262,12 @@ int ldc_mean_rows_split(const float* x, float* y, float* x_split, int B, int row
 int ldc_gate_residual(const float* resid, const float* y, const float* gate, float* out, int B,
                       int rows, int D, int ld_res, long long res_bs, int ld_y, long long y_bs,
                       int gate_bs, void* stream);
+/* ldc_gate_residual in place (resid += gate * y) followed by out = LayerNorm(resid; eps) * weight + bias (out_split: written in
+ * the LDC_GEMM_A_SPLIT format) in ONE launch: the refiner block's gated attention residual + norm2
+ * (models/LaDCast_3D_model.py:296-300); bit-identical to ldc_gate_residual + ldc_layernorm_mod(mode 1). */
+int ldc_gate_residual_layernorm(float* resid, const float* y, const float* gate, float* out, int B, int rows, int D, int ld_res,
+                                long long res_bs, int ld_y, long long y_bs, int gate_bs, int ld_out, long long out_bs,
+                                const float* weight, const float* bias, float eps, int out_split, void* stream);
 
 /* Layout changes between the reference's channel-major latents (B, C, T*H*W) and
  * token-major (B, T*H*W, ld) (models/embeddings.py:56-59 flatten/transpose and

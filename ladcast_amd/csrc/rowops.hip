@@ -12,13 +12,17 @@ namespace {
 // ---------------------------------------------------------------------------
 constexpr int LN_MAX_V4 = 8;  // D <= 64 lanes * 8 float4 * 4 = 2048
 
-__global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restrict__ x, float* __restrict__ y,
+// pre_y != nullptr (ldc_gate_residual_layernorm): the row is first updated in place, x += gate[b] * pre_y (the refiner's gated
+// attention residual, models/LaDCast_3D_model.py:296-299), then normalised - one launch instead of gate_residual + LayerNorm
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(float* __restrict__ x, float* __restrict__ y,
                                                             int rows, int D, int ldx, long long x_bs, int ldy,
                                                             long long y_bs, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int split_row,
                                                             const float* __restrict__ scale2,
                                                             const float* __restrict__ shift2, int mod_bs, int mode,
-                                                            float eps, int out_split) {
+                                                            float eps, int out_split, const float* __restrict__ pre_y,
+                                                            const float* __restrict__ pre_gate, int ld_prey,
+                                                            long long prey_bs, int gate_bs) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
     scale = scale2;
     shift = shift2;
   }
-  const float* xr = x + b * x_bs + static_cast<long long>(row) * ldx;
+  float* xr = x + b * x_bs + static_cast<long long>(row) * ldx;
   float* yr = y + b * y_bs + static_cast<long long>(row) * ldy;
   const int nv4 = D >> 2;
   float4 v[LN_MAX_V4];
@@ -37,6 +41,12 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
     const int c = lane + 64 * i;
     if (c < nv4) {
       v[i] = reinterpret_cast<const float4*>(xr)[c];
+      if (pre_y) {  // same arithmetic as gate_residual_kernel: one fma per element
+        const float4 yv = reinterpret_cast<const float4*>(pre_y + b * prey_bs + static_cast<long long>(row) * ld_prey)[c];
+        const float4 g = reinterpret_cast<const float4*>(pre_gate + static_cast<long long>(b) * gate_bs)[c];
+        v[i] = make_float4(fmaf(yv.x, g.x, v[i].x), fmaf(yv.y, g.y, v[i].y), fmaf(yv.z, g.z, v[i].z), fmaf(yv.w, g.w, v[i].w));
+        reinterpret_cast<float4*>(xr)[c] = v[i];
+      }
       sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     } else {
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const float* __restr
   const float4 r = reinterpret_cast<const float4*>(resid + b * res_bs + static_cast<long long>(row) * ld_res)[c];
   const float4 v = reinterpret_cast<const float4*>(y + b * y_bs + static_cast<long long>(row) * ld_y)[c];
   const float4 g = reinterpret_cast<const float4*>(gate + static_cast<long long>(b) * gate_bs)[c];
-  float4 o = make_float4(r.x + v.x * g.x, r.y + v.y * g.y, r.z + v.z * g.z, r.w + v.w * g.w);
+  float4 o = make_float4(fmaf(v.x, g.x, r.x), fmaf(v.y, g.y, r.y), fmaf(v.z, g.z, r.z), fmaf(v.w, g.w, r.w));
   reinterpret_cast<float4*>(out + b * res_bs + static_cast<long long>(row) * ld_res)[c] = o;
 }
 
@@ -235,7 +245,8 @@ template <int LS_CPW>
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const float* __restrict__ add,
                                                   int add_rows, float* __restrict__ y, int rows, int N, int K, int kc,
-                                                  int act_in, int act_out, int iters) {
+                                                  int act_in, int act_out, int iters, const float* __restrict__ mod = nullptr,
+                                                  int mod_rows = 1) {
   // iters > 1 (host: only when K <= kc, one staged chunk): the workgroup stages act_in(x) once and walks `iters`
   // consecutive column groups - fewer, longer-lived workgroups for the wide AdaLN modulation GEMV
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [rows_here][kc]
@@ -264,8 +275,24 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
         if (k0) __syncthreads();
         for (int idx = threadIdx.x; idx < rows_here * nv4; idx += 256) {
           const int i = idx / nv4, c = idx - i * nv4;
-          float4 xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
-          if (act_in != LDC_ACT_NONE) {
+          float4 xv;
+          if (act_in == LDC_ACT_IN_TIMESTEP_SINCOS) {
+            // x holds one timestep per row; the staged row is its 256-wide sinusoidal embedding (same expressions as
+            // timestep_embedding_kernel: bit-identical values), K == 256
+            const float t = x[(r_base + i) % x_rows];
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = k0 + 4 * c + j;
+              const float f = expf(-9.210340371976184f * static_cast<float>(k & 127) / 128.0f);
+              const float a = t * f;
+              e[j] = k < 128 ? cosf(a) : sinf(a);
+            }
+            xv = make_float4(e[0], e[1], e[2], e[3]);
+          } else {
+            xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
+          }
+          if (act_in != LDC_ACT_NONE && act_in != LDC_ACT_IN_TIMESTEP_SINCOS) {
             xv.x = ldc_apply_act(xv.x, act_in);
             xv.y = ldc_apply_act(xv.y, act_in);
             xv.z = ldc_apply_act(xv.z, act_in);
@@ -308,6 +335,10 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
           float v = sum + (bias ? bias[n] : 0.f);
           v = ldc_apply_act(v, act_out);
           if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
+          if (mod) {  // v * (1 + scale) + shift, scale | shift = the two halves of a [mod_rows][2 N] table; no contraction: the
+            const float* mr = mod + static_cast<long long>(r % mod_rows) * 2 * N;  // same bits as temb_modulate_kernel
+            v = __fadd_rn(__fmul_rn(v, __fadd_rn(1.f, mr[n])), mr[N + n]);
+          }
           y[static_cast<long long>(r) * N + n] = v;
         }
       }
@@ -320,8 +351,8 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ add, int add_rows,
                                                            float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
-                                                           int act_out, int iters) {
-  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters);
+                                                           int act_out, int iters, const float* __restrict__ mod, int mod_rows) {
+  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters, mod, mod_rows);
 }
 
 // up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears in one launch: blockIdx.z picks the problem
@@ -356,8 +387,34 @@ extern "C" int ldc_layernorm_mod2(const float* x, float* y, int B, int rows, int
   if (mode != 0 && mode != 1) return LDC_ERR_UNSUPPORTED;
   if (out_split && ((D & 7) || (ldy & 7) || (y_bs & 7) || (reinterpret_cast<unsigned long long>(y) & 31ull))) return LDC_ERR_ALIGN;
   dim3 grid(ldc_cdiv(rows, 4), B);
-  hipLaunchKernelGGL(layernorm_mod_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, D, ldx,
-                     x_bs, ldy, y_bs, scale, shift, split_row, scale2, shift2, mod_bs, mode, eps, out_split);
+  hipLaunchKernelGGL(layernorm_mod_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), const_cast<float*>(x), y, rows, D,
+                     ldx, x_bs, ldy, y_bs, scale, shift, split_row, scale2, shift2, mod_bs, mode, eps, out_split,
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0, 0LL, 0);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_gate_residual_layernorm(float* resid, const float* yv, const float* gate, float* out, int B, int rows, int D,
+                                           int ld_res, long long res_bs, int ld_y, long long y_bs, int gate_bs, int ld_out,
+                                           long long out_bs, const float* weight, const float* bias, float eps, int out_split,
+                                           void* stream) {
+  LDC_CHECK_PTR(resid);
+  LDC_CHECK_PTR(yv);
+  LDC_CHECK_PTR(gate);
+  LDC_CHECK_PTR(out);
+  if (B <= 0 || rows <= 0 || D <= 0) return LDC_ERR_ARG;
+  if ((D & 3) || D > 64 * 4 * LN_MAX_V4) return LDC_ERR_UNSUPPORTED;
+  if ((ld_res & 3) || (ld_y & 3) || (ld_out & 3) || (res_bs & 3) || (y_bs & 3) || (out_bs & 3) || (gate_bs & 3)) return LDC_ERR_ALIGN;
+  LDC_CHECK_ALIGN16(resid);
+  LDC_CHECK_ALIGN16(yv);
+  LDC_CHECK_ALIGN16(gate);
+  LDC_CHECK_ALIGN16(out);
+  if (weight) LDC_CHECK_ALIGN16(weight);
+  if (bias) LDC_CHECK_ALIGN16(bias);
+  if (out_split && ((D & 7) || (ld_out & 7) || (out_bs & 7) || (reinterpret_cast<unsigned long long>(out) & 31ull))) return LDC_ERR_ALIGN;
+  dim3 grid(ldc_cdiv(rows, 4), B);
+  hipLaunchKernelGGL(layernorm_mod_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), resid, out, rows, D, ld_res, res_bs,
+                     ld_out, out_bs, weight, bias, rows, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0, 1,
+                     eps, out_split, yv, gate, ld_y, y_bs, gate_bs);
   return ldc_launch_status();
 }
 
@@ -426,16 +483,21 @@ extern "C" int ldc_gate_residual(const float* resid, const float* y, const float
   return ldc_launch_status();
 }
 
-extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bias, const float* add,
-                                int add_rows, float* y, int rows, int N, int K, int act_in, int act_out,
-                                void* stream) {
+static int linear_small_impl(const float* x, int x_rows, const float* W, const float* bias, const float* add, int add_rows,
+                             const float* mod, int mod_rows, float* y, int rows, int N, int K, int act_in, int act_out,
+                             void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(W);
   LDC_CHECK_PTR(y);
   if (rows <= 0 || N <= 0 || K <= 0 || x_rows <= 0) return LDC_ERR_ARG;
   if (add && add_rows <= 0) return LDC_ERR_ARG;
+  if (mod && mod_rows <= 0) return LDC_ERR_ARG;
   if (K & 3) return LDC_ERR_ALIGN;
-  LDC_CHECK_ALIGN16(x);
+  if (act_in == LDC_ACT_IN_TIMESTEP_SINCOS) {
+    if (K != 256) return LDC_ERR_ARG;  // x: one float per row, any 4-byte alignment
+  } else {
+    LDC_CHECK_ALIGN16(x);
+  }
   LDC_CHECK_ALIGN16(W);
   const int kc = K < LS_KC ? K : LS_KC;
   const int rows_max = rows < LS_ROWS ? rows : LS_ROWS;
@@ -459,13 +521,26 @@ extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, cons
     }
     dim3 grid(ldc_cdiv(ldc_cdiv(N, 4 * LS_CPW_MAX), iters), row_groups);
     hipLaunchKernelGGL(linear_small_kernel<LS_CPW_MAX>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W,
-                       bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters);
+                       bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters, mod, mod_rows);
   } else {
     dim3 grid(ldc_cdiv(N, 4), row_groups);
     hipLaunchKernelGGL(linear_small_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add,
-                       add_rows, y, rows, N, K, kc, act_in, act_out, 1);
+                       add_rows, y, rows, N, K, kc, act_in, act_out, 1, mod, mod_rows);
   }
   return ldc_launch_status();
+}
+
+extern "C" int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bias, const float* add,
+                                int add_rows, float* y, int rows, int N, int K, int act_in, int act_out,
+                                void* stream) {
+  return linear_small_impl(x, x_rows, W, bias, add, add_rows, nullptr, 1, y, rows, N, K, act_in, act_out, stream);
+}
+
+extern "C" int ldc_linear_small_mod(const float* x, int x_rows, const float* W, const float* bias, const float* add,
+                                    int add_rows, const float* mod, int mod_rows, float* y, int rows, int N, int K, int act_in,
+                                    int act_out, void* stream) {
+  LDC_CHECK_PTR(mod);
+  return linear_small_impl(x, x_rows, W, bias, add, add_rows, mod, mod_rows, y, rows, N, K, act_in, act_out, stream);
 }
 
 extern "C" int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, void* stream) {
@@ -481,7 +556,11 @@ extern "C" int ldc_linear_small_grouped(const ldc_linear_small_problem* problems
     if (q.rows <= 0 || q.N <= 0 || q.K <= 0 || q.x_rows <= 0) return LDC_ERR_ARG;
     if (q.add && q.add_rows <= 0) return LDC_ERR_ARG;
     if (q.K & 3) return LDC_ERR_ALIGN;
-    LDC_CHECK_ALIGN16(q.x);
+    if (q.act_in == LDC_ACT_IN_TIMESTEP_SINCOS) {
+      if (q.K != 256) return LDC_ERR_ARG;
+    } else {
+      LDC_CHECK_ALIGN16(q.x);
+    }
     LDC_CHECK_ALIGN16(q.W);
     for (int j = 0; j < i; ++j)  // problems of one launch run concurrently: no output may be another's input
       if (problems[j].y == q.x || problems[j].y == q.add || q.y == problems[j].x || q.y == problems[j].add || q.y == problems[j].y)

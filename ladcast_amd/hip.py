@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip.so")
 
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
+ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per row, the input row = its sinusoidal embedding
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
 ATTN_OUT_SPLIT, ATTN_BF16_1TERM = 1, 2
 
@@ -74,8 +75,9 @@ def _load():
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_linear_small_grouped": (I, [POINTER(LinearSmallProblem), I, P]),
+        "ldc_linear_small_mod": (I, [P, I, P, P, P, I, P, I, P, I, I, I, I, I, P]),
+        "ldc_gate_residual_layernorm": (I, [P, P, P, P, I, I, I, I, L, I, L, I, I, L, P, P, F, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
-        "ldc_attn_fwd_bf16x3": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
@@ -207,10 +209,22 @@ def pack_weight_bf16x2(W):
     return out
 
 
-def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE):
-    _dev(x, W, y, bias, add)
-    _check(lib.ldc_linear_small(_p(x), x_rows if x_rows is not None else rows, _p(W), _p(bias), _p(add), add_rows, _p(y),
-                                rows, N, K, act_in, act_out, _stream()), "ldc_linear_small")
+def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE, mod=None, mod_rows=1):
+    """mod ([mod_rows][2 N]): y = y * (1 + mod[:, :N]) + mod[:, N:] as the epilogue (ldc_linear_small_mod)"""
+    _dev(x, W, y, bias, add, mod)
+    xr = x_rows if x_rows is not None else rows
+    if mod is not None:
+        _check(lib.ldc_linear_small_mod(_p(x), xr, _p(W), _p(bias), _p(add), add_rows, _p(mod), mod_rows, _p(y), rows, N, K, act_in, act_out, _stream()),
+               "ldc_linear_small_mod")
+        return
+    _check(lib.ldc_linear_small(_p(x), xr, _p(W), _p(bias), _p(add), add_rows, _p(y), rows, N, K, act_in, act_out, _stream()), "ldc_linear_small")
+
+
+def gate_residual_layernorm(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs, ld_out, out_bs, weight, bias, eps, out_split=False):
+    """resid += gate * y in place, then out = LayerNorm(resid) * weight + bias (one launch)"""
+    _dev(resid, y, gate, out, weight, bias)
+    _check(lib.ldc_gate_residual_layernorm(_p(resid), _p(y), _p(gate), _p(out), B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs, ld_out, out_bs,
+                                           _p(weight), _p(bias), eps, 1 if out_split else 0, _stream()), "ldc_gate_residual_layernorm")
 
 
 LINEAR_SMALL_MAX_GROUPED = 4  # LDC_LINEAR_SMALL_MAX_GROUPED
@@ -232,10 +246,10 @@ def linear_small_grouped(problems):
     _check(lib.ldc_linear_small_grouped(arr, n, _stream()), "ldc_linear_small_grouped")
 
 
-def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, split_bf16=False):
+def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs):
+    """exact-fp32 attention on fp32 q / k / v views (ldc_attn_fwd)"""
     _dev(Q, K, V, O)
-    fn = lib.ldc_attn_fwd_bf16x3 if split_bf16 else lib.ldc_attn_fwd
-    _check(fn(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd" + ("_bf16x3" if split_bf16 else ""))
+    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd")
 
 
 _score_ws = {}

@@ -431,7 +431,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         return out
 
     # -- building blocks ---------------------------------------------------------------------
-    def _timestep_mlps(self, tsin, Bt, pooled, B, ws):
+    def _timestep_mlps(self, timestep, Bt, pooled, B, ws):
         """Both CombinedTimestepTextProjEmbeddings of one forward (the refiner's and the model's): their timestep MLPs
         depend only on the timestep, and the refiner's text MLP starts from the first pooled context - three independent
         first layers in one launch, the two timestep second layers in the next, then the refiner's sum.
@@ -439,9 +439,11 @@ class LaDCastTransformer3DModel(ModelMixin):
         D = self.inner_dim
         r, m = self.context_refiner.time_text_embed, self.time_text_embed
         P = hip.linear_small_problem
+        # the sinusoidal timestep embedding (diffusers Timesteps) is computed while the first Linears stage their input row
+        TS = hip.ACT_IN_TIMESTEP_SINCOS
         hip.linear_small_grouped([
-            P(tsin, r.timestep_embedder.linear_1.weight, ws.t1, rows=Bt, N=D, K=256, bias=r.timestep_embedder.linear_1.bias, act_out=hip.ACT_SILU),
-            P(tsin, m.timestep_embedder.linear_1.weight, ws.t1m, rows=Bt, N=D, K=256, bias=m.timestep_embedder.linear_1.bias, act_out=hip.ACT_SILU),
+            P(timestep, r.timestep_embedder.linear_1.weight, ws.t1, rows=Bt, N=D, K=256, bias=r.timestep_embedder.linear_1.bias, act_in=TS, act_out=hip.ACT_SILU),
+            P(timestep, m.timestep_embedder.linear_1.weight, ws.t1m, rows=Bt, N=D, K=256, bias=m.timestep_embedder.linear_1.bias, act_in=TS, act_out=hip.ACT_SILU),
             P(pooled, r.text_embedder.linear_1.weight, ws.p1, rows=B, N=D, K=D, bias=r.text_embedder.linear_1.bias, act_out=hip.ACT_SILU),
         ])
         hip.linear_small_grouped([
@@ -451,12 +453,14 @@ class LaDCastTransformer3DModel(ModelMixin):
         tx = r.text_embedder
         hip.linear_small(ws.p1, tx.linear_2.weight, ws.temb_r, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=ws.t2, add_rows=Bt)
 
-    def _text_mlp(self, emb, pooled, B, Bt, t2, ws, out):
-        """text_embedder(pooled) + the timestep MLP output computed earlier"""
+    def _text_mlp(self, emb, pooled, B, Bt, t2, ws, out, te=None):
+        """text_embedder(pooled) + the timestep MLP output computed earlier; te (rows, 2D): the time-elapsed modulation
+        temb * (1 + scale) + shift (models/LaDCast_3D_model.py:958-969) as the second Linear's epilogue"""
         D = self.inner_dim
         tx = emb.text_embedder
         hip.linear_small(pooled, tx.linear_1.weight, ws.p1, rows=B, N=D, K=D, bias=tx.linear_1.bias, act_out=hip.ACT_SILU)
-        hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt)
+        hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt, mod=te,
+                         mod_rows=1 if te is None else te.shape[0])
 
     def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False):
         """Attention over token rows [row0, row0 + Sx + Sc) of the fused qkv buffer -> out.
@@ -487,7 +491,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
                                 wq=nq.weight, wk=nk.weight, eps=nq.eps, cos=c, sin=s_)
             r0 += rows
-        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, split_bf16=False)
+        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs)
 
     def _qkv_epi(self, norm_q, norm_k, cos, sin):
         """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + rotary tables (None = no RoPE)"""
@@ -664,12 +668,11 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
-        hip.timestep_embedding(timestep, ws.tsin, Bt)
         if split:  # the pooling pass also leaves the embedded context in the split format for proj_in (nh_c is free until the first norm)
             hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D, x_split=nh_c, lds=D, s_bs=SD)
         else:
             hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
-        self._timestep_mlps(ws.tsin, Bt, ws.pooled, B, ws)
+        self._timestep_mlps(timestep, Bt, ws.pooled, B, ws)
         if split:
             run1(nh_c, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=ref.proj_in.bias, flags=AS)
         else:
@@ -681,8 +684,9 @@ class LaDCastTransformer3DModel(ModelMixin):
                     [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, cc, cs)])
             self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
-            hip.gate_residual(h_c, ws.att[:, Nx:], ws.mod_a, h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D)
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm2.weight, shift=blk.norm2.bias, mode=1, eps=blk.norm2.eps, out_split=split)
+            # gated attention residual + norm2 in one launch
+            hip.gate_residual_layernorm(h_c, ws.att[:, Nx:], ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
+                                        ld_out=D, out_bs=SD, weight=blk.norm2.weight, bias=blk.norm2.bias, eps=blk.norm2.eps, out_split=split)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
             run1(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU, flags=AS | CS)
@@ -691,9 +695,7 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         # 3. conditioning embedding, models/LaDCast_3D_model.py:953-969
         hip.mean_rows(h_c, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=SD)
-        self._text_mlp(self.time_text_embed, ws.pooled, B, Bt, ws.t2m, ws, ws.temb)
-        if te is not None:
-            hip.temb_modulate(ws.temb, te, B=B, D=D, te_rows=te.shape[0])
+        self._text_mlp(self.time_text_embed, ws.pooled, B, Bt, ws.t2m, ws, ws.temb, te=te)
         NM = plan.mod_w.shape[0]
         hip.linear_small(ws.temb, plan.mod_w, ws.mods, rows=B, N=NM, K=D, bias=plan.mod_b, act_in=hip.ACT_SILU)
 

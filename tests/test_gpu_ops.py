@@ -276,22 +276,6 @@ def test_attention(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
 
 
-@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 2250, 16)])
-def test_attention_bf16x3(hip, B, S, H):
-    D = H * 128
-    qkv = rnd(B, S, 3 * D, seed=11)
-    qkv[..., :D] *= 4.0  # logits with std ~4: a sharp softmax, so errors in S are not washed out
-    d_qkv = dev(qkv)
-    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
-    hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D,
-                 ldo=D + 64, o_bs=S * (D + 64), split_bf16=True)
-    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
-    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
-    assert torch.isfinite(out[:, :, :D]).all()
-    assert rel(out[:, :, :D], want) < 2e-5
-    assert torch.isnan(out[:, :, D:]).all()
-
-
 def _packed(hip, B, S, H):
     return torch.empty(hip.attn_packed_bytes(B, S, H) // 4, device="cuda", dtype=torch.float32)
 
@@ -415,19 +399,6 @@ def test_attention_packed_rescale_branch(hip):
     out = torch.empty(1, S, 128, device="cuda")
     hip.attn_pack(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], pk, B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, split_row=S)
     hip.attn_fwd_packed(pk, out, B=1, S=S, H=1, ldo=128, o_bs=S * 128)
-    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
-    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
-    assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
-
-
-def test_attention_bf16x3_rescale_branch(hip):
-    S = 200
-    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
-    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0
-    d_qkv = dev(qkv)
-    out = torch.empty(1, S, 128, device="cuda")
-    hip.attn_fwd(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], out, B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, ldo=128, o_bs=S * 128,
-                 split_bf16=True)
     q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
     want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
     assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
@@ -813,3 +784,55 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     assert rel(h1 + l1, h2 + l2) < 1e-5
     with pytest.raises(RuntimeError):  # N must be 3 * heads * 128
         hip.gemm_grouped_qkv(probs[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, None, heads=H + 1)])
+
+
+# -- launch merges: each fused launch is bit-identical to the two launches it replaces ---------------------------------------------------
+def test_timestep_sinusoid_inside_the_first_linear_is_bitwise(hip):
+    D = 1536
+    t = dev(torch.tensor([0.3, -1.553652, 1.0955067, 0.0, 0.77]))[1:4]  # 4-byte-aligned view, as the sampler's c_noise[i : i + 1]
+    W, b = dev(rnd(D, 256, seed=1) / 16), dev(rnd(D, seed=2))
+    tsin = torch.empty(3, 256, device="cuda")
+    hip.timestep_embedding(t.contiguous(), tsin, 3)
+    y0, y1, y2 = [torch.empty(3, D, device="cuda") for _ in range(3)]
+    hip.linear_small(tsin, W, y0, rows=3, N=D, K=256, bias=b, act_out=hip.ACT_SILU)
+    hip.linear_small(t, W, y1, rows=3, N=D, K=256, bias=b, act_in=hip.ACT_IN_TIMESTEP_SINCOS, act_out=hip.ACT_SILU)
+    hip.linear_small_grouped([hip.linear_small_problem(t, W, y2, rows=3, N=D, K=256, bias=b, act_in=hip.ACT_IN_TIMESTEP_SINCOS, act_out=hip.ACT_SILU)])
+    assert torch.equal(y1, y0) and torch.equal(y2, y0)
+    want = F.silu(L.get_timestep_embedding(t.cpu(), 256).double() @ W.cpu().double().T + b.cpu().double())
+    assert rel(y1, want) < 1e-5
+    with pytest.raises(RuntimeError):
+        hip.linear_small(t, W[:, :128].contiguous(), y1, rows=3, N=D, K=128, act_in=hip.ACT_IN_TIMESTEP_SINCOS)  # K must be 256
+
+
+@pytest.mark.parametrize("B,te_rows", [(1, 1), (3, 1), (3, 3)])
+def test_linear_small_modulation_epilogue_is_bitwise(hip, B, te_rows):
+    D = 1536
+    x, W, b, add = dev(rnd(B, D, seed=1)), dev(rnd(D, D, seed=2) / 40), dev(rnd(D, seed=3)), dev(rnd(1, D, seed=4))
+    te = dev(rnd(te_rows, 2 * D, seed=5) * 0.3)
+    y0, y1 = torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda")
+    hip.linear_small(x, W, y0, rows=B, N=D, K=D, bias=b, add=add, add_rows=1)
+    hip.temb_modulate(y0, te, B=B, D=D, te_rows=te_rows)
+    hip.linear_small(x, W, y1, rows=B, N=D, K=D, bias=b, add=add, add_rows=1, mod=te, mod_rows=te_rows)
+    assert torch.equal(y1, y0)
+    v = x.cpu().double() @ W.cpu().double().T + b.cpu().double() + add.cpu().double()
+    t = te.cpu().double().expand(B, -1) if te_rows == 1 else te.cpu().double()
+    assert rel(y1, v * (1 + t[:, :D]) + t[:, D:]) < 1e-5
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_gate_residual_layernorm_is_bitwise(hip, split):
+    B, rows, D = 2, 450, 1536
+    h, y, gate = rnd(B, rows + 3, D, seed=1), dev(rnd(B, rows, D, seed=2)), dev(rnd(B, 2 * D, seed=3))
+    w, b = dev(1 + 0.1 * rnd(D, seed=4)), dev(0.1 * rnd(D, seed=5))
+    h0, h1 = dev(h), dev(h)
+    o0, o1 = torch.full((B, rows, D), float("nan"), device="cuda"), torch.full((B, rows, D), float("nan"), device="cuda")
+    kw = dict(B=B, rows=rows, D=D, ld_res=D, res_bs=(rows + 3) * D, ld_y=D, y_bs=rows * D, gate_bs=2 * D)
+    hip.gate_residual(h0, y, gate, h0, **kw)
+    hip.layernorm_mod(h0, o0, B=B, rows=rows, D=D, ldx=D, x_bs=(rows + 3) * D, ldy=D, y_bs=rows * D, scale=w, shift=b, mode=1, eps=1e-7, out_split=split)
+    hip.gate_residual_layernorm(h1, y, gate, o1, ld_out=D, out_bs=rows * D, weight=w, bias=b, eps=1e-7, out_split=split, **kw)
+    assert torch.equal(h1, h0) and torch.equal(o1.view(torch.int32), o0.view(torch.int32))
+    assert torch.equal(h1[:, rows:].cpu(), h[:, rows:])  # rows past `rows` untouched
+    want_h = h[:, :rows].double() + gate.cpu()[:, None, :D].double() * y.cpu().double()
+    assert rel(h1[:, :rows], want_h) < 1e-6
+    if not split:
+        assert rel(o1, F.layer_norm(want_h, (D,), w.cpu().double(), b.cpu().double(), 1e-7)) < 1e-5
