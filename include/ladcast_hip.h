@@ -198,15 +198,16 @@ int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H
  * models/LaDCast_3D_model.py:103-169,183-203. */
 /* The QKV projection with those operand rows as its OUTPUT: ldc_gemm_grouped_bf16x3 (pre-split activations, K % 32 == 0) whose
  * epilogue, for every problem i with epi[i].heads > 0 (N = 3 * heads * 128, C = the fused buffer, no act / gate / residual), adds
- * the bias, applies RMSNorm(128, eps) * wq | wk and the rotary embedding (table row = rope_row0 + m; NULL = none) to the q and k
+ * the bias, applies RMSNorm(128, eps) * wq | wk and the rotary embedding (compact table, row = rope_row0 + m; NULL = none) to the q and k
  * heads, multiplies q by qscale (0 = log2(e) / sqrt(128)) and writes the split rows - to_q/to_k/to_v (+ add_*_proj), norm_q/k,
  * apply_rotary_emb of models/LaDCast_3D_model.py:92-169,175-190 in one launch.  Problems with heads == 0 get the ordinary epilogue.
  * LDC_ERR_UNSUPPORTED: shape not served by that kernel - run the plain GEMM, then ldc_attn_qkv_prepare_split. */
 typedef struct ldc_qkv_epilogue {
-  const float* wq;  /* [128] */
-  const float* wk;  /* [128] */
-  const float* cos; /* [rows][128] */
-  const float* sin;
+  const float* wq;   /* [128] */
+  const float* wk;   /* [128] */
+  const float* rope; /* [rows][64][2] = (cos_i, sin_i) of rotary pair i: the compact form of the reference's [rows][128] cos / sin
+                        tables, which hold every value twice (repeat_interleave(2)); NULL = no rotary embedding */
+  const float* reserved; /* NULL */
   float eps, qscale;
   int heads, rope_row0;
 } ldc_qkv_epilogue;

@@ -56,8 +56,7 @@ struct DevProblem {
   int qkv_heads;  // 0 = ordinary epilogue
   int rope_row0;
   const float* qk_w[2];
-  const float* rope_cos;
-  const float* rope_sin;
+  const float* rope_cs;  // [rows][64][2]: (cos, sin) of rotary pair i
   float eps, qscale;
 };
 
@@ -110,6 +109,14 @@ __device__ __forceinline__ float xor32_add(float x) {
 // bias -> RMSNorm(128, eps) * weight -> adjacent-pair rotary embedding (q and k heads; same operation order as
 // qk_rmsnorm_rope_kernel) -> q * qscale -> hi / lo split, written as the operand rows of attn_split.hip: q / k in the
 // LDC_GEMM_A_SPLIT group format, v as [hi x128 | lo x128].  This is what attn_pack_kernel did in a separate pass.
+// The rotary table is the compact form [rows][64][2] = (cos_i, sin_i) per rotary pair (the reference's [rows][128] cos / sin
+// tables repeat every value twice, get_1d_rotary_pos_embed: repeat_interleave(2)).  (A factored table - distinct (cos, sin) rows per
+// axis, ~10 KB, plus a coordinate triple per token - gave the same bits and no gain on the 128-row instance, +24 us on the 256-row
+// one, whose registers the extra address arithmetic does not fit: dropped.)
+// Measured (tools/qkv_epilogue_ab.py, profiles/r02_*_qkv_epilogue_ab.log): +2.5 / +4 / +12 us per launch on the refiner / dual /
+// single-block QKV launches over the plain epilogue, against the 16-22 us pack pass it replaces; a variant that first turns the
+// accumulators into a row-per-lane layout through LDS (contiguous table reads, no cross-lane sums) was 3x worse (+50 us on the
+// 256-row launch: two lanes per row serialise what 4 lanes x 8 column tiles issue in parallel here) and was dropped.
 template <int BM>
 __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                              int lane) {
@@ -118,63 +125,68 @@ __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm,
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v
   const int nl = 4 * (lane >> 4);
+  const float* __restrict__ bias = P.bias ? P.bias + bn * BN + nl : nullptr;
+  const float* __restrict__ w = which < 2 ? P.qk_w[which] : nullptr;
+  const float* __restrict__ rope = which < 2 ? P.rope_cs : nullptr;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
     if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
-    float x[8][4];
+    float r = 1.f;
+    if (w) {  // pass 1: sum of squares of the head row (acc + bias, recomputed below: registers, not time, are what is scarce here)
+      float ss = 0.f;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const f32x4 av = acc[rt * 8 + ct];
-      x[ct][0] = av[0]; x[ct][1] = av[1]; x[ct][2] = av[2]; x[ct][3] = av[3];
-      if (P.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(P.bias + bn * BN + 16 * ct + nl);
-        x[ct][0] += bv.x; x[ct][1] += bv.y; x[ct][2] += bv.z; x[ct][3] += bv.w;
+      for (int ct = 0; ct < 8; ++ct) {
+        f32x4 x = acc[rt * 8 + ct];
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ct);
+          x[0] += bv.x; x[1] += bv.y; x[2] += bv.z; x[3] += bv.w;
+        }
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
       }
+      ss = xor32_add(xor16_add(ss));
+      r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
     }
     unsigned char* row = reinterpret_cast<unsigned char*>(C + static_cast<long long>(m) * P.d.ldc + bn * BN);
-    if (which < 2) {
-      const float* __restrict__ w = P.qk_w[which];
-      if (w) {
-        float ss = 0.f;
+    const float* __restrict__ cs = rope ? rope + static_cast<long long>(P.rope_row0 + m) * 128 + nl : nullptr;
+    // pass 2, four column tiles at a time (the accumulators of a 256-row tile leave room for little else)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) ss += x[ct][0] * x[ct][0] + x[ct][1] * x[ct][1] + x[ct][2] * x[ct][2] + x[ct][3] * x[ct][3];
-        ss = xor32_add(xor16_add(ss));
-        const float r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
+    for (int half = 0; half < 2; ++half) {
+      float x[4][4];
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int ct = 4 * half + c4;
+        const f32x4 av = acc[rt * 8 + ct];
+        x[c4][0] = av[0]; x[c4][1] = av[1]; x[c4][2] = av[2]; x[c4][3] = av[3];
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ct);
+          x[c4][0] += bv.x; x[c4][1] += bv.y; x[c4][2] += bv.z; x[c4][3] += bv.w;
+        }
+        if (w) {
           const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + nl);
-          x[ct][0] = x[ct][0] * r * wv.x; x[ct][1] = x[ct][1] * r * wv.y; x[ct][2] = x[ct][2] * r * wv.z; x[ct][3] = x[ct][3] * r * wv.w;
+          x[c4][0] = x[c4][0] * r * wv.x; x[c4][1] = x[c4][1] * r * wv.y; x[c4][2] = x[c4][2] * r * wv.z; x[c4][3] = x[c4][3] * r * wv.w;
         }
-      }
-      if (P.rope_cos) {
-        const long long trow = static_cast<long long>(P.rope_row0 + m) * 128 + nl;
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-          const float4 c = *reinterpret_cast<const float4*>(P.rope_cos + trow + 16 * ct);
-          const float4 s = *reinterpret_cast<const float4*>(P.rope_sin + trow + 16 * ct);
-          const float o0 = x[ct][0] * c.x + (-x[ct][1]) * s.x, o1 = x[ct][1] * c.y + x[ct][0] * s.y;
-          const float o2 = x[ct][2] * c.z + (-x[ct][3]) * s.z, o3 = x[ct][3] * c.w + x[ct][2] * s.w;
-          x[ct][0] = o0; x[ct][1] = o1; x[ct][2] = o2; x[ct][3] = o3;
+        if (cs) {  // (cos, sin) of this lane's two rotary pairs: one 16-byte load
+          const float4 t = *reinterpret_cast<const float4*>(cs + 16 * ct);
+          const float o0 = x[c4][0] * t.x + (-x[c4][1]) * t.y, o1 = x[c4][1] * t.x + x[c4][0] * t.y;
+          const float o2 = x[c4][2] * t.z + (-x[c4][3]) * t.w, o3 = x[c4][3] * t.z + x[c4][2] * t.w;
+          x[c4][0] = o0; x[c4][1] = o1; x[c4][2] = o2; x[c4][3] = o3;
         }
+        if (which == 0) { x[c4][0] *= P.qscale; x[c4][1] *= P.qscale; x[c4][2] *= P.qscale; x[c4][3] *= P.qscale; }
       }
-      if (which == 0) {
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) { x[ct][0] *= P.qscale; x[ct][1] *= P.qscale; x[ct][2] *= P.qscale; x[ct][3] *= P.qscale; }
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int n = 16 * (4 * half + c4) + nl;
+        float r0, r1, r2, r3;
+        const unsigned hx = ldc_split_pair(x[c4][0], x[c4][1], r0, r1), hy = ldc_split_pair(x[c4][2], x[c4][3], r2, r3);
+        const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
+        // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
+        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+        unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
+                                       : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
+        *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
       }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const int n = 16 * ct + nl;
-      float r0, r1, r2, r3;
-      const unsigned hx = ldc_split_pair(x[ct][0], x[ct][1], r0, r1), hy = ldc_split_pair(x[ct][2], x[ct][3], r2, r3);
-      const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
-      // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
-      const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
-      const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
-      unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
-                                     : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
-      *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
   }
 }
@@ -660,15 +672,14 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       const ldc_qkv_epilogue& e = epi[i];
       auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
       if (d.N != 3 * e.heads * BN || d.act != LDC_ACT_NONE || q.gate != nullptr || q.R != nullptr) return LDC_ERR_ARG;
-      if ((e.wq == nullptr) != (e.wk == nullptr) || (e.cos == nullptr) != (e.sin == nullptr) || e.rope_row0 < 0) return LDC_ERR_ARG;
+      if ((e.wq == nullptr) != (e.wk == nullptr) || e.reserved != nullptr || e.rope_row0 < 0) return LDC_ERR_ARG;
       if ((d.ldc & 7) || (d.c_bs & 7) || (reinterpret_cast<unsigned long long>(q.C) & 31ull)) return LDC_ERR_ALIGN;
-      if (!al16(e.wq) || !al16(e.wk) || !al16(e.cos) || !al16(e.sin) || (q.bias && !al16(q.bias))) return LDC_ERR_ALIGN;
+      if (!al16(e.wq) || !al16(e.wk) || !al16(e.rope) || (q.bias && !al16(q.bias))) return LDC_ERR_ALIGN;
       P.qkv_heads = e.heads;
       P.rope_row0 = e.rope_row0;
       P.qk_w[0] = e.wq;
       P.qk_w[1] = e.wk;
-      P.rope_cos = e.cos;
-      P.rope_sin = e.sin;
+      P.rope_cs = e.rope;
       P.eps = e.eps;
       P.qscale = e.qscale != 0.f ? e.qscale : 0.08838834764831845f * 1.4426950408889634f;
     }

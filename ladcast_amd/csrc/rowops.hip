@@ -241,6 +241,14 @@ constexpr int LS_ROWS = 8;
 constexpr int LS_CPW_MAX = 4; // output columns per wave: 4 for wide outputs, 1 when that would leave CUs idle
 constexpr int LS_KC = 2048;   // K chunk staged in LDS (8 rows x 2048 x 4 B = 64 KiB)
 
+// v * (1 + scale) + shift with separately rounded product and sum (no fma contraction): the bits of temb_modulate_kernel
+__device__ __forceinline__ float modulate_nocontract(float v, float scale, float shift) {
+#pragma clang fp contract(off)
+  const float f = 1.f + scale;
+  const float p = v * f;
+  return p + shift;
+}
+
 template <int LS_CPW>
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const float* __restrict__ add,
@@ -337,7 +345,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
           if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
           if (mod) {  // v * (1 + scale) + shift, scale | shift = the two halves of a [mod_rows][2 N] table; no contraction: the
             const float* mr = mod + static_cast<long long>(r % mod_rows) * 2 * N;  // same bits as temb_modulate_kernel
-            v = __fadd_rn(__fmul_rn(v, __fadd_rn(1.f, mr[n])), mr[N + n]);
+            v = modulate_nocontract(v, mr[n], mr[N + n]);
           }
           y[static_cast<long long>(r) * N + n] = v;
         }

@@ -41,7 +41,7 @@ MAX_GROUPED = 4
 
 
 class QkvEpilogue(Structure):  # ldc_qkv_epilogue
-    _fields_ = [("wq", c_void_p), ("wk", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("eps", c_float), ("qscale", c_float),
+    _fields_ = [("wq", c_void_p), ("wk", c_void_p), ("rope", c_void_p), ("reserved", c_void_p), ("eps", c_float), ("qscale", c_float),
                 ("heads", c_int), ("rope_row0", c_int)]
 
 
@@ -286,11 +286,20 @@ def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None
                                     *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
 
 
-def qkv_epilogue(wq=None, wk=None, cos=None, sin=None, *, eps=1e-7, heads, rope_row0=0, qscale=0.0):
-    """epilogue of one QKV-projection problem of `gemm_grouped_qkv` (ldc_qkv_epilogue); returns (struct, keep-alive tuple)"""
-    _dev(wq, wk, cos, sin)
+def compact_rope_table(cos, sin):
+    """the reference's [rows][128] cos / sin tables (every value twice: get_1d_rotary_pos_embed's repeat_interleave(2)) -> the
+    [rows][64][2] (cos_i, sin_i) table of `qkv_epilogue`; refuses tables that are not of that form"""
+    if not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+        raise ValueError("rotary tables must hold every (cos, sin) value twice (adjacent-pair RoPE)")
+    return torch.stack([cos[:, 0::2], sin[:, 0::2]], dim=-1).reshape(cos.shape[0], cos.shape[1]).contiguous()
+
+
+def qkv_epilogue(wq=None, wk=None, rope=None, *, eps=1e-7, heads, rope_row0=0, qscale=0.0):
+    """epilogue of one QKV-projection problem of `gemm_grouped_qkv` (ldc_qkv_epilogue); rope = `compact_rope_table(cos, sin)`;
+    returns (struct, keep-alive tuple)"""
+    _dev(wq, wk, rope)
     pv = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    return QkvEpilogue(pv(wq), pv(wk), pv(cos), pv(sin), eps, qscale, heads, rope_row0), (wq, wk, cos, sin)
+    return QkvEpilogue(pv(wq), pv(wk), pv(rope), None, eps, qscale, heads, rope_row0), (wq, wk, rope)
 
 
 def gemm_grouped_qkv(problems, epilogues):

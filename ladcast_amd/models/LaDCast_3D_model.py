@@ -408,8 +408,11 @@ class LaDCastTransformer3DModel(ModelMixin):
             pc, ps = rope_tables_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
             cc, cs = rope_tables_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
             pc, ps, cc, cs = (t.to(dev) for t in (pc, ps, cc, cs))
-            # joint [S][128] tables of the single-stream blocks (pred rows, then cond rows): one table for a fused QKV epilogue
-            self._rope[key] = (pc, ps, cc, cs, torch.cat([pc, cc], dim=0).contiguous(), torch.cat([ps, cs], dim=0).contiguous())
+            # compact (cos_i, sin_i) tables for the fused QKV epilogue: pred rows, cond rows, and the joint table of the single-stream
+            # blocks (pred rows, then cond rows)
+            pk, ck = hip.compact_rope_table(pc, ps), hip.compact_rope_table(cc, cs)
+            jk = torch.cat([pk, ck], dim=0).contiguous()
+            self._rope[key] = (pc, ps, cc, cs, pk, ck, jk)
         return self._rope[key]
 
     def _time_elapsed_embedding(self, time_elapsed, dev):
@@ -493,11 +496,11 @@ class LaDCastTransformer3DModel(ModelMixin):
             r0 += rows
         hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs)
 
-    def _qkv_epi(self, norm_q, norm_k, cos, sin):
-        """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + rotary tables (None = no RoPE)"""
+    def _qkv_epi(self, norm_q, norm_k, rope):
+        """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + compact rotary table (None = no RoPE)"""
         if norm_q.eps != norm_k.eps:
             raise NotImplementedError("the fused QKV epilogue takes one RMSNorm eps for q and k")
-        return hip.qkv_epilogue(norm_q.weight, norm_k.weight, cos, sin, eps=norm_q.eps, heads=self.config.num_attention_heads)
+        return hip.qkv_epilogue(norm_q.weight, norm_k.weight, rope, eps=norm_q.eps, heads=self.config.num_attention_heads)
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -618,7 +621,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         if key not in self._ws:
             self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(plan.kx_pad, plan.kc_pad), C_out, plan.mod_w.shape[0])
         ws = self._ws[key]
-        pc, ps, cc, cs, jc, js = self._rope_tables(R, T_in, Hh, Ww, dev)
+        pc, ps, cc, cs, pk, ck, jk = self._rope_tables(R, T_in, Hh, Ww, dev)
         SD = S * D
         h_x, h_c = ws.h[:, :Nx], ws.h[:, Nx:]
         nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
@@ -681,7 +684,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)
             run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
-                    [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, cc, cs)])
+                    [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
             self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
@@ -713,7 +716,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             run_qkv([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
-            ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pc, ps), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None, None)])
+            ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
             self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
                             (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
@@ -745,7 +748,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
                   flags=AS | CS),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
-            ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jc, js)])
+            ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
             self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
                             (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,

@@ -760,11 +760,11 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     mlp = torch.empty(batch, S, 512, device="cuda")
     f = hip.GEMM_A_SPLIT
     probs = [hip.gemm_problem(Ap, hip.pack_weight_bf16x2(dev(Wx)), qkv, M=Nx, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D, bias=dev(bx), flags=f)]
-    epis = [hip.qkv_epilogue(dev(wq0), dev(wk0), dev(cos0), dev(sin0), eps=1e-7, heads=H)]
+    epis = [hip.qkv_epilogue(dev(wq0), dev(wk0), hip.compact_rope_table(dev(cos0), dev(sin0)), eps=1e-7, heads=H)]
     if Nc:
         probs.append(hip.gemm_problem(Ap[:, Nx:], hip.pack_weight_bf16x2(dev(Wc)), qkv[:, Nx:], M=Nc, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D,
                                       bias=dev(bc), flags=f))
-        epis.append(hip.qkv_epilogue(dev(wq1), dev(wk1), None, None, eps=1e-7, heads=H))
+        epis.append(hip.qkv_epilogue(dev(wq1), dev(wk1), None, eps=1e-7, heads=H))
     probs.append(hip.gemm_problem(Ap, hip.pack_weight_bf16x2(dev(Wm)), mlp, M=S, N=512, K=K, batch=batch, a_bs=S * K, c_bs=S * 512, bias=dev(bm), act=2, flags=f))
     epis.append(None)
     hip.gemm_grouped_qkv(probs, epis)
@@ -783,7 +783,7 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     h2, l2 = _unsplit(qkv2[..., : 2 * D].reshape(batch * S, 2 * D), batch * S, 2 * D)
     assert rel(h1 + l1, h2 + l2) < 1e-5
     with pytest.raises(RuntimeError):  # N must be 3 * heads * 128
-        hip.gemm_grouped_qkv(probs[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, None, heads=H + 1)])
+        hip.gemm_grouped_qkv(probs[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, heads=H + 1)])
 
 
 # -- launch merges: each fused launch is bit-identical to the two launches it replaces ---------------------------------------------------

@@ -10,7 +10,7 @@ D = H * 128
 calls = {"refiner qkv": [(450, 3 * D, D, "q")], "dual qkv": [(1800, 3 * D, D, "q"), (450, 3 * D, D, "q")],
          "single qkv+mlp": [(2250, 6144, D, "m"), (2250, 3 * D, D, "q")]}
 wq, wk = torch.rand(128, device="cuda") + 0.5, torch.rand(128, device="cuda") + 0.5
-cos, sin = torch.rand(2250, 128, device="cuda"), torch.rand(2250, 128, device="cuda")
+rope = torch.rand(2250, 128, device="cuda")  # compact (cos_i, sin_i) table
 for name, probs in calls.items():
     ps, epis = [], []
     for M, N, K, kind in probs:
@@ -18,8 +18,11 @@ for name, probs in calls.items():
         b = torch.randn(N, device="cuda")
         fl = hip.GEMM_A_SPLIT | (hip.GEMM_C_SPLIT if kind == "m" else 0)
         ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, bias=b, act=2 if kind == "m" else 0, flags=fl))
-        epis.append(hip.qkv_epilogue(wq, wk, cos, sin, heads=H) if kind == "q" else None)
-    variants = {"plain": lambda: hip.gemm_grouped(ps, split_bf16=True), "qkv epilogue": lambda: hip.gemm_grouped_qkv(ps, epis)}
+        epis.append(hip.qkv_epilogue(wq, wk, rope, heads=H) if kind == "q" else None)
+    epis_nr = [hip.qkv_epilogue(wq, wk, None, heads=H) if e is not None else None for e in epis]  # norm + split only (no rotary table traffic)
+    epis_nn = [hip.qkv_epilogue(None, None, None, heads=H) if e is not None else None for e in epis]  # split only
+    variants = {"plain": lambda: hip.gemm_grouped(ps, split_bf16=True), "qkv epilogue": lambda: hip.gemm_grouped_qkv(ps, epis),
+                "no rope": lambda: hip.gemm_grouped_qkv(ps, epis_nr), "split only": lambda: hip.gemm_grouped_qkv(ps, epis_nn)}
     t_end = time.time() + 1.5
     while time.time() < t_end:
         for fn in variants.values():
