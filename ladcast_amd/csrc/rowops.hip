@@ -249,7 +249,9 @@ __device__ __forceinline__ float modulate_nocontract(float v, float scale, float
   return p + shift;
 }
 
-template <int LS_CPW>
+// FULL = false compiles the timestep-sinusoid input and the modulation epilogue out: the wide (LS_CPW_MAX) instantiation that streams
+// the 38 D x D AdaLN matrix sits at 125 VGPRs = 4 waves per SIMD, and nine more registers would cost it a wave (76 -> 126 us measured)
+template <int LS_CPW, bool FULL = true>
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const float* __restrict__ add,
                                                   int add_rows, float* __restrict__ y, int rows, int N, int K, int kc,
@@ -284,7 +286,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
         for (int idx = threadIdx.x; idx < rows_here * nv4; idx += 256) {
           const int i = idx / nv4, c = idx - i * nv4;
           float4 xv;
-          if (act_in == LDC_ACT_IN_TIMESTEP_SINCOS) {
+          if (FULL && act_in == LDC_ACT_IN_TIMESTEP_SINCOS) {
             // x holds one timestep per row; the staged row is its 256-wide sinusoidal embedding (same expressions as
             // timestep_embedding_kernel: bit-identical values), K == 256
             const float t = x[(r_base + i) % x_rows];
@@ -300,7 +302,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
           } else {
             xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
           }
-          if (act_in != LDC_ACT_NONE && act_in != LDC_ACT_IN_TIMESTEP_SINCOS) {
+          if (act_in != LDC_ACT_NONE && !(FULL && act_in == LDC_ACT_IN_TIMESTEP_SINCOS)) {
             xv.x = ldc_apply_act(xv.x, act_in);
             xv.y = ldc_apply_act(xv.y, act_in);
             xv.z = ldc_apply_act(xv.z, act_in);
@@ -343,7 +345,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
           float v = sum + (bias ? bias[n] : 0.f);
           v = ldc_apply_act(v, act_out);
           if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
-          if (mod) {  // v * (1 + scale) + shift, scale | shift = the two halves of a [mod_rows][2 N] table; no contraction: the
+          if (FULL && mod) {  // v * (1 + scale) + shift, scale | shift = the two halves of a [mod_rows][2 N] table; no contraction: the
             const float* mr = mod + static_cast<long long>(r % mod_rows) * 2 * N;  // same bits as temb_modulate_kernel
             v = modulate_nocontract(v, mr[n], mr[N + n]);
           }
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            const float* __restrict__ add, int add_rows,
                                                            float* __restrict__ y, int rows, int N, int K, int kc, int act_in,
                                                            int act_out, int iters, const float* __restrict__ mod, int mod_rows) {
-  linear_small_body<LS_CPW>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters, mod, mod_rows);
+  linear_small_body<LS_CPW, LS_CPW == 1>(x, x_rows, W, bias, add, add_rows, y, rows, N, K, kc, act_in, act_out, iters, mod, mod_rows);
 }
 
 // up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears in one launch: blockIdx.z picks the problem
@@ -519,7 +521,8 @@ static int linear_small_impl(const float* x, int x_rows, const float* W, const f
   }();
   (void)attr_set;
   const int row_groups = ldc_cdiv(rows, LS_ROWS);
-  if (static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
+  const bool plain = mod == nullptr && act_in != LDC_ACT_IN_TIMESTEP_SINCOS;  // the wide instantiation has neither feature
+  if (plain && static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
     int iters = 1;
     if (K <= LS_KC) {  // one staged chunk: walk several column groups per workgroup, keep >= 4 workgroups per CU
       const long long groups = static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups;
