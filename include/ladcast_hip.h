@@ -152,15 +152,18 @@ typedef struct ldc_linear_small_problem {
 int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, void* stream);
 
 /* ---------------------------------------------------------------------------
- * Attention   O = softmax(Q K^T / sqrt(128)) V   per (batch, head), no mask
+ * Attention   O = softmax(Q K^T / sqrt(128) + key_bias) V   per (batch, head)
  *   Q,K,V: token-major [B][S][H][128] views with row stride ld_qkv and batch stride
  *   qkv_bs (so they can be column slices of one fused QKV buffer);
- *   O: [B][S][H*128] with row stride ldo, batch stride o_bs.
+ *   O: [B][S][H*128] with row stride ldo, batch stride o_bs;
+ *   key_bias: NULL, or [S] floats added to every query's score of that key - the float
+ *   attention mask of `scale_attn_by_lat` (models/LaDCast_3D_model.py:683-693,873-882:
+ *   a (1, 1, 1, keys) tensor, i.e. a function of the key alone).
  * Replaces F.scaled_dot_product_attention at models/LaDCast_3D_model.py:199-203
  * (incl. the transpose/flatten back to [B, N, C]).  head_dim must be 128.
  * ------------------------------------------------------------------------- */
 int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
-                 int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream);
+                 int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream);
 
 /* Split-bf16 attention in two steps, for callers that also need the q/k RMSNorm + rotary embedding:
  *   ldc_attn_pack_bf16x3     reads Q, K, V (same views as ldc_attn_fwd), applies to q and k the per-head
@@ -218,7 +221,8 @@ int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, int S, int H
                                const float* wq0, const float* wk0, const float* cos0, const float* sin0, const float* wq1,
                                const float* wk1, const float* cos1, const float* sin1, float eps, void* stream);
 int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
-                       long long qkv_bs, int ldo, long long o_bs, int flags, void* stream);
+                       long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* stream);
+/* key_bias: as ldc_attn_fwd's, but 32 * ceil(S / 32) floats (16-byte aligned; entries past S are ignored). */
 
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the
  * adjacent-pair rotary embedding (cos/sin tables [rows][128], NULL = no RoPE),

@@ -38,6 +38,7 @@ struct AttnArgs {
   long long qkv_bs, o_bs;
   float qscale;
   int nq;  // query blocks per (batch, head)
+  const float* kbias;  // additive per-key score bias (an SDPA float mask that only depends on the key), [S] or nullptr
 };
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
@@ -149,6 +150,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
 
     // ---- online softmax over the key axis (registers + the other lane half) --
     const int key_base = t * KT + 4 * half;
+    if (p.kbias) {  // scale_attn_by_lat (models/LaDCast_3D_model.py:873-882); scores are in log2 units here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_base + (r & 3) + 8 * (r >> 2);
+        s[r] += p.kbias[key < S ? key : S - 1] * 1.4426950408889634f;
+      }
+    }
     if (t == nt - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
 }  // namespace
 
 extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
-                            int ld_qkv, long long qkv_bs, int ldo, long long o_bs, void* stream) {
+                            int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream) {
   LDC_CHECK_PTR(Q);
   LDC_CHECK_PTR(K);
   LDC_CHECK_PTR(V);
@@ -227,6 +235,7 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
   AttnArgs p{Q, K, V, O, S, H, ld_qkv, ldo, qkv_bs, o_bs,
              0.08838834764831845f * 1.4426950408889634f};  // 1/sqrt(128) * log2(e)
   p.nq = ldc_cdiv(S, QB);
+  p.kbias = key_bias;
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   const size_t lds = 2 * STAGE * sizeof(float);
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)

@@ -160,6 +160,7 @@ struct AttnArgs {
   long long o_bs;
   int nq, nt;
   int out_split;
+  const float* kbias;  // additive per-key score bias (natural-log units, as an SDPA float mask), 32 * nt floats, or nullptr
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -216,7 +217,9 @@ __device__ __forceinline__ float xor32_add(float x) {
       if (kb_ + 16 * kt_ + r_ >= S) { SN[kt_][0][r_] = -1.0e30f; SN[kt_][1][r_] = -1.0e30f; } \
   }
 
-template <int NGRP, int TERMS>
+// BIAS: scores += kbias[key] (models/LaDCast_3D_model.py:873-882 `scale_attn_by_lat`: a float attention mask that only depends on
+// the key) - it enters as the initial value of the S accumulators, so it costs no instruction in the MFMA stream
+template <int NGRP, int TERMS, bool BIAS>
 __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;  // key-range group (wave-uniform)
@@ -318,10 +321,27 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
 
   // ---- prologue: scores of the group's first tile, their running max and exponentials (nothing to overlap with yet) ----
   f32x4 eA[2][2], eB[2][2];
+  // key bias of a tile in the accumulator layout (keys 32 t + 16 kt + 4 g4 + r), in log2 units; prefetched one tile ahead
+  auto load_bias = [&](int t, int kt) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p.kbias + t * KT + 16 * kt + 4 * g4);
+    return v * 1.4426950408889634f;
+  };
+  f32x4 kb_next[2] = {zero4, zero4};
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) eA[kt][qt] = eB[kt][qt] = zero4;
+  if constexpr (BIAS) {
+    if (t_begin < t_end) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const f32x4 v = load_bias(t_begin, kt);
+        eA[kt][0] = v;
+        eA[kt][1] = v;
+        kb_next[kt] = load_bias(t_begin + 1 < nt ? t_begin + 1 : t_begin, kt);
+      }
+    }
+  }
   if (t_begin < t_end) issue_k(t_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -395,6 +415,12 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
     const unsigned v_ad = ring_lds + (it & 1) * VTILE_B + v_off;            // V_t
     float t0, t1, t2, t3, mx[2], m_new[2], alpha_n[2];
     i32x4v ph[2], pl[2];
+    const f32x4 c0[2] = {BIAS ? kb_next[0] : zero4, BIAS ? kb_next[1] : zero4};  // S_next accumulators start from the key bias of tile t + 1
+    if constexpr (BIAS) {  // prefetch tile t + 2's (consumed after the next barrier)
+      const int tb = t + 2 < nt ? t + 2 : nt - 1;
+      kb_next[0] = load_bias(tb, 0);
+      kb_next[1] = load_bias(tb, 1);
+    }
     if constexpr (TERMS == 1) pl[0] = pl[1] = i32x4v{0, 0, 0, 0};
     if constexpr (TERMS == 3) {
 #include "attn_split_body_t3.inc"
@@ -511,7 +537,7 @@ extern "C" int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, i
 }
 
 extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
-                                  long long qkv_bs, int ldo, long long o_bs, int flags, void* stream) {
+                                  long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* stream) {
   LDC_CHECK_PTR(Q);
   LDC_CHECK_PTR(K);
   LDC_CHECK_PTR(V);
@@ -522,6 +548,7 @@ extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V
   LDC_CHECK_ALIGN16(V);
   LDC_CHECK_ALIGN16(O);
   if ((ld_qkv & 3) || (qkv_bs & 3) || (ldo & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
+  if (key_bias) LDC_CHECK_ALIGN16(key_bias);
   const int out_split = flags & LDC_ATTN_OUT_SPLIT;
   const bool one_term = (flags & LDC_ATTN_BF16_1TERM) != 0;
   if (out_split && ((ldo & 7) || (o_bs & 7) || (reinterpret_cast<unsigned long long>(O) & 31ull))) return LDC_ERR_ALIGN;
@@ -539,22 +566,30 @@ extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V
   p.nt = ldc_cdiv(S, KT);
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
-  static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);
-    return true;
-  }();
-  (void)attr_set;
+  p.kbias = key_bias;
   const long long nwg = static_cast<long long>(p.nq) * H * B;
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  if (one_term) {
-    if (nwg <= 256) hipLaunchKernelGGL((attn_fwd_split_kernel<2, 1>), grid, dim3(512), 2 * GROUP_LDS, st, p);
-    else hipLaunchKernelGGL((attn_fwd_split_kernel<1, 1>), grid, dim3(256), GROUP_LDS, st, p);
-  } else {
-    if (nwg <= 256) hipLaunchKernelGGL((attn_fwd_split_kernel<2, 3>), grid, dim3(512), 2 * GROUP_LDS, st, p);
-    else hipLaunchKernelGGL((attn_fwd_split_kernel<1, 3>), grid, dim3(256), GROUP_LDS, st, p);
+  const int variant = (nwg <= 256 ? 4 : 0) | (one_term ? 2 : 0) | (key_bias ? 1 : 0);
+#define LDC_ATTN_LAUNCH(NG, T, BI)                                                                                              \
+  {                                                                                                                             \
+    static const bool attr_set = [] {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<NG, T, BI>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, NG * GROUP_LDS);                                    \
+      return true;                                                                                                              \
+    }();                                                                                                                        \
+    (void)attr_set;                                                                                                             \
+    hipLaunchKernelGGL((attn_fwd_split_kernel<NG, T, BI>), grid, dim3(256 * NG), NG * GROUP_LDS, st, p);                        \
   }
+  switch (variant) {
+    case 0: LDC_ATTN_LAUNCH(1, 3, false) break;
+    case 1: LDC_ATTN_LAUNCH(1, 3, true) break;
+    case 2: LDC_ATTN_LAUNCH(1, 1, false) break;
+    case 3: LDC_ATTN_LAUNCH(1, 1, true) break;
+    case 4: LDC_ATTN_LAUNCH(2, 3, false) break;
+    case 5: LDC_ATTN_LAUNCH(2, 3, true) break;
+    case 6: LDC_ATTN_LAUNCH(2, 1, false) break;
+    default: LDC_ATTN_LAUNCH(2, 1, true) break;
+  }
+#undef LDC_ATTN_LAUNCH
   return ldc_launch_status();
 }

@@ -71,13 +71,13 @@ def _load():
         "ldc_sizeof_qkv_epilogue": (I, []),
         "ldc_gemm_grouped_bf16x3_qkv": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
         "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
-        "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
+        "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, P, I, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_linear_small_grouped": (I, [POINTER(LinearSmallProblem), I, P]),
         "ldc_linear_small_mod": (I, [P, I, P, P, P, I, P, I, P, I, I, I, I, I, P]),
         "ldc_gate_residual_layernorm": (I, [P, P, P, P, I, I, I, I, L, I, L, I, I, L, P, P, F, I, P]),
-        "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P]),
+        "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
@@ -246,10 +246,12 @@ def linear_small_grouped(problems):
     _check(lib.ldc_linear_small_grouped(arr, n, _stream()), "ldc_linear_small_grouped")
 
 
-def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs):
-    """exact-fp32 attention on fp32 q / k / v views (ldc_attn_fwd)"""
-    _dev(Q, K, V, O)
-    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _stream()), "ldc_attn_fwd")
+def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, key_bias=None):
+    """exact-fp32 attention on fp32 q / k / v views (ldc_attn_fwd); key_bias: [S] additive score bias per key (or None)"""
+    _dev(Q, K, V, O, key_bias)
+    if key_bias is not None and key_bias.numel() < S:
+        raise ValueError("key_bias must hold one value per key")
+    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _stream()), "ldc_attn_fwd")
 
 
 _score_ws = {}
@@ -321,11 +323,22 @@ def attn_qkv_prepare_split(Q, K, V, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=
                                           _p(seg1[0]), _p(seg1[1]), _p(seg1[2]), _p(seg1[3]), eps, _stream()), "ldc_attn_qkv_prepare_split")
 
 
-def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=False, one_term=False):
-    """attention on row-major split-bf16 operand rows (ldc_attn_fwd_split)"""
-    _dev(Q, K, V, O)
+def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=False, one_term=False, key_bias=None):
+    """attention on row-major split-bf16 operand rows (ldc_attn_fwd_split); key_bias: additive score bias per key, padded to a multiple
+    of 32 entries (`pad_key_bias`), or None"""
+    _dev(Q, K, V, O, key_bias)
+    if key_bias is not None and key_bias.numel() < 32 * ((S + 31) // 32):
+        raise ValueError("key_bias must be padded to a multiple of 32 keys (hip.pad_key_bias)")
     flags = (ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
-    _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, flags, _stream()), "ldc_attn_fwd_split")
+    _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), flags, _stream()), "ldc_attn_fwd_split")
+
+
+def pad_key_bias(bias):
+    """[S] -> [32 * ceil(S / 32)] (zero-padded, contiguous): the form `attn_fwd_split` reads 16 bytes at a time"""
+    S = bias.numel()
+    out = torch.zeros(32 * ((S + 31) // 32), device=bias.device, dtype=torch.float32)
+    out[:S] = bias.reshape(-1)
+    return out
 
 
 def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False, one_term=False):

@@ -224,8 +224,8 @@ class LaDCastTransformer3DModel(ModelMixin):
     ) -> None:
         super().__init__()
         self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
-        if nope or scale_attn_by_lat:
-            raise NotImplementedError("nope / scale_attn_by_lat are not used by any shipped config")
+        if nope:
+            raise NotImplementedError("nope is not used by any shipped config")
         if patch_size != 1 or patch_size_t != 1:
             raise NotImplementedError("shipped configs use patch size 1 (configs/ladcast_375M.yaml:11-12)")
         if attention_head_dim != 128 or qk_norm != "rms_norm":
@@ -255,6 +255,15 @@ class LaDCastTransformer3DModel(ModelMixin):
         self.norm_out = _AdaLinearP(d, 2 * d)
         self.proj_out = nn.Linear(d, out_channels)
         self.requires_grad_(False)
+        # scale_attn_by_lat (models/LaDCast_3D_model.py:682-693): normalised cos-latitude weights of the (hard-wired) 15 x 30 latent grid,
+        # added to the attention scores as a (1, 1, 1, keys) float mask; a plain attribute (not a parameter / buffer) as in the reference
+        self.scale_attn_by_lat = bool(scale_attn_by_lat)
+        self.attn_lat_weights = None
+        if scale_attn_by_lat:
+            w = np.cos(np.deg2rad(np.linspace(-83.25, 84.75, 15)))
+            w = w / w.mean()  # evaluate/utils.py:40-48
+            self.attn_lat_weights = torch.from_numpy(w / w.sum()).float().repeat_interleave(30).view(1, 1, 1, -1)
+        self._kbias = {}
         self._plan = None
         self._plan_gen = 0  # bumped on every plan rebuild (plan_identity): graphs captured outside the model key on it
         self._ws = {}
@@ -274,6 +283,23 @@ class LaDCastTransformer3DModel(ModelMixin):
         if not flag:
             self._graphs = {}
         return self
+
+    def set_attn_lat_weights(self, weights: torch.Tensor):
+        """replace `attn_lat_weights` ((1, 1, 1, h * w) or (h * w,)) and drop the device copies / graphs made from the old ones"""
+        self.attn_lat_weights = weights.detach().float().reshape(1, 1, 1, -1).cpu()
+        self._kbias = {}
+        self._graphs = {}
+        return self
+
+    def _key_bias(self, frames, dev):
+        """the per-key additive score bias of an attention call over `frames` latent frames of keys (:873-880: the weights tiled per
+        frame), padded for the split kernels; None when scale_attn_by_lat is off"""
+        if not self.scale_attn_by_lat:
+            return None
+        key = (frames, str(dev))
+        if key not in self._kbias:
+            self._kbias[key] = hip.pad_key_bias(self.attn_lat_weights.reshape(-1).repeat(frames).to(dev))
+        return self._kbias[key]
 
     def set_gemm_precision(self, mode: str):
         """"fp32": exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  "bf16x3": split-bf16 error-compensated
@@ -326,6 +352,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._te_cache = None
         self._te_buf = {}
         self._graphs = {}
+        self._kbias = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -465,7 +492,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt, mod=te,
                          mod_rows=1 if te is None else te.shape[0])
 
-    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False):
+    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False, key_bias=None):
         """Attention over token rows [row0, row0 + Sx + Sc) of the fused qkv buffer -> out.
         fp32 mode: q/k RMSNorm + RoPE per segment in place (seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the
         next Sc rows seg_c; ldc_qk_rmsnorm_rope) + ldc_attn_fwd.  Split-bf16 / bf16 modes: the QKV projection's epilogue has already
@@ -479,10 +506,12 @@ class LaDCastTransformer3DModel(ModelMixin):
         v = qkv[:, row0:, 2 * D : 3 * D]
         if self.gemm_precision in ("bf16x3", "bf16") and not _PACKED_ATTENTION:
             hip.attn_fwd_split(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, out_split=out_split,
-                               one_term=self.gemm_precision == "bf16")
+                               one_term=self.gemm_precision == "bf16", key_bias=key_bias)
             return
         segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
         if self.gemm_precision in ("bf16x3", "bf16"):  # measurement aid (LDC_ATTN_PATH=packed): the second-generation pack pass + attention
+            if key_bias is not None:
+                raise NotImplementedError("the packed attention path has no key bias")
             if getattr(ws, "apack", None) is None:
                 ws.apack = torch.empty(hip.attn_packed_bytes(B, full, H) // 4, device=qkv.device, dtype=torch.float32)
             sg = [(n.weight, m.weight, c, s_) for (_, (n, m, c, s_)) in segs] + [(None, None, None, None)]
@@ -494,7 +523,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
                                 wq=nq.weight, wk=nk.weight, eps=nq.eps, cos=c, sin=s_)
             r0 += rows
-        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs)
+        hip.attn_fwd(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, key_bias=key_bias)
 
     def _qkv_epi(self, norm_q, norm_k, rope):
         """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + compact rotary table (None = no RoPE)"""
@@ -669,6 +698,14 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
             hip.gemm(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias)
 
+        # scale_attn_by_lat: per-key score bias, the same weights tiled over the frames of the keys (:873-880); key order inside a frame is
+        # the token order, and the mask does not depend on the frame, so pred-then-cond (ours) and the reference's tiling agree
+        kb_all = kb_cond = None
+        if self.scale_attn_by_lat:
+            if Hh * Ww != self.attn_lat_weights.numel():
+                raise ValueError("scale_attn_by_lat is hard-wired to the 15 x 30 latent grid (models/LaDCast_3D_model.py:684-692)")
+            kb_all, kb_cond = self._key_bias(R + T_in, dev), self._key_bias(T_in, dev)
+
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
         if split:  # the pooling pass also leaves the embedded context in the split format for proj_in (nh_c is free until the first norm)
@@ -685,7 +722,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)
             run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
                     [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
-            self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None)
+            self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
             hip.gate_residual_layernorm(h_c, ws.att[:, Nx:], ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
@@ -718,7 +755,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
             ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
             self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split)
+                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split, key_bias=kb_all)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
             run([
                 G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
@@ -750,7 +787,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
             ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
             self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split)
+                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split, key_bias=kb_all)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD, flags=AS)
 

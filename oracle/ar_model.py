@@ -297,8 +297,9 @@ CONFIG_1_6B = dict(CONFIG_375M, num_attention_heads=16, num_layers=5, num_single
 
 
 class LaDCastTransformer3DModel(nn.Module):
-    """models/LaDCast_3D_model.py:569-1071 (``scale_attn_by_lat`` / ``nope`` stay at their
-    default False: the shipped configs never set them)."""
+    """models/LaDCast_3D_model.py:569-1071 (``nope`` stays at its default False: no shipped config sets it;
+    ``scale_attn_by_lat`` - also off in both shipped configs - is restated: a (1, 1, 1, keys) float mask of normalised
+    cos-latitude weights ADDED to the attention scores of every block, :682-693,873-882,950)."""
 
     def __init__(
         self,
@@ -326,8 +327,8 @@ class LaDCastTransformer3DModel(nn.Module):
         scale_attn_by_lat: bool = False,
     ):
         super().__init__()
-        if nope or scale_attn_by_lat:
-            raise NotImplementedError("nope / scale_attn_by_lat are not on the shipped-config path")
+        if nope:
+            raise NotImplementedError("nope is not on the shipped-config path")
         if patch_size != 1 or patch_size_t != 1:
             raise NotImplementedError("shipped configs use patch size 1")
         self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
@@ -358,6 +359,12 @@ class LaDCastTransformer3DModel(nn.Module):
         )
         self.norm_out = AdaLayerNormContinuous(d, d, eps=1e-7)
         self.proj_out = nn.Linear(d, patch_size_t * patch_size * patch_size * out_channels)
+        self.scale_attn_by_lat = scale_attn_by_lat
+        if scale_attn_by_lat:  # :682-693 (the 15 x 30 latent grid is hard-wired in the reference)
+            w = np.cos(np.deg2rad(np.linspace(-83.25, 84.75, 15)))
+            w = w / w.mean()  # evaluate/utils.py:40-48
+            w = torch.from_numpy(w / w.sum()).float()
+            self.attn_lat_weights = w.repeat_interleave(30).view(1, 1, 1, -1)
 
     @property
     def dtype(self):
@@ -403,7 +410,11 @@ class LaDCastTransformer3DModel(nn.Module):
 
         x = self.x_embedder(hidden_states)
         ctx = self.context_embedder(conditioning_tensors)
-        ctx = self.context_refiner(ctx, timestep, image_rotary_emb=cond_rope, attention_mask=None)
+        pred_mask = cond_mask = None
+        if self.scale_attn_by_lat:  # :873-880
+            pred_mask = self.attn_lat_weights.repeat(1, 1, 1, t_in + r).to(hidden_states.device)
+            cond_mask = self.attn_lat_weights.repeat(1, 1, 1, t_in).to(hidden_states.device)
+        ctx = self.context_refiner(ctx, timestep, image_rotary_emb=cond_rope, attention_mask=cond_mask)
 
         temb = self.time_text_embed(timestep, ctx.mean(dim=1))
         if time_elapsed is not None and self.time_elapsed_embed is not None:
@@ -413,9 +424,9 @@ class LaDCastTransformer3DModel(nn.Module):
             temb = temb * (1 + scale) + shift
 
         for blk in self.transformer_blocks:
-            x, ctx = blk(x, ctx, temb, None, image_rope, cond_rope)
+            x, ctx = blk(x, ctx, temb, pred_mask, image_rope, cond_rope)
         for blk in self.single_transformer_blocks:
-            x, ctx = blk(x, ctx, temb, None, image_rope, cond_rope)
+            x, ctx = blk(x, ctx, temb, pred_mask, image_rope, cond_rope)
 
         x = self.proj_out(self.norm_out(x, temb))
         x = x.reshape(b, r, h, w, -1, 1, 1, 1).permute(0, 4, 1, 5, 2, 6, 3, 7)

@@ -477,6 +477,20 @@ def ar_forward_fixtures():
             y = model(x, t, known, time_elapsed=te).sample.double().flatten()
             out[name] = y[::7].float().numpy()  # every 7th value + the norm: small fixture, still sensitive to any wiring change
             out[name + "_norm"] = np.array(y.norm().item())
+        # scale_attn_by_lat = True (off in both shipped configs): the reference forward builds a (1, 1, 1, keys) float mask from
+        # attn_lat_weights (:873-880) and hands it to every block; the constructor lines that make attn_lat_weights (:684-693) are
+        # re-run here with the reference's own weight function (evaluate/utils.py:40-48).  Amplified 200x in a second case so that the
+        # mask (values ~1/450) moves the output by more than rounding.
+        lw = _ref_functions("/root/reference/ladcast/evaluate/utils.py", ["get_normalized_lat_weights_based_on_cos"], dict(typing_ns))
+        tmp = lw["get_normalized_lat_weights_based_on_cos"](np.linspace(-83.25, 84.75, 15))
+        tmp = torch.from_numpy(tmp / tmp.sum()).float().repeat_interleave(30)
+        object.__setattr__(model, "scale_attn_by_lat", True)
+        for name, amp in (("lat", 1.0), ("lat200", 200.0)):
+            object.__setattr__(model, "attn_lat_weights", (amp * tmp).view(1, 1, 1, -1))
+            x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+            y = model(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
+            out[name] = y[::7].float().numpy()
+            out[name + "_norm"] = np.array(y.norm().item())
     np.savez_compressed(os.path.join(HERE, "ar_forward_ref.npz"), **out)
 
 

@@ -836,3 +836,31 @@ def test_gate_residual_layernorm_is_bitwise(hip, split):
     assert rel(h1[:, :rows], want_h) < 1e-6
     if not split:
         assert rel(o1, F.layer_norm(want_h, (D,), w.cpu().double(), b.cpu().double(), 1e-7)) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 97, 2), (1, 4500, 12), (1, 1, 1)])
+def test_attention_key_bias(hip, B, S, H):
+    """per-key additive score bias (`scale_attn_by_lat`: a (1, 1, 1, keys) float attention mask) in the fp32 kernel and in the split
+    kernel (both wave-group layouts, both arithmetic modes), against sdpa(attn_mask=bias)"""
+    D = H * 128
+    qkv = rnd(B, S, 3 * D, seed=11)
+    qkv[..., :D] *= 2.0
+    bias = rnd(S, seed=12) * 3.0  # large enough to reorder the softmax
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    want = F.scaled_dot_product_attention(q, k, v, attn_mask=bias.double().view(1, 1, 1, S)).transpose(1, 2).reshape(B, S, D)
+    plain = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+    assert S == 1 or rel(plain, want) > 1e-2  # the bias matters
+    d_qkv = dev(qkv)
+    out = torch.empty(B, S, D, device="cuda")
+    kw = dict(B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D)
+    hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, key_bias=dev(bias), **kw)
+    assert rel(out, want) < 2e-6
+    _prep(hip, d_qkv, B, S, H, D, split_row=S)
+    kb = hip.pad_key_bias(dev(bias))
+    assert kb.numel() % 32 == 0 and torch.equal(kb[:S].cpu(), bias)
+    for one_term, tol in ((False, 2e-5), (True, 1e-2)):
+        out.fill_(float("nan"))
+        hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, key_bias=kb, one_term=one_term, **kw)
+        assert rel(out, want) < tol, one_term
+    with pytest.raises(ValueError):
+        hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, key_bias=dev(bias)[: max(S - 1, 0)], **kw)

@@ -70,6 +70,34 @@ def test_product_transformer_reproduces_the_reference_forward_code(golden_dir):
             assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < tol
 
 
+def test_product_scale_attn_by_lat_reproduces_the_reference_forward_code(golden_dir):
+    """`scale_attn_by_lat=True`: the per-key score bias of every attention call (refiner: cond keys; blocks: pred + cond keys) against the
+    fixtures made by the reference's forward code, with the reference's weights and with them amplified 200x; all three arithmetic modes."""
+    from ladcast_amd.models import LaDCastTransformer3DModel
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    cfg = dict(tiny_ar_config(), scale_attn_by_lat=True)
+    m = LaDCastTransformer3DModel.from_config(cfg)
+    m.load_state_dict(make_ar(tiny_ar_config()).state_dict(), strict=True)
+    m = m.cuda().eval()
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+    base = m.attn_lat_weights.clone()
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 5e-3)):
+        m.set_gemm_precision(prec)
+        for name, amp in (("lat", 1.0), ("lat200", 200.0)):
+            m.set_attn_lat_weights(amp * base)
+            y = m(x, torch.tensor([0.3]).cuda(), synth_known(2).cuda(), time_elapsed=torch.tensor([2018010100]).cuda()).sample.double().flatten().cpu()
+            want = torch.from_numpy(z[name]).double()
+            assert ((y[::7] - want).norm() / want.norm()).item() < tol, (prec, name)
+    # hipGraph replay gives the same bits
+    m.set_gemm_precision("bf16x3")
+    y0 = m(x, torch.tensor([0.3]).cuda(), synth_known(2).cuda(), time_elapsed=torch.tensor([2018010100]).cuda()).sample
+    m.enable_hip_graph(True)
+    y1 = m(x, torch.tensor([0.3]).cuda(), synth_known(2).cuda(), time_elapsed=torch.tensor([2018010100]).cuda()).sample
+    assert torch.equal(y0, y1)
+
+
 def test_product_dcae_reproduces_the_reference_forward_code(golden_dir):
     """the same for the autoencoder: tests/golden/dcae_forward_ref.npz (reference forward code of every DCAE class incl. AutoencoderDC.encode /
     decode) vs the HIP autoencoder with the same seeded weights"""

@@ -115,6 +115,29 @@ def test_transformer_forward_equals_the_reference_forward_code(golden_dir):
             assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < 1e-6
 
 
+def test_scale_attn_by_lat_equals_the_reference_forward_code(golden_dir):
+    """`scale_attn_by_lat=True` (off in both shipped configs): the reference's forward adds a (1, 1, 1, keys) float mask of normalised
+    cos-latitude weights to the attention scores of the refiner and of every block (models/LaDCast_3D_model.py:682-693,873-882,950).  Fixtures
+    `lat` (the reference's weights) and `lat200` (the same weights x 200, so that the mask moves the output far beyond rounding) were made
+    by the reference's forward code with the reference's own weight function (make_golden.py::ar_forward_fixtures)."""
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    assert np.abs(z["lat200"] - z["lat"]).max() > 1e-3  # the amplified mask really changes the output
+    m = make_ar(dict(tiny_ar_config(), scale_attn_by_lat=True))
+    plain = make_ar(tiny_ar_config())
+    assert [k for k in m.state_dict()] == [k for k in plain.state_dict()]  # no parameters: attn_lat_weights is a plain attribute
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+    base = m.attn_lat_weights.clone()
+    with torch.no_grad():
+        for name, amp in (("lat", 1.0), ("lat200", 200.0)):
+            m.attn_lat_weights = amp * base
+            y = m(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
+            want = torch.from_numpy(z[name]).double()
+            assert ((y[::7] - want).norm() / want.norm()).item() < 1e-6
+            assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < 1e-6
+
+
 def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
     """tests/golden/dcae_forward_ref.npz: the tiny autoencoder's latent and reconstruction when the forward of every DCAE class the reference
     defines (ResBlock, GLUMBConv, EfficientViTBlock, the linear-attention container + processor, DCDown/UpBlock2d, Encoder, Decoder) is the

@@ -59,7 +59,7 @@ class Body:
     def mm_qk(self, kind, slot, kt, qt, s, first):
         a = {"lh": f"kl{slot}", "hl": f"kh{slot}", "hh": f"kh{slot}"}[kind]
         b = {"lh": f"qh[{qt}][{s}]", "hl": f"ql[{qt}][{s}]", "hh": f"qh[{qt}][{s}]"}[kind]
-        c = "zero4" if first else f"sn[{kt}][{qt}]"
+        c = f"c0[{kt}]" if first else f"sn[{kt}][{qt}]"  # c0: zero, or the additive key bias of the tile (scale_attn_by_lat)
         self.e(f"sn[{kt}][{qt}] = LDC_MFMA(LDC_BF(({a})), {b}, {c});")
         self.sb()
 
