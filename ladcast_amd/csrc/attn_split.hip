@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
     // unconditional (no branch in the MFMA stream): past the group's last tile the tile index is clamped, and what then lands in the
     // two stages is only ever read by iterations that do not exist (V) or whose scores are discarded (K, S_next of the last iteration)
     const bool vq = t + 1 < t_end;
-    const float lazy_thr = vq ? 8.0f : 3.0e38f;  // S_next is a real tile? (the last iteration computes it from a stale stage: never move the max)
+    const bool live_next = vq;  // S_next is a real tile (the last iteration computes it from a stale stage: NaN / inf possible)
     const bool mask_next = (t + 1 == nt - 1);  // ... and may hold keys past S
     const unsigned char* const ksrc = k_src(t + 2 < t_end ? t + 2 : t_end - 1);
     const unsigned char* const vsrc0 = v_src(vq ? t + 1 : t_end - 1, 0);

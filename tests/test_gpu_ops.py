@@ -864,3 +864,27 @@ def test_attention_key_bias(hip, B, S, H):
         assert rel(out, want) < tol, one_term
     with pytest.raises(ValueError):
         hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], out, key_bias=dev(bias)[: max(S - 1, 0)], **kw)
+
+
+def test_attention_split_ignores_stale_lds(hip):
+    """The last iteration of a key-range group computes S_next from a ring stage nothing was loaded into: whatever an earlier kernel left in
+    LDS - NaN and inf bit patterns included - must not reach the running max.  (Found in round 2: an inf there passed the lazy-max
+    threshold; random rows came out NaN whenever a group's first tile was also its last.)  Poison LDS with a kernel fed NaN / inf, then run
+    the shapes whose groups have a single tile."""
+    for poison in (float("nan"), float("inf"), -float("inf")):
+        x = torch.full((1, 512, 384), poison, device="cuda")
+        o2 = torch.empty(1, 512, 128, device="cuda")
+        hip.attn_fwd(x[:, :, :128], x[:, :, 128:256], x[:, :, 256:], o2, B=1, S=512, H=1, ld_qkv=384, qkv_bs=512 * 384, ldo=128, o_bs=512 * 128)
+        for (B, S, H) in ((1, 33, 1), (1, 1, 1), (3, 70, 2), (1, 40, 3)):
+            D = H * 128
+            qkv = rnd(B, S, 3 * D, seed=11)
+            d = dev(qkv)
+            _prep(hip, d, B, S, H, D, split_row=S)
+            out = torch.full((B, S, D), float("nan"), device="cuda")
+            for one_term in (False, True):
+                hip.attn_fwd_split(d[:, :, :D], d[:, :, D : 2 * D], d[:, :, 2 * D :], out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D,
+                                   one_term=one_term)
+                q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+                want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
+                assert torch.isfinite(out).all(), (poison, B, S, H, one_term)
+                assert rel(out, want) < (1e-2 if one_term else 2e-5)

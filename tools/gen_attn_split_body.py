@@ -98,9 +98,9 @@ def generate(terms):
         piecesB.append(f"mx[{qt}] = xor32_max(mx[{qt}]); asm volatile(\"\" : \"+v\"(mx[{qt}]));")
     for qt in range(2):
         # lazy running max (scores are in log2 units): it only moves when exceeded by more than 2^8, so the rescale of O is rare;
-        # the last iteration's S_next is computed from a stale stage and must not move it (lazy_thr = huge there); one compare + one
-        # select per query, no control flow inside the MFMA stream
-        piecesB.append(f"m_new[{qt}] = (mx[{qt}] - m_run[{qt}] > lazy_thr) ? mx[{qt}] : m_run[{qt}]; "
+        # the last iteration's S_next is computed from a stale stage - any bit pattern, NaN and inf included - and must not move it:
+        # the compare is ANDed (bitwise: no short-circuit branch) with the wave-uniform live_next; one compare + one select per query
+        piecesB.append(f"m_new[{qt}] = ((mx[{qt}] - m_run[{qt}] > 8.0f) & live_next) ? mx[{qt}] : m_run[{qt}]; "
                        f"alpha_n[{qt}] = __builtin_amdgcn_exp2f(m_run[{qt}] - m_new[{qt}]); m_run[{qt}] = m_new[{qt}]; "
                        f"asm volatile(\"\" : \"+v\"(m_new[{qt}]), \"+v\"(alpha_n[{qt}]));")
     for kt in range(2):
