@@ -74,12 +74,19 @@ typedef struct ldc_gemm_desc {
  *   LDC_GEMM_C_SPLIT  C is written in that format (after bias / activation / gate / residual). */
 #define LDC_GEMM_A_SPLIT 1
 #define LDC_GEMM_C_SPLIT 2
-/*   LDC_GEMM_BF16_1TERM  single-term bf16 contraction Ah.Wh (fp32 accumulate): the "bf16" mixed-precision mode
+/*   LDC_GEMM_BF16_1TERM  single-term bf16 contraction bf16(A).bf16(W) (fp32 accumulate): the "bf16" mixed-precision mode
  *                     (BASELINE configs[4] "fp16/bf16 mixed"; what torch.autocast(bfloat16) does to an nn.Linear's
  *                     operands, the reference's fp32 islands - models/LaDCast_3D_model.py:953, models/DCAE.py:162,180 -
- *                     never reach a GEMM here).  Needs LDC_GEMM_A_SPLIT; all problems of one call must agree.
- *                     ~2e-3 rel-L2 per model forward instead of ~4e-6. */
+ *                     never reach a GEMM here).  In this mode the operands are PLAIN bf16 ROWS (LDC_FMT_BF16): a row of
+ *                     K values occupies the first 2 K bytes of the 4 K bytes its fp32 row would (same pointers, same
+ *                     strides, half the bytes moved); LDC_GEMM_A_SPLIT (required) then means "A is in that format" and
+ *                     LDC_GEMM_C_SPLIT "write C in that format"; W comes from ldc_pack_weight_bf16 ([N][K] bf16).
+ *                     K % 64 == 0; all problems of one call must agree.  ~1.5e-3 rel-L2 per model forward instead of ~6e-6. */
 #define LDC_GEMM_BF16_1TERM 4
+/* activation formats of the producers' `out_split` / `x_fmt` arguments: fp32, split-bf16 groups (LDC_GEMM_A_SPLIT), plain bf16 rows */
+#define LDC_FMT_F32 0
+#define LDC_FMT_SPLIT 1
+#define LDC_FMT_BF16 2
 int ldc_sizeof_gemm_desc(void);
 int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const float* gate,
                       const float* R, float* C, const ldc_gemm_desc* d, void* stream);
@@ -117,6 +124,8 @@ int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, l
 int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                             void* stream);
 int ldc_pack_weight_bf16x2(const float* W, void* out, int N, int K, int ldw, void* stream);
+/* fp32 [N][K] (row stride ldw) -> plain bf16 [N][K] (2 N K bytes), the W operand of the LDC_GEMM_BF16_1TERM mode */
+int ldc_pack_weight_bf16(const float* W, void* out, int N, int K, int ldw, void* stream);
 
 /* Small-M linear (M = rows <= 64): y[r] = act_out(W . act_in(x[r % x_rows]) + bias)
  *                                           + add[r % add_rows]
@@ -187,6 +196,7 @@ int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H
  * the attention of the "bf16" mixed-precision mode (see LDC_GEMM_BF16_1TERM). */
 #define LDC_ATTN_OUT_SPLIT 1
 #define LDC_ATTN_BF16_1TERM 2
+#define LDC_ATTN_OUT_BF16 4 /* ldc_attn_fwd_split only: O as plain bf16 rows (LDC_FMT_BF16) */
 
 /* Split-bf16 attention on ROW-MAJOR operand rows (third generation; no packed copy of the operands):
  *   Q, K, V are views into a fused [B][S][3][H][128]-float buffer (row stride ld_qkv, batch stride qkv_bs, in floats) whose
@@ -260,7 +270,7 @@ int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, int ldx, lon
  * x_split (row stride lds, batch stride s_bs, in floats; D % 8 == 0), so that the Linear consuming x
  * (context_refiner.proj_in, models/LaDCast_3D_model.py:362-380) takes the pre-split GEMM kernel. */
 int ldc_mean_rows_split(const float* x, float* y, float* x_split, int B, int rows, int D, int ldx,
-                        long long x_bs, int lds, long long s_bs, void* stream);
+                        long long x_bs, int lds, long long s_bs, int fmt /* LDC_FMT_SPLIT | LDC_FMT_BF16 */, void* stream);
 
 /* out[b][r][c] = resid[b][r][c] + gate[b][c] * y[b][r][c]  (refiner gated residual on the
  * projection-less attention output, models/LaDCast_3D_model.py:296-297) */

@@ -488,7 +488,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
     for (int dt = 0; dt < 8; ++dt) {
       const int n = 16 * dt + 4 * g4;
       float4 v = make_float4(o[dt][qt][0] * inv, o[dt][qt][1] * inv, o[dt][qt][2] * inv, o[dt][qt][3] * inv);
-      if (p.out_split) {
+      if (p.out_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
+        unsigned char* rowb = reinterpret_cast<unsigned char*>(orow - head * HD);  // bf16 columns are 2 bytes: offset from the ROW start
+        *reinterpret_cast<uint2*>(rowb + 2 * (head * HD + n)) = make_uint2(pack_pair(v.x, v.y), pack_pair(v.z, v.w));
+      } else if (p.out_split) {
         // LDC_GEMM_A_SPLIT format: columns 8c..8c+7 live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16
         // further the other half: v_permlane16_swap gives the even lane group both hi halves, the odd one both lo halves
         float r0, r1, r2, r3;
@@ -549,7 +552,7 @@ extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V
   LDC_CHECK_ALIGN16(O);
   if ((ld_qkv & 3) || (qkv_bs & 3) || (ldo & 3) || (o_bs & 3)) return LDC_ERR_ALIGN;
   if (key_bias) LDC_CHECK_ALIGN16(key_bias);
-  const int out_split = flags & LDC_ATTN_OUT_SPLIT;
+  const int out_split = (flags & LDC_ATTN_OUT_BF16) ? LDC_FMT_BF16 : (flags & LDC_ATTN_OUT_SPLIT) ? LDC_FMT_SPLIT : 0;
   const bool one_term = (flags & LDC_ATTN_BF16_1TERM) != 0;
   if (out_split && ((ldo & 7) || (o_bs & 7) || (reinterpret_cast<unsigned long long>(O) & 31ull))) return LDC_ERR_ALIGN;
   if (static_cast<long long>(ldc_cdiv(S, QB)) * H * B > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
@@ -562,7 +565,7 @@ extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V
   p.S = S; p.H = H; p.ldo = ldo; p.o_bs = o_bs;
   p.ldb = static_cast<long long>(ld_qkv) * 4;
   p.bsb = qkv_bs * 4;
-  p.out_split = out_split ? 1 : 0;
+  p.out_split = out_split;
   p.nt = ldc_cdiv(S, KT);
   p.nq = ldc_cdiv(S, QB);
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);

@@ -232,7 +232,10 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
           v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
-        if (P.c_split) {
+        if (P.c_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
+          const uint2 h2 = make_uint2(ldc_pack_pair(v.x, v.y), ldc_pack_pair(v.z, v.w));
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(crow) + 2 * n) = h2;
+        } else if (P.c_split) {
           // columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16 further
           // (k-group ^ 1) the other half of the same row: v_permlane16_swap hands the even k-group both hi halves and the
           // odd one both lo halves, so each lane stores 16 contiguous bytes instead of two 8-byte pieces
@@ -275,8 +278,11 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 #define LDC_STAMP_CLK(i)
 #endif
 
-// TERMS = 3: split-bf16 contraction Ah.Wh + Ah.Wl + Al.Wh; TERMS = 1 (LDC_GEMM_BF16_1TERM, the "bf16" mixed-precision mode):
-// Ah.Wh only - the same operand images, the lo chunks are staged but never read (a third of the MFMAs, half the fragment reads)
+// TERMS = 3: split-bf16 contraction Ah.Wh + Ah.Wl + Al.Wh over operand rows of [hi x8 | lo x8] groups (32 k per 128-byte k-step).
+// TERMS = 1 (LDC_GEMM_BF16_1TERM, the "bf16" mixed-precision mode): the operands are PLAIN bf16 rows, so a 128-byte k-step holds
+// 64 k; the same DMAs, LDS image and fragment reads - the chunk the split mode calls "hi" of k-group g is k 16 g .. 16 g + 7 here,
+// its "lo" chunk k 16 g + 8 .. 16 g + 15 (any assignment of k to the two MFMA k-blocks works as long as A and W agree) - and two
+// MFMAs per column tile, (first chunks) + (second chunks), instead of three: two thirds of the MFMAs for twice the k.
 template <int BM, int TERMS>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const int M = P.d.M, N = P.d.N, K = P.d.K;
     const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
     const int lda = P.d.lda;
-    const long long w_row_bytes = static_cast<long long>(K) * 4;
+    const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
 
     // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
     // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
@@ -390,26 +396,21 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 
     i32x4v wh0, wl0, wh1, wl1, wh2, wl2, wh3, wl3;           // W fragment window: 4 column tiles
     i32x4v ah0[RT], al0[RT], ah1[RT], al1[RT];               // A fragments of the current / next k-step
-    if constexpr (TERMS == 1) {  // the lo registers are never loaded: give the asm constraints below a defined value
-      wl0 = wl1 = wl2 = wl3 = i32x4v{0, 0, 0, 0};
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) al0[rt] = al1[rt] = i32x4v{0, 0, 0, 0};
-    }
 
 #define LDC_SB __builtin_amdgcn_sched_barrier(0)
     // SBH / SBL: lane base (hi / lo chunk) + stage offset; the tile offset is an immediate
 #define LDC_RD_W(WH, WL, SBH, SBL, CT)                                           \
   {                                                                              \
     LDC_DS_READ(WH, SBH, (CT) * (16 * ROW_B));                                   \
-    if constexpr (TERMS == 3) LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));         \
+    LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));                                   \
   }
 #define LDC_RD_A(AH, AL, SBH, SBL)                                               \
   {                                                                              \
     LDC_DS_READ(AH[0], SBH, 0);                                                  \
-    if constexpr (TERMS == 3) LDC_DS_READ(AL[0], SBL, 0);                        \
+    LDC_DS_READ(AL[0], SBL, 0);                                                  \
     if constexpr (RT == 2) {                                                     \
       LDC_DS_READ(AH[RT - 1], SBH, 16 * ROW_B);                                  \
-      if constexpr (TERMS == 3) LDC_DS_READ(AL[RT - 1], SBL, 16 * ROW_B);        \
+      LDC_DS_READ(AL[RT - 1], SBL, 16 * ROW_B);                                  \
     }                                                                            \
   }
 #define LDC_MM(ACC, WF, AF)                                                                                  \
@@ -422,6 +423,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       LDC_MM(acc[(CT)], WH, AH[0])                                               \
       if constexpr (RT == 2) {                                                   \
         LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])                                    \
+      }                                                                          \
+      LDC_MM(acc[(CT)], WL, AL[0])                                               \
+      if constexpr (RT == 2) {                                                   \
+        LDC_MM(acc[8 + (CT)], WL, AL[RT - 1])                                    \
       }                                                                          \
     } else if constexpr (RT == 2) {                                              \
       LDC_MM(acc[(CT)], WH, AL[0])                                               \
@@ -441,13 +446,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #else
 #define LDC_KSTEP_BARRIER __builtin_amdgcn_s_barrier();
 #endif
-    // wait until the fragment window holds at most 3 column tiles of outstanding reads (6 reads with lo chunks, 3 without)
+    // wait until the fragment window holds at most 3 column tiles (6 reads) of outstanding reads
 #define LDC_WAIT(N, X, Y)                                                        \
-  if constexpr (TERMS == 3) {                                                    \
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(X), "+v"(Y));                     \
-  } else {                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(X), "+v"(Y));                     \
-  }                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(X), "+v"(Y));                       \
   LDC_SB;
     // one k-step: (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt+1
 #define LDC_KSTEP(AH, AL, AHN, ALN)                                                                          \
@@ -460,14 +461,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     constexpr bool dma2 = true; /* second half of k-step kt+2's DMAs (clamped past the end) */             \
     constexpr bool dma3 = true; /* first half of k-step kt+3's (into stage st, free behind barrier(kt+1)) */ \
     /* W(kt, 0..3) were issued in the order 0, 1, 2, 3 and nothing after them except A(kt) before them */    \
-    if constexpr (RT == 2 && TERMS == 3) {                                                                   \
+    if constexpr (RT == 2) {                                                                                 \
       asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
-    } else if constexpr (TERMS == 3) {                                                                       \
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                 \
-    } else if constexpr (RT == 2) {                                                                          \
-      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(AH[0]), "+v"(AH[1]), "+v"(wh0));                            \
     } else {                                                                                                 \
-      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(AH[0]), "+v"(wh0));                                         \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                 \
     }                                                                                                        \
     LDC_SB;                                                                                                  \
     LDC_CT(0, wh0, wl0, AH, AL)                                                                              \
@@ -642,7 +639,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     LDC_CHECK_PTR(q.C);
     const ldc_gemm_desc& d = q.d;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
-    if (d.K % BK) return LDC_ERR_UNSUPPORTED;
+    if (d.K % (TERMS == 3 ? BK : 2 * BK)) return LDC_ERR_UNSUPPORTED;  // a 128-byte k-step: 32 split / 64 plain-bf16 values
     if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
     LDC_CHECK_ALIGN16(q.A);
     LDC_CHECK_ALIGN16(q.W);
@@ -663,7 +660,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (q.gate) v4 = v4 && al16(q.gate) && (d.gate_bs % 4 == 0);
       if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
       P.vec4 = v4 ? 1 : 0;
-      P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? 1 : 0;
+      P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? (TERMS == 3 ? LDC_FMT_SPLIT : LDC_FMT_BF16) : 0;
       if (P.c_split && !(v4 && d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_bs % 8 == 0 &&
                          (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
         return LDC_ERR_ALIGN;
@@ -685,7 +682,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
-    P.kt = d.K / BK;
+    P.kt = d.K / (TERMS == 3 ? BK : 2 * BK);
     P.unit0 = U;
     P.tile0 = tiles;
     {

@@ -582,6 +582,30 @@ extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, 
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, true);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __restrict__ W, uint2* __restrict__ out, long long N, int K4, int ldw) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;  // one float4 -> 4 bf16
+  if (idx >= N * K4) return;
+  const long long n = idx / K4;
+  const int c = static_cast<int>(idx - n * K4);
+  const float4 v = reinterpret_cast<const float4*>(W + n * ldw)[c];
+  out[idx] = make_uint2(ldc_pack_pair(v.x, v.y), ldc_pack_pair(v.z, v.w));
+}
+}  // namespace
+
+extern "C" int ldc_pack_weight_bf16(const float* W, void* out, int N, int K, int ldw, void* stream) {
+  LDC_CHECK_PTR(W);
+  LDC_CHECK_PTR(out);
+  if (N <= 0 || K <= 0) return LDC_ERR_ARG;
+  if ((K & 7) || (ldw & 3)) return LDC_ERR_ALIGN;
+  LDC_CHECK_ALIGN16(W);
+  LDC_CHECK_ALIGN16(out);
+  const long long total = static_cast<long long>(N) * (K >> 2);
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(ldc_cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), W,
+                     static_cast<uint2*>(out), static_cast<long long>(N), K >> 2, ldw);
+  return ldc_launch_status();
+}
+
 extern "C" int ldc_pack_weight_bf16x2(const float* W, void* out, int N, int K, int ldw, void* stream) {
   LDC_CHECK_PTR(W);
   LDC_CHECK_PTR(out);

@@ -31,10 +31,14 @@ __global__ __launch_bounds__(256) void chan_to_token_kernel(const float* __restr
       if (!(tx & 1) && n < N && c < fill) {
         float r0, r1;
         const unsigned hi = ldc_split_pair(v, w, r0, r1);
-        const unsigned lo = ldc_pack_pair(r0, r1);
-        unsigned char* grp = reinterpret_cast<unsigned char*>(ob + static_cast<long long>(n) * ldo + (c & ~7)) + 2 * (c & 7);
-        *reinterpret_cast<unsigned*>(grp) = hi;
-        *reinterpret_cast<unsigned*>(grp + 16) = lo;
+        if (out_split == LDC_FMT_BF16) {  // plain bf16 row
+          *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(ob + static_cast<long long>(n) * ldo) + 2 * c) = hi;
+        } else {
+          const unsigned lo = ldc_pack_pair(r0, r1);
+          unsigned char* grp = reinterpret_cast<unsigned char*>(ob + static_cast<long long>(n) * ldo + (c & ~7)) + 2 * (c & 7);
+          *reinterpret_cast<unsigned*>(grp) = hi;
+          *reinterpret_cast<unsigned*>(grp + 16) = lo;
+        }
       }
     }
     return;
@@ -107,7 +111,7 @@ extern "C" int ldc_chan_to_token_split(const float* in, float* out, int B, int C
   if (out_split && ((fill_cols & 7) || (ldo & 7) || (reinterpret_cast<unsigned long long>(out) & 31ull))) return LDC_ERR_ALIGN;
   dim3 grid(ldc_cdiv(N, 32), ldc_cdiv(fill_cols, 32), B);
   hipLaunchKernelGGL(chan_to_token_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, out, C, N, ldo,
-                     fill_cols, out_split ? 1 : 0);
+                     fill_cols, out_split);
   return ldc_launch_status();
 }
 

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(float* __restrict__ 
       o.y = (v[i].y - mean) * rstd * (one + m.y) + a.y;
       o.z = (v[i].z - mean) * rstd * (one + m.z) + a.z;
       o.w = (v[i].w - mean) * rstd * (one + m.w) + a.w;
-      if (out_split) {
+      if (out_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 8 c
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(yr) + 8 * c) = make_uint2(ldc_pack_pair(o.x, o.y), ldc_pack_pair(o.z, o.w));
+      } else if (out_split) {
         // split activation format (ladcast_hip.h, LDC_GEMM_A_SPLIT): columns 8g..8g+7 in 32 bytes [hi x8 | lo x8];
         // this lane has columns 4c..4c+3 = half of group c >> 1
         float r0, r1, r2, r3;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict
 // block = 64 column PAIRS x 16 row-groups
 __global__ __launch_bounds__(1024) void mean_rows_split_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                float* __restrict__ xs, int rows, int D, int ldx,
-                                                               long long x_bs, int lds, long long s_bs) {
+                                                               long long x_bs, int lds, long long s_bs, int fmt) {
   __shared__ float2 part[16][64];
   const int c = threadIdx.x & 63;
   const int col = (blockIdx.x * 64 + c) * 2;
@@ -181,7 +183,8 @@ __global__ __launch_bounds__(1024) void mean_rows_split_kernel(const float* __re
   float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   if (col < D) {
     const float* xb = x + b * x_bs + col;
-    unsigned char* sb = reinterpret_cast<unsigned char*>(xs + b * s_bs + (col & ~7)) + 2 * (col & 7);
+    unsigned char* sb = fmt == LDC_FMT_BF16 ? reinterpret_cast<unsigned char*>(xs + b * s_bs) + 2 * col  // plain bf16 row
+                                            : reinterpret_cast<unsigned char*>(xs + b * s_bs + (col & ~7)) + 2 * (col & 7);
     auto take = [&](int r, float2& acc) {
       const float2 v = *reinterpret_cast<const float2*>(xb + static_cast<long long>(r) * ldx);
       acc.x += v.x;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(1024) void mean_rows_split_kernel(const float* __re
       const unsigned hi = ldc_split_pair(v.x, v.y, r0, r1);
       unsigned char* d = sb + static_cast<long long>(r) * lds * 4;
       *reinterpret_cast<unsigned*>(d) = hi;
-      *reinterpret_cast<unsigned*>(d + 16) = ldc_pack_pair(r0, r1);
+      if (fmt != LDC_FMT_BF16) *reinterpret_cast<unsigned*>(d + 16) = ldc_pack_pair(r0, r1);
     };
     int r = g;
     for (; r + 48 < rows; r += 64) {
@@ -462,7 +465,7 @@ extern "C" int ldc_mean_rows(const float* x, float* y, int B, int rows, int D, i
 }
 
 extern "C" int ldc_mean_rows_split(const float* x, float* y, float* x_split, int B, int rows, int D, int ldx,
-                                   long long x_bs, int lds, long long s_bs, void* stream) {
+                                   long long x_bs, int lds, long long s_bs, int fmt, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(y);
   LDC_CHECK_PTR(x_split);
@@ -471,9 +474,10 @@ extern "C" int ldc_mean_rows_split(const float* x, float* y, float* x_split, int
       (reinterpret_cast<unsigned long long>(x_split) & 31ull))
     return LDC_ERR_ALIGN;
   if (x == x_split) return LDC_ERR_ARG;  // other workgroups' rows would be read after being overwritten
+  if (fmt != LDC_FMT_SPLIT && fmt != LDC_FMT_BF16) return LDC_ERR_ARG;
   dim3 grid(ldc_cdiv(D, 128), B);
   hipLaunchKernelGGL(mean_rows_split_kernel, grid, dim3(1024), 0, static_cast<hipStream_t>(stream), x, y, x_split, rows, D,
-                     ldx, x_bs, lds, s_bs);
+                     ldx, x_bs, lds, s_bs, fmt);
   return ldc_launch_status();
 }
 

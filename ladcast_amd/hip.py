@@ -21,7 +21,8 @@ LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per row, the input row = its sinusoidal embedding
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
-ATTN_OUT_SPLIT, ATTN_BF16_1TERM = 1, 2
+ATTN_OUT_SPLIT, ATTN_BF16_1TERM, ATTN_OUT_BF16 = 1, 2, 4
+FMT_F32, FMT_SPLIT, FMT_BF16 = 0, 1, 2  # activation formats of the producers' `out_split` arguments (True == FMT_SPLIT)
 
 
 class GemmDesc(Structure):
@@ -73,6 +74,7 @@ def _load():
         "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
         "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, P, I, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
+        "ldc_pack_weight_bf16": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
         "ldc_linear_small_grouped": (I, [POINTER(LinearSmallProblem), I, P]),
         "ldc_linear_small_mod": (I, [P, I, P, P, P, I, P, I, P, I, I, I, I, I, P]),
@@ -88,7 +90,7 @@ def _load():
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, I, P]),
         "ldc_layernorm_mod2": (I, [P, P, I, I, I, I, L, I, L, P, P, I, P, P, I, I, F, I, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
-        "ldc_mean_rows_split": (I, [P, P, P, I, I, I, I, L, I, L, P]),
+        "ldc_mean_rows_split": (I, [P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_chan_to_token_split": (I, [P, P, I, I, I, I, I, I, P]),
         "ldc_gate_residual": (I, [P, P, P, P, I, I, I, I, L, I, L, I, P]),
         "ldc_chan_to_token": (I, [P, P, I, I, I, I, I, P]),
@@ -209,6 +211,16 @@ def pack_weight_bf16x2(W):
     return out
 
 
+def pack_weight_bf16(W):
+    """fp32 [N, K] (K % 8 == 0) -> plain bf16 [N, K] weight buffer (the W operand of the single-term bf16 mode)"""
+    _dev(W)
+    W = W.contiguous()
+    N, K = W.shape
+    out = torch.empty(N * K, device=W.device, dtype=torch.bfloat16)
+    _check(lib.ldc_pack_weight_bf16(_p(W), _p(out), N, K, K, _stream()), "ldc_pack_weight_bf16")
+    return out
+
+
 def linear_small(x, W, y, *, rows, N, K, x_rows=None, bias=None, add=None, add_rows=1, act_in=ACT_NONE, act_out=ACT_NONE, mod=None, mod_rows=1):
     """mod ([mod_rows][2 N]): y = y * (1 + mod[:, :N]) + mod[:, N:] as the epilogue (ldc_linear_small_mod)"""
     _dev(x, W, y, bias, add, mod)
@@ -224,7 +236,7 @@ def gate_residual_layernorm(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, 
     """resid += gate * y in place, then out = LayerNorm(resid) * weight + bias (one launch)"""
     _dev(resid, y, gate, out, weight, bias)
     _check(lib.ldc_gate_residual_layernorm(_p(resid), _p(y), _p(gate), _p(out), B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs, ld_out, out_bs,
-                                           _p(weight), _p(bias), eps, 1 if out_split else 0, _stream()), "ldc_gate_residual_layernorm")
+                                           _p(weight), _p(bias), eps, int(out_split), _stream()), "ldc_gate_residual_layernorm")
 
 
 LINEAR_SMALL_MAX_GROUPED = 4  # LDC_LINEAR_SMALL_MAX_GROUPED
@@ -329,7 +341,7 @@ def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=
     _dev(Q, K, V, O, key_bias)
     if key_bias is not None and key_bias.numel() < 32 * ((S + 31) // 32):
         raise ValueError("key_bias must be padded to a multiple of 32 keys (hip.pad_key_bias)")
-    flags = (ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
+    flags = (ATTN_OUT_BF16 if int(out_split) == FMT_BF16 else ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
     _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), flags, _stream()), "ldc_attn_fwd_split")
 
 
@@ -361,22 +373,23 @@ def layernorm_mod(x, y, *, B, rows, D, ldx, x_bs, ldy, y_bs, scale=None, shift=N
     _dev(x, y, scale, shift, scale2, shift2)
     if split_row is None:
         _check(lib.ldc_layernorm_mod(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), mod_bs, mode, eps,
-                                     1 if out_split else 0, _stream()),
+                                     int(out_split), _stream()),
                "ldc_layernorm_mod")
     else:
         _check(lib.ldc_layernorm_mod2(_p(x), _p(y), B, rows, D, ldx, x_bs, ldy, y_bs, _p(scale), _p(shift), split_row, _p(scale2), _p(shift2),
-                                      mod_bs, mode, eps, 1 if out_split else 0, _stream()),
+                                      mod_bs, mode, eps, int(out_split), _stream()),
                "ldc_layernorm_mod2")
 
 
-def mean_rows(x, y, *, B, rows, D, ldx, x_bs, x_split=None, lds=None, s_bs=None):
-    """x_split: also write x in the split activation format (GEMM_A_SPLIT) to this buffer (row stride lds, batch stride s_bs)"""
+def mean_rows(x, y, *, B, rows, D, ldx, x_bs, x_split=None, lds=None, s_bs=None, fmt=FMT_SPLIT):
+    """x_split: also write x in the split (fmt FMT_SPLIT) or plain-bf16 (FMT_BF16) activation format to this buffer (row stride lds,
+    batch stride s_bs, in floats)"""
     _dev(x, y, x_split)
     if x_split is None:
         _check(lib.ldc_mean_rows(_p(x), _p(y), B, rows, D, ldx, x_bs, _stream()), "ldc_mean_rows")
     else:
         _check(lib.ldc_mean_rows_split(_p(x), _p(y), _p(x_split), B, rows, D, ldx, x_bs, lds if lds is not None else ldx,
-                                       s_bs if s_bs is not None else x_bs, _stream()), "ldc_mean_rows_split")
+                                       s_bs if s_bs is not None else x_bs, int(fmt), _stream()), "ldc_mean_rows_split")
 
 
 def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs, gate_bs):
@@ -387,7 +400,7 @@ def gate_residual(resid, y, gate, out, *, B, rows, D, ld_res, res_bs, ld_y, y_bs
 
 def chan_to_token(x, out, *, B, C, N, ldo, fill_cols=None, out_split=False):
     _dev(x, out)
-    _check(lib.ldc_chan_to_token_split(_p(x), _p(out), B, C, N, ldo, ldo if fill_cols is None else fill_cols, 1 if out_split else 0, _stream()),
+    _check(lib.ldc_chan_to_token_split(_p(x), _p(out), B, C, N, ldo, ldo if fill_cols is None else fill_cols, int(out_split), _stream()),
            "ldc_chan_to_token")
 
 

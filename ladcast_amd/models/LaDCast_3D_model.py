@@ -383,9 +383,11 @@ class LaDCastTransformer3DModel(ModelMixin):
         d = self.inner_dim
         plan.wx = self.x_embedder.proj.weight.reshape(d, -1).contiguous()
         plan.wc = self.context_embedder.proj.weight.reshape(d, -1).contiguous()
-        # split-bf16 mode: the patch embeds run on the bf16x3 kernel with K zero-padded to a multiple of 32
-        plan.kx_pad = -(-plan.wx.shape[1] // 32) * 32
-        plan.kc_pad = -(-plan.wc.shape[1] // 32) * 32
+        # split-bf16 / bf16 modes: the patch embeds run on the MFMA kernel with K zero-padded to a whole 128-byte k-step
+        # (32 split values, 64 plain bf16 values)
+        kq = 64 if self.gemm_precision == "bf16" else 32
+        plan.kx_pad = -(-plan.wx.shape[1] // kq) * kq
+        plan.kc_pad = -(-plan.wc.shape[1] // kq) * kq
         # Every AdaLN modulation driven by the conditioning embedding (dual blocks: 6D per stream, single blocks: 3D,
         # output head: 2D) is one [sum N, D] matrix: one HBM-bound GEMV launch per forward instead of one per block.
         mods = []
@@ -400,7 +402,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             plan.mod_off[id(m)] = off
             off += m.weight.shape[0]
         # split-bf16 mode: every token-stream GEMM weight gets a pre-split [N][K/8][hi|lo] copy (same bytes as fp32)
-        plan.split = self.gemm_precision in ("bf16x3", "bf16")  # both run on the split operand images
+        plan.split = self.gemm_precision in ("bf16x3", "bf16")  # pre-converted operands: split-bf16 groups / plain bf16 rows
         plan.one_term = self.gemm_precision == "bf16"
         plan.packed = {}
         if plan.split:
@@ -414,12 +416,13 @@ class LaDCastTransformer3DModel(ModelMixin):
                        blk.ff_context.net[0].proj.weight, blk.ff_context.net[2].weight]
             for blk in self.single_transformer_blocks:
                 ws += [blk.proj_mlp.weight, blk.proj_out.weight]
+            pack = hip.pack_weight_bf16 if plan.one_term else hip.pack_weight_bf16x2
             for w in ws:
-                plan.packed[id(w)] = hip.pack_weight_bf16x2(w)
+                plan.packed[id(w)] = pack(w)
             for w, kp in ((plan.wx, plan.kx_pad), (plan.wc, plan.kc_pad)):
                 wp = torch.zeros(w.shape[0], kp, device=w.device, dtype=w.dtype)
                 wp[:, : w.shape[1]] = w
-                plan.packed[id(w)] = hip.pack_weight_bf16x2(wp)
+                plan.packed[id(w)] = pack(wp)
         self._plan = plan
         self._plan_gen += 1
 
@@ -664,6 +667,9 @@ class LaDCastTransformer3DModel(ModelMixin):
         # buffers, strides and column offsets are the same as in fp32 mode
         AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
         CS = hip.GEMM_C_SPLIT if split else 0
+        # what the producers of GEMM operands write: fp32, split-bf16 groups (bf16x3), plain bf16 rows (bf16: a row's K values in the
+        # first 2 K bytes of its fp32 row - same buffers and strides; only COLUMN offsets differ, 2 bytes per column instead of 4)
+        fmt = hip.FMT_BF16 if plan.one_term else hip.FMT_SPLIT if split else hip.FMT_F32
 
         def G(A, W, C, **kw):  # weight in the format of the active precision mode
             return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
@@ -685,8 +691,8 @@ class LaDCastTransformer3DModel(ModelMixin):
             KX, KC = plan.kx_pad, plan.kc_pad
             xtok, ctok = ws.xtok.view(-1)[: B * Nx * KX].view(B, Nx, KX), ws.ctok.view(-1)[: B * Nc * KC].view(B, Nc, KC)
             # token rows are written in the split format by the transpose itself -> the pre-split GEMM kernel
-            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX, out_split=True)
-            hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC, out_split=True)
+            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX, out_split=fmt)
+            hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC, out_split=fmt)
             run([
                 G(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias, flags=AS),
                 G(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias, flags=AS),
@@ -709,7 +715,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
         if split:  # the pooling pass also leaves the embedded context in the split format for proj_in (nh_c is free until the first norm)
-            hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D, x_split=nh_c, lds=D, s_bs=SD)
+            hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D, x_split=nh_c, lds=D, s_bs=SD, fmt=fmt)
         else:
             hip.mean_rows(ws.ctx0, ws.pooled, B=B, rows=Nc, D=D, ldx=D, x_bs=Nc * D)
         self._timestep_mlps(timestep, Bt, ws.pooled, B, ws)
@@ -719,14 +725,14 @@ class LaDCastTransformer3DModel(ModelMixin):
             run1(ws.ctx0, ref.proj_in.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=Nc * D, c_bs=SD, bias=ref.proj_in.bias)
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
-            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=split)
+            hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=fmt)
             run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
                     [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
             self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
             hip.gate_residual_layernorm(h_c, ws.att[:, Nx:], ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
-                                        ld_out=D, out_bs=SD, weight=blk.norm2.weight, bias=blk.norm2.bias, eps=blk.norm2.eps, out_split=split)
+                                        ld_out=D, out_bs=SD, weight=blk.norm2.weight, bias=blk.norm2.bias, eps=blk.norm2.eps, out_split=fmt)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
             run1(nh_c, f0.weight, ws.cat, M=Nc, N=F, K=D, batch=B, a_bs=SD, c_bs=Nc * F, bias=f0.bias, act=hip.ACT_SILU, flags=AS | CS)
@@ -749,20 +755,20 @@ class LaDCastTransformer3DModel(ModelMixin):
             mx, mc = mod_of(blk.norm1.linear, 6 * D), mod_of(blk.norm1_context.linear, 6 * D)
             # norm1 + norm1_context: the two streams are adjacent rows of ws.h -> one launch, two modulation sets
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, split_row=Nx, scale2=mc[:, D:], shift2=mc,
-                              mod_bs=NM, mode=0, eps=1e-6, out_split=split)
+                              mod_bs=NM, mode=0, eps=1e-6, out_split=fmt)
             run_qkv([
                 G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                 G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
             ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
             self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=split, key_bias=kb_all)
+                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=fmt, key_bias=kb_all)
             o, oc = blk.attn.to_out[0], blk.attn.to_add_out
             run([
                 G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
                 G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD, flags=AS),
             ])
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], split_row=Nx,
-                              scale2=mc[:, 4 * D :], shift2=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
+                              scale2=mc[:, 4 * D :], shift2=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=fmt)
             up, down = [], []
             for (hs, nhs, rows, ff, mod, off) in ((h_x, nh_x, Nx, blk.ff, mx, 0), (h_c, nh_c, Nc, blk.ff_context, mc, Nx)):
                 f0, f2 = ff.net[0].proj, ff.net[2]
@@ -780,20 +786,22 @@ class LaDCastTransformer3DModel(ModelMixin):
             mod = mod_of(blk.norm.linear, 3 * D)
             F = blk.proj_mlp.weight.shape[0]
             W5 = D + F
-            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6, out_split=split)
+            # columns [D, 5 D) of the [attn | mlp] concat rows; in the plain-bf16 row format that is byte offset 2 D, not 4 D
+            cat_mlp = ws.cat.view(torch.bfloat16)[:, :, D:] if plan.one_term else ws.cat[:, :, D:]
+            hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6, out_split=fmt)
             run_qkv([
-                G(ws.nh, blk.proj_mlp.weight, ws.cat[:, :, D:], M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
+                G(ws.nh, blk.proj_mlp.weight, cat_mlp, M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
                   flags=AS | CS),
                 G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
             ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
             self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=split, key_bias=kb_all)
+                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=fmt, key_bias=kb_all)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD, flags=AS)
 
         # 6. output head, models/LaDCast_3D_model.py:1044-1062 (patch size 1: un-patchify == transpose)
         mo = mod_of(self.norm_out.linear, 2 * D)
-        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mo, shift=mo[:, D:], mod_bs=NM, mode=0, eps=1e-7, out_split=split)
+        hip.layernorm_mod(h_x, nh_x, B=B, rows=Nx, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mo, shift=mo[:, D:], mod_bs=NM, mode=0, eps=1e-7, out_split=fmt)
         run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias, flags=AS)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)

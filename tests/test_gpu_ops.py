@@ -595,29 +595,72 @@ def test_sampler_state_kernels_are_bit_exact(hip):
 
 
 # -- single-term bf16 mode (LDC_GEMM_BF16_1TERM / LDC_ATTN_BF16_1TERM; BASELINE configs[4] "fp16/bf16 mixed") -------------------
-@pytest.mark.parametrize("M,N,K,batch", [(2250, 1536, 1536, 1), (450, 4608, 1536, 2), (2250, 1536, 7680, 1), (300, 264, 160, 1), (5000, 6144, 1536, 1),
-                                         (1, 8, 32, 1), (1800, 84, 1536, 1)])
+def _bf16_rows(x):
+    """fp32 [..., K] -> a buffer of the same fp32 shape whose rows hold the K values as plain bf16 in their first 2 K bytes (LDC_FMT_BF16)"""
+    buf = torch.zeros_like(x)
+    buf.view(torch.bfloat16)[..., : x.shape[-1]] = x.bfloat16()
+    return buf
+
+
+def _from_bf16_rows(buf, K):
+    return buf.detach().cpu().view(torch.bfloat16)[..., :K].float()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(2250, 1536, 1536, 1), (450, 4608, 1536, 2), (2250, 1536, 7680, 1), (300, 264, 192, 1), (5000, 6144, 1536, 1),
+                                         (1, 8, 64, 1), (1800, 84, 1536, 1)])
 def test_gemm_bf16_single_term(hip, M, N, K, batch):
-    """C = bf16(A) . bf16(W)^T with fp32 accumulation: bit-level statement of the mode - against the fp64 product of the
-    ROUNDED operands only the accumulation order differs (1e-5); against the unrounded product it is bf16-accurate (stated
-    tolerance 6e-3: two operands with 2^-9 relative rounding each, averaged over K)."""
+    """C = bf16(A) . bf16(W)^T with fp32 accumulation on PLAIN bf16 operand rows (half the bytes of the split format, 64 k per k-step):
+    against the fp64 product of the ROUNDED operands only the accumulation order differs (1e-5); against the unrounded product it is
+    bf16-accurate (stated tolerance 6e-3).  LDC_GEMM_C_SPLIT writes C as bf16 rows too."""
     A, W, b = rnd(batch, M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3)
-    Ap = hip.pack_weight_bf16x2(dev(A).reshape(batch * M, K))
-    Wp = hip.pack_weight_bf16x2(dev(W))
+    Ap = dev(_bf16_rows(A))
+    Wp = hip.pack_weight_bf16(dev(W))
+    assert torch.equal(Wp.cpu().view(N, K).float(), W.bfloat16().float())
     C = torch.empty(batch, M, N, device="cuda")
     f1 = hip.GEMM_A_SPLIT | hip.GEMM_BF16_1TERM
-    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b), flags=f1)], split_bf16=True)
+    kw = dict(M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b))
+    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, flags=f1, **kw)], split_bf16=True)
     want_r = A.bfloat16().double() @ W.bfloat16().double().T + b.double()
     assert rel(C, want_r) < 1e-5
     e = rel(C, A.double() @ W.double().T + b.double())
     assert 1e-4 < e < 6e-3, e  # it really is the single-term product, not the compensated one
-    # the split-bf16 contraction on the same images for comparison
-    C3 = torch.empty_like(C)
-    hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C3, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, bias=dev(b), flags=hip.GEMM_A_SPLIT)], split_bf16=True)
-    assert rel(C3, A.double() @ W.double().T + b.double()) < 1e-5
+    if N % 8 == 0:
+        C2 = torch.full((batch, M, N), float("nan"), device="cuda")
+        hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C2, flags=f1 | hip.GEMM_C_SPLIT, **kw)], split_bf16=True)
+        assert torch.equal(_from_bf16_rows(C2, N), C.cpu().bfloat16().float())  # the bf16 rounding of exactly the fp32 output
     with pytest.raises(RuntimeError):  # one arithmetic per launch
-        hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, flags=f1),
-                          hip.gemm_problem(Ap, Wp, C3, M=M, N=N, K=K, batch=batch, a_bs=M * K, c_bs=M * N, flags=hip.GEMM_A_SPLIT)], split_bf16=True)
+        hip.gemm_grouped([hip.gemm_problem(Ap, Wp, C, flags=f1, **kw),
+                          hip.gemm_problem(Ap, hip.pack_weight_bf16x2(dev(W)), C, flags=hip.GEMM_A_SPLIT, **kw)], split_bf16=True)
+
+
+def test_bf16_row_producers(hip):
+    """LayerNorm, the transpose, the pooling pass and the attention write their output as plain bf16 rows (LDC_FMT_BF16) = the bf16
+    rounding of exactly the fp32 values they write otherwise"""
+    B, rows, D = 2, 450, 1536
+    x, sc, sh = dev(rnd(B, rows, D, seed=1)), dev(rnd(B, D, seed=2) * 0.1), dev(rnd(B, D, seed=3) * 0.1)
+    y0, y2 = torch.empty(B, rows, D, device="cuda"), torch.zeros(B, rows, D, device="cuda")
+    kw = dict(B=B, rows=rows, D=D, ldx=D, x_bs=rows * D, ldy=D, y_bs=rows * D, scale=sc, shift=sh, mod_bs=D, mode=0, eps=1e-6)
+    hip.layernorm_mod(x, y0, **kw)
+    hip.layernorm_mod(x, y2, out_split=hip.FMT_BF16, **kw)
+    assert torch.equal(_from_bf16_rows(y2, D), y0.cpu().bfloat16().float())
+    img = dev(rnd(B, 84, 900, seed=4))
+    t0, t2 = torch.empty(B, 900, 128, device="cuda"), torch.zeros(B, 900, 128, device="cuda")
+    hip.chan_to_token(img, t0, B=B, C=84, N=900, ldo=128, fill_cols=128)
+    hip.chan_to_token(img, t2, B=B, C=84, N=900, ldo=128, fill_cols=128, out_split=hip.FMT_BF16)
+    assert torch.equal(_from_bf16_rows(t2, 128), t0.cpu().bfloat16().float())
+    m0, m2, xs = torch.empty(B, D, device="cuda"), torch.empty(B, D, device="cuda"), torch.zeros(B, rows, D, device="cuda")
+    hip.mean_rows(x, m0, B=B, rows=rows, D=D, ldx=D, x_bs=rows * D)
+    hip.mean_rows(x, m2, B=B, rows=rows, D=D, ldx=D, x_bs=rows * D, x_split=xs, lds=D, s_bs=rows * D, fmt=hip.FMT_BF16)
+    assert torch.equal(m2, m0) and torch.equal(_from_bf16_rows(xs, D), x.cpu().bfloat16().float())
+    S, H = 200, 3
+    Dh = H * 128
+    qkv = dev(rnd(1, S, 3 * Dh, seed=5))
+    _prep(hip, qkv, 1, S, H, Dh, split_row=S)
+    o0, o2 = torch.empty(1, S, Dh + 128, device="cuda"), torch.zeros(1, S, Dh + 128, device="cuda")
+    akw = dict(B=1, S=S, H=H, ld_qkv=3 * Dh, qkv_bs=S * 3 * Dh, ldo=Dh + 128, o_bs=S * (Dh + 128))
+    hip.attn_fwd_split(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], o0, **akw)
+    hip.attn_fwd_split(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], o2, out_split=hip.FMT_BF16, **akw)
+    assert torch.equal(_from_bf16_rows(o2, Dh + 128)[..., :Dh], o0.cpu()[..., :Dh].bfloat16().float())
 
 
 @pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 97, 2)])

@@ -133,7 +133,12 @@ def main():
                 mk = torch.zeros if MODE == "zeros" else torch.randn
                 A, W, C = mk(M, K, device="cuda"), mk(N, K, device="cuda"), torch.empty(M, N, device="cuda")
                 fl = hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if MODE == "bf16" else 0)
-                ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, flags=fl))
+                if MODE == "bf16":  # plain bf16 operand rows
+                    Ab = torch.zeros_like(A)
+                    Ab.view(torch.bfloat16)[:, :K] = A.bfloat16()
+                    ps.append(hip.gemm_problem(Ab, hip.pack_weight_bf16(W), C, M=M, N=N, K=K, flags=fl))
+                else:
+                    ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, flags=fl))
             fn = lambda: hip.gemm_grouped(ps, split_bf16=True)  # noqa: E731
         for _ in range(20):
             fn()

@@ -48,7 +48,12 @@ for name, probs in SHAPES.items():
             ps = []
             for M, N, K in probs:
                 A, W, C = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.empty(M, N, device="cuda")
-                ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, flags=fl))
+                if mode == "single_term":  # plain bf16 operand rows (first 2 K bytes of each fp32-sized row)
+                    Ab = torch.zeros_like(A)
+                    Ab.view(torch.bfloat16)[:, :K] = A.bfloat16()
+                    ps.append(hip.gemm_problem(Ab, hip.pack_weight_bf16(W), C, M=M, N=N, K=K, flags=fl))
+                else:
+                    ps.append(hip.gemm_problem(hip.pack_weight_bf16x2(A), hip.pack_weight_bf16x2(W), C, M=M, N=N, K=K, flags=fl))
             row[f"ours_{mode}_us"], row[f"ours_{mode}_tflops"] = timed(lambda: hip.gemm_grouped(ps, split_bf16=True), flops)
         row["ours_split3_over_vendor_third"] = round(row["ours_split3_tflops"] / (row["vendor_bf16_tflops"] / 3.0), 3)
     res["rows"][name] = row
