@@ -649,9 +649,10 @@ class LaDCastTransformer3DModel(ModelMixin):
         C_out = cfg.out_channels or cfg.in_channels
         Bt = timestep.shape[0]
 
-        key = (B, Bt, Nx, Nc)
+        kpad = max(plan.kx_pad, plan.kc_pad)  # differs between precision modes (k-step of the operand format)
+        key = (B, Bt, Nx, Nc, kpad)
         if key not in self._ws:
-            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, max(plan.kx_pad, plan.kc_pad), C_out, plan.mod_w.shape[0])
+            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, kpad, C_out, plan.mod_w.shape[0])
         ws = self._ws[key]
         pc, ps, cc, cs, pk, ck, jk = self._rope_tables(R, T_in, Hh, Ww, dev)
         SD = S * D
