@@ -65,6 +65,44 @@ __device__ __forceinline__ unsigned ldc_split_pair(float a, float b, float& ra, 
   return u;
 }
 
+// 4 consecutive values (columns c .. c + 3, c % 4 == 0) of a row into the split activation format (LDC_FMT_SPLIT: columns
+// 8 g .. 8 g + 7 in 32 bytes [hi x8 | lo x8]): 8 bytes of hi and 8 bytes of lo.  `row` = start of the row.
+__device__ __forceinline__ void ldc_store_split4(unsigned char* row, int c, float x0, float x1, float x2, float x3) {
+  float r0, r1, r2, r3;
+  const unsigned h0 = ldc_split_pair(x0, x1, r0, r1), h1 = ldc_split_pair(x2, x3, r2, r3);
+  unsigned char* g = row + 4 * (c & ~7) + 2 * (c & 7);
+  *reinterpret_cast<uint2*>(g) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(g + 16) = make_uint2(ldc_pack_pair(r0, r1), ldc_pack_pair(r2, r3));
+}
+// the same for a row whose width C is 4 mod 8: the caller of the LAST 4 columns also clears the other half of the group, so the
+// pad columns C .. C + 3 read as zeros (the GEMMs / convs read whole 8-column groups)
+__device__ __forceinline__ void ldc_zero_split4(unsigned char* row, int c) {
+  unsigned char* g = row + 4 * (c & ~7) + 2 * (c & 7);
+  *reinterpret_cast<uint2*>(g) = make_uint2(0u, 0u);
+  *reinterpret_cast<uint2*>(g + 16) = make_uint2(0u, 0u);
+}
+
+// Source pixel (row-major index inside one image) of tap (ky, kx) of a ks x ks SphereConv2d at output pixel (h, w): rows past a
+// pole are mirrored and rolled by W / 2, columns wrap, and at the two pole rows the kernel rows that reach over the pole are
+// flipped left-right (models/sphere_conv.py:62-129,174-192).  Same rule as gemm_f32.hip / dcae.hip; the wrap is one conditional
+// add / subtract instead of a modulo (ks / 2 <= W / 2, checked by the callers).
+__device__ __forceinline__ int ldc_sphere_src_pixel(int h, int w, int ky, int kx, int H, int W, int ks) {
+  const int p = ks >> 1;
+  if ((h == 0 && ky < p) || (h == H - 1 && ky >= ks - p)) kx = ks - 1 - kx;
+  int r = h + ky - p;
+  int c = w + kx - p;
+  if (r < 0) {
+    r = -1 - r;
+    c -= W >> 1;
+  } else if (r >= H) {
+    r = 2 * H - 1 - r;
+    c -= W >> 1;
+  }
+  if (c < 0) c += W;
+  if (c >= W) c -= W;
+  return r * W + c;
+}
+
 // wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -32,7 +32,7 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
 template <int KS, bool GLU>
 __global__ __launch_bounds__(256) void sphere_dwconv_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ y, int H,
-                                                            int W, int C, int ldx, int ldy) {
+                                                            int W, int C, int ldx, int ldy, int out_fmt) {
   const int pix = blockIdx.y;  // b*H*W + h*W + w
   const int hw = H * W;
   const int bimg = pix / hw;
@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void sphere_dwconv_kernel(const float* __restr
     a0.z *= ldc_silu(a1.z);
     a0.w *= ldc_silu(a1.w);
   }
-  *reinterpret_cast<float4*>(y + static_cast<long long>(pix) * ldy + c0) = a0;
+  if (out_fmt == LDC_FMT_SPLIT)  // operand rows of the next pointwise conv (gemm_bf16x3_v3.hip)
+    ldc_store_split4(reinterpret_cast<unsigned char*>(y + static_cast<long long>(pix) * ldy), c0, a0.x, a0.y, a0.z, a0.w);
+  else
+    *reinterpret_cast<float4*>(y + static_cast<long long>(pix) * ldy + c0) = a0;
 }
 
 // grouped 1x1 conv, 32 -> 32 channels per group: y[m][g*32+o] = sum_i W[g*32+o][i] * x[m][g*32+i]
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void relu_linear_attn_kv_kernel(const float* _
 
 __global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ part,
                                                                      float* __restrict__ y, int P, int ldq, int ldy, float eps,
-                                                                     int nslice) {
+                                                                     int nslice, int out_fmt) {
   __shared__ float kv[33][32];
   const int g = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float
 #pragma unroll
   for (int j = 0; j < 32; ++j) den = fmaf(kv[32][j], q[j], den);
   const float inv = 1.0f / (den + eps);
-  float* yp = y + static_cast<long long>(b) * P * ldy + g * 32 + static_cast<long long>(p) * ldy + 8 * qt;
+  float* yrow = y + static_cast<long long>(b) * P * ldy + static_cast<long long>(p) * ldy;
+  const int ch = g * 32 + 8 * qt;  // this thread's 8 channels: one group of the split format
 #pragma unroll
   for (int c = 0; c < 8; c += 4) {
     float o[4];
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float
       for (int j = 0; j < 32; ++j) s = fmaf(kv[8 * qt + c + u][j], q[j], s);
       o[u] = s * inv;
     }
-    *reinterpret_cast<float4*>(yp + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yrow), ch + c, o[0], o[1], o[2], o[3]);
+    else *reinterpret_cast<float4*>(yrow + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float
 //   y = act(x * rsqrt(mean(x^2) + eps) * w + b (+ resid))          (models/DCAE.py:259-260,317-322,371-377,729-730)
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, const float* __restrict__ resid,
-                                                           float* __restrict__ y, long long rows, int C, int ldx, int ldr,
-                                                           int ldy, float eps, int act) {
+                                                           float* __restrict__ y, float* __restrict__ ys, long long rows, int C,
+                                                           int ldx, int ldr, int ldy, int lds, float eps, int act) {
   const int lane = threadIdx.x & 63;
   const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
   }
   const float r = rsqrtf(wave_sum(ss) / static_cast<float>(C) + eps);
   const float* rr = resid ? resid + row * ldr : nullptr;
-  float* yr = y + row * ldy;
+  float* yr = y ? y + row * ldy : nullptr;  // fp32 copy: residual stream / input of a depthwise conv
+  unsigned char* sr = ys ? reinterpret_cast<unsigned char*>(ys + row * lds) : nullptr;  // split copy: operand rows of the next conv
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
@@ -229,54 +235,94 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
       o.y = ldc_apply_act(o.y, act);
       o.z = ldc_apply_act(o.z, act);
       o.w = ldc_apply_act(o.w, act);
-      reinterpret_cast<float4*>(yr)[c] = o;
+      if (yr) reinterpret_cast<float4*>(yr)[c] = o;
+      if (sr) {
+        ldc_store_split4(sr, 4 * c, o.x, o.y, o.z, o.w);
+        if ((C & 4) && c == nv4 - 1) ldc_zero_split4(sr, 4 * c + 4);
+      }
     }
   }
 }
 
+// fp32 rows -> split rows (the conv_in outputs, whose epilogue writes the fp32 stream)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, float* __restrict__ ys, long long rows, int C,
+                                                         int ldx, int lds) {
+  const int nv4 = C >> 2;
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= rows * nv4) return;
+  const long long row = idx / nv4;
+  const int c = static_cast<int>(idx - row * nv4);
+  const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * c);
+  unsigned char* sr = reinterpret_cast<unsigned char*>(ys + row * lds);
+  ldc_store_split4(sr, 4 * c, v.x, v.y, v.z, v.w);
+  if ((C & 4) && c == nv4 - 1) ldc_zero_split4(sr, 4 * c + 4);
+}
+
 // DCDownBlock2d tail: y[b,h2,w2,co] = cv[b,2h2+i,2w2+j,c] (co = 4c+2i+j)  +  mean_g xs[co*G+g],
 // xs = pixel_unshuffle(x): channel q = 4cx+2i'+j' <- x[b,2h2+i',2w2+j',cx]     (models/DCAE.py:477-490)
+// One thread = 4 consecutive output channels (one c, the four (i, j)); fp32 rows and / or split rows (ys) for the next conv.
 __global__ __launch_bounds__(256) void pixel_unshuffle_shortcut_kernel(const float* __restrict__ cv,
                                                                        const float* __restrict__ x, float* __restrict__ y,
-                                                                       int H2, int W2, int cout, int cin, int G,
-                                                                       long long total) {
+                                                                       float* __restrict__ ys, int H2, int W2, int cout, int cin,
+                                                                       int G, int lds, long long total4) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int co = static_cast<int>(idx % cout);
-  const long long pix = idx / cout;  // b*H2*W2 + h2*W2 + w2
+  if (idx >= total4) return;
+  const int cq = cout >> 2;
+  const int c = static_cast<int>(idx % cq);
+  const long long pix = idx / cq;  // b*H2*W2 + h2*W2 + w2
   const int w2 = static_cast<int>(pix % W2);
   const long long bh = pix / W2;
   const int h2 = static_cast<int>(bh % H2);
   const long long b = bh / H2;
   const int Wf = 2 * W2, Hf = 2 * H2;
-  const int cq = cout >> 2;
   const long long pbase = (b * Hf + 2 * h2) * Wf + 2 * w2;  // top-left full-res pixel
-  const int c = co >> 2, i = (co >> 1) & 1, j = co & 1;
-  float v = cv[(pbase + static_cast<long long>(i) * Wf + j) * cq + c];
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) {
-    const int q = co * G + g;
-    const int cx = q >> 2, ii = (q >> 1) & 1, jj = q & 1;
-    s += x[(pbase + static_cast<long long>(ii) * Wf + jj) * cin + cx];
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int co = 4 * c + e, i = e >> 1, j = e & 1;
+    const float v = cv[(pbase + static_cast<long long>(i) * Wf + j) * cq + c];
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const int q = co * G + g;
+      const int cx = q >> 2, ii = (q >> 1) & 1, jj = q & 1;
+      s += x[(pbase + static_cast<long long>(ii) * Wf + jj) * cin + cx];
+    }
+    o[e] = v + s / static_cast<float>(G);
   }
-  y[idx] = v + s / static_cast<float>(G);
+  if (y) *reinterpret_cast<float4*>(y + pix * cout + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+  if (ys) {
+    unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
+    ldc_store_split4(sr, 4 * c, o[0], o[1], o[2], o[3]);
+    if ((cout & 4) && c == cq - 1) ldc_zero_split4(sr, 4 * c + 4);
+  }
 }
 
 // DCUpBlock2d tail: y[b,2h+i,2w+j,c] = cv[b,h,w,4c+2i+j] + x[b,h,w,(4c+2i+j)/rep]   (models/DCAE.py:526-532)
 __global__ __launch_bounds__(256) void pixel_shuffle_shortcut_kernel(const float* __restrict__ cv, const float* __restrict__ x,
-                                                                     float* __restrict__ y, int H, int W, int cout, int cin,
-                                                                     int rep, long long total) {
+                                                                     float* __restrict__ y, float* __restrict__ ys, int H, int W,
+                                                                     int cout, int cin, int rep, int lds, long long total4) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c = static_cast<int>(idx % cout);
-  const long long pix = idx / cout;  // b*(2H)*(2W) + hf*(2W) + wf
+  if (idx >= total4) return;
+  const int cq = cout >> 2;
+  const int c4 = static_cast<int>(idx % cq);
+  const long long pix = idx / cq;  // b*(2H)*(2W) + hf*(2W) + wf
   const int wf = static_cast<int>(pix % (2 * W));
   const long long bh = pix / (2 * W);
   const int hf = static_cast<int>(bh % (2 * H));
   const long long b = bh / (2 * H);
   const long long src = (b * H + (hf >> 1)) * W + (wf >> 1);
-  const int q = 4 * c + 2 * (hf & 1) + (wf & 1);
-  y[idx] = cv[src * (4LL * cout) + q] + x[src * cin + q / rep];
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = 4 * (4 * c4 + e) + 2 * (hf & 1) + (wf & 1);
+    o[e] = cv[src * (4LL * cout) + q] + x[src * cin + q / rep];
+  }
+  if (y) *reinterpret_cast<float4*>(y + pix * cout + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
+  if (ys) {
+    unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
+    ldc_store_split4(sr, 4 * c4, o[0], o[1], o[2], o[3]);
+    if ((cout & 4) && c4 == cq - 1) ldc_zero_split4(sr, 4 * c4 + 4);
+  }
 }
 
 // channel regroup: cin > cout: y[m][c] = mean_g x[m][c*G+g] (G = cin/cout); else y[m][q] = x[m][q / (cout/cin)]
@@ -300,12 +346,19 @@ __global__ __launch_bounds__(256) void chan_regroup_kernel(const float* __restri
 
 extern "C" int ldc_sphere_dwconv_nhwc(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
                                       int C, int ldx, int ldy, int ksize, int glu, void* stream) {
+  return ldc_sphere_dwconv_nhwc_fmt(x, wt, bias, y, B, H, W, C, ldx, ldy, ksize, glu, LDC_FMT_F32, stream);
+}
+
+extern "C" int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W,
+                                          int C, int ldx, int ldy, int ksize, int glu, int out_fmt, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(wt);
   LDC_CHECK_PTR(y);
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return LDC_ERR_ARG;
   if ((ksize != 3 && ksize != 5) || (W & 1) || H < 2 || H < ksize / 2) return LDC_ERR_UNSUPPORTED;
   if ((C & 3) || (ldx & 3) || (ldy & 3) || (glu && (C & 7))) return LDC_ERR_ALIGN;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt == LDC_FMT_SPLIT && (((glu ? C / 2 : C) & 7) || (ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(wt);
   LDC_CHECK_ALIGN16(y);
@@ -314,10 +367,10 @@ extern "C" int ldc_sphere_dwconv_nhwc(const float* x, const float* wt, const flo
   const int nvec = (glu ? C / 2 : C) / 4;
   dim3 grid(ldc_cdiv(nvec, 256), static_cast<unsigned>(pix));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (ksize == 3 && glu) hipLaunchKernelGGL((sphere_dwconv_kernel<3, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy);
-  else if (ksize == 3) hipLaunchKernelGGL((sphere_dwconv_kernel<3, false>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy);
-  else if (glu) hipLaunchKernelGGL((sphere_dwconv_kernel<5, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy);
-  else hipLaunchKernelGGL((sphere_dwconv_kernel<5, false>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy);
+  if (ksize == 3 && glu) hipLaunchKernelGGL((sphere_dwconv_kernel<3, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
+  else if (ksize == 3) hipLaunchKernelGGL((sphere_dwconv_kernel<3, false>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
+  else if (glu) hipLaunchKernelGGL((sphere_dwconv_kernel<5, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
+  else hipLaunchKernelGGL((sphere_dwconv_kernel<5, false>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
   return ldc_launch_status();
 }
 
@@ -348,12 +401,19 @@ extern "C" long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int grou
 
 extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                                          void* workspace, long long workspace_bytes, void* stream) {
+  return ldc_relu_linear_attn_nhwc_fmt(qkv, y, B, P, groups, ldq, ldy, eps, LDC_FMT_F32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
+                                             int out_fmt, void* workspace, long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(qkv);
   LDC_CHECK_PTR(y);
   LDC_CHECK_PTR(workspace);
   if (B <= 0 || P <= 0 || groups <= 0) return LDC_ERR_ARG;
   if ((ldq & 3) || (ldy & 3)) return LDC_ERR_ALIGN;
   if (groups > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt == LDC_FMT_SPLIT && ((ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
   if (workspace_bytes < ldc_relu_linear_attn_workspace_bytes(B, P, groups)) return LDC_ERR_ARG;
@@ -366,48 +426,88 @@ extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int 
   int st = ldc_launch_status();
   if (st != LDC_OK) return st;
   hipLaunchKernelGGL(relu_linear_attn_apply_kernel, dim3(ldc_cdiv(P, 64), groups, B), dim3(256), 0, s, qkv, part, y, P, ldq, ldy, eps,
-                     nsl);
+                     nsl, out_fmt);
   return ldc_launch_status();
 }
 
 extern "C" int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y,
                                 long long rows, int C, int ldx, int ldr, int ldy, float eps, int act, void* stream) {
+  LDC_CHECK_PTR(y);
+  return ldc_rmsnorm_rows_split(x, w, b, resid, y, nullptr, rows, C, ldx, ldr, ldy, 0, eps, act, stream);
+}
+
+// y (fp32 rows) and / or ys (split rows, lds >= C rounded up to 8, pad columns zeroed): at least one
+extern "C" int ldc_rmsnorm_rows_split(const float* x, const float* w, const float* b, const float* resid, float* y, float* ys,
+                                      long long rows, int C, int ldx, int ldr, int ldy, int lds, float eps, int act, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(w);
-  LDC_CHECK_PTR(y);
+  if (y == nullptr && ys == nullptr) return LDC_ERR_ARG;
   if (rows <= 0 || C <= 0) return LDC_ERR_ARG;
-  if ((C & 3) || C > 1024 || (ldx & 3) || (ldy & 3) || (resid && (ldr & 3))) return LDC_ERR_UNSUPPORTED;
+  if ((C & 3) || C > 1024 || (ldx & 3) || (y && (ldy & 3)) || (resid && (ldr & 3))) return LDC_ERR_UNSUPPORTED;
+  if (ys && ((lds & 7) || lds < ((C + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(w);
-  LDC_CHECK_ALIGN16(y);
+  if (y) LDC_CHECK_ALIGN16(y);
   hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(ldc_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b,
-                     resid, y, rows, C, ldx, ldr, ldy, eps, act);
+                     resid, y, ys, rows, C, ldx, ldr, ldy, lds, eps, act);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, void* stream) {
+  LDC_CHECK_PTR(x);
+  LDC_CHECK_PTR(ys);
+  if (rows <= 0 || C <= 0) return LDC_ERR_ARG;
+  if ((C & 3) || (ldx & 3) || (lds & 7) || lds < ((C + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u)) return LDC_ERR_ALIGN;
+  LDC_CHECK_ALIGN16(x);
+  hipLaunchKernelGGL(split_rows_kernel, dim3(ldc_cdiv(rows * (C >> 2), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ys,
+                     rows, C, ldx, lds);
   return ldc_launch_status();
 }
 
 extern "C" int ldc_pixel_unshuffle_shortcut(const float* cv, const float* x, float* y, int B, int H2, int W2, int cout,
                                             int cin, void* stream) {
+  LDC_CHECK_PTR(y);
+  return ldc_pixel_unshuffle_shortcut_split(cv, x, y, nullptr, B, H2, W2, cout, cin, 0, stream);
+}
+
+static int split_out_ok(const float* y, const float* ys, int cout, int lds) {
+  if (y == nullptr && ys == nullptr) return LDC_ERR_ARG;
+  if (y && (reinterpret_cast<uintptr_t>(y) & 15u)) return LDC_ERR_ALIGN;
+  if (ys && ((lds & 7) || lds < ((cout + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u))) return LDC_ERR_ALIGN;
+  return LDC_OK;
+}
+
+extern "C" int ldc_pixel_unshuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H2, int W2,
+                                                  int cout, int cin, int lds, void* stream) {
   LDC_CHECK_PTR(cv);
   LDC_CHECK_PTR(x);
-  LDC_CHECK_PTR(y);
   if (B <= 0 || H2 <= 0 || W2 <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
   if ((cout & 3) || (4 * cin) % cout) return LDC_ERR_UNSUPPORTED;
-  const long long total = static_cast<long long>(B) * H2 * W2 * cout;
-  hipLaunchKernelGGL(pixel_unshuffle_shortcut_kernel, dim3(ldc_cdiv(total, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), cv, x, y, H2, W2, cout, cin, 4 * cin / cout, total);
+  const int ok = split_out_ok(y, ys, cout, lds);
+  if (ok != LDC_OK) return ok;
+  const long long total4 = static_cast<long long>(B) * H2 * W2 * (cout >> 2);
+  hipLaunchKernelGGL(pixel_unshuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), cv, x, y, ys, H2, W2, cout, cin, 4 * cin / cout, lds, total4);
   return ldc_launch_status();
 }
 
 extern "C" int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B, int H, int W, int cout,
                                           int cin, void* stream) {
+  LDC_CHECK_PTR(y);
+  return ldc_pixel_shuffle_shortcut_split(cv, x, y, nullptr, B, H, W, cout, cin, 0, stream);
+}
+
+extern "C" int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H, int W, int cout,
+                                                int cin, int lds, void* stream) {
   LDC_CHECK_PTR(cv);
   LDC_CHECK_PTR(x);
-  LDC_CHECK_PTR(y);
   if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
-  if ((4 * cout) % cin) return LDC_ERR_UNSUPPORTED;
-  const long long total = static_cast<long long>(B) * 4 * H * W * cout;
-  hipLaunchKernelGGL(pixel_shuffle_shortcut_kernel, dim3(ldc_cdiv(total, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), cv, x, y, H, W, cout, cin, 4 * cout / cin, total);
+  if ((cout & 3) || (4 * cout) % cin) return LDC_ERR_UNSUPPORTED;
+  const int ok = split_out_ok(y, ys, cout, lds);
+  if (ok != LDC_OK) return ok;
+  const long long total4 = static_cast<long long>(B) * 4 * H * W * (cout >> 2);
+  hipLaunchKernelGGL(pixel_shuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), cv, x, y, ys, H, W, cout, cin, 4 * cout / cin, lds, total4);
   return ldc_launch_status();
 }
 

@@ -58,6 +58,9 @@ struct DevProblem {
   const float* qk_w[2];
   const float* rope_cs;  // [rows][64][2]: (cos, sin) of rotary pair i
   float eps, qscale;
+  // implicit-GEMM SphereConv2d (CONV instantiations): A row m = output pixel, k-step = (tap, 32-channel chunk)
+  int cH, cW, cin, ks, kshift;     // 2^kshift k-steps per tap
+  const unsigned char* zero16;     // 16 zero bytes: source of the chunks behind cin in a tap's last k-step
 };
 
 struct SKArgs {
@@ -192,13 +195,15 @@ __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm,
 }
 
 // acc[rt * 8 + ct]: rows 16 (RT wave + rt) + lane % 16, columns 16 ct + 4 (lane / 16) + (0..3)
-template <int BM>
+template <int BM, bool QKV = true>
 __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                               int lane) {
   constexpr int RT = BM / 128;
-  if (P.qkv_heads) {
-    qkv_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
-    return;
+  if constexpr (QKV) {
+    if (P.qkv_heads) {
+      qkv_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+      return;
+    }
   }
   const int M = P.d.M, N = P.d.N;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
@@ -206,6 +211,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
   const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
   const int act = P.d.act;
   const int n_lane = bn * BN + 4 * (lane >> 4);
+  const int Nw = P.c_split == LDC_FMT_SPLIT ? ((N + 7) & ~7) : N;  // split rows are written in whole 8-column groups
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
@@ -215,23 +221,25 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
       const int n = n_lane + 16 * ct;
-      if (n >= N) continue;
+      if (n >= Nw) continue;
+      const bool pad = n >= N;  // split rows with N = 4 mod 8: the pad half of the last group is written as zeros
       const f32x4 av = acc[rt * 8 + ct];
       if (P.vec4) {
         float4 v = make_float4(av[0], av[1], av[2], av[3]);
-        if (P.bias) {
+        if (P.bias && !pad) {
           const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         }
         v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
-        if (gate) {
+        if (gate && !pad) {
           const float4 gv = *reinterpret_cast<const float4*>(gate + n);
           v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
         }
-        if (rrow) {
+        if (rrow && !pad) {
           const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
           v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         }
+        if (pad) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (P.c_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
           const uint2 h2 = make_uint2(ldc_pack_pair(v.x, v.y), ldc_pack_pair(v.z, v.w));
           *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(crow) + 2 * n) = h2;
@@ -283,8 +291,12 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 // 64 k; the same DMAs, LDS image and fragment reads - the chunk the split mode calls "hi" of k-group g is k 16 g .. 16 g + 7 here,
 // its "lo" chunk k 16 g + 8 .. 16 g + 15 (any assignment of k to the two MFMA k-blocks works as long as A and W agree) - and two
 // MFMAs per column tile, (first chunks) + (second chunks), instead of three: two thirds of the MFMAs for twice the k.
-template <int BM, int TERMS>
+// CONV: the A rows are gathered - row m of k-step (tap, chunk) is the 128-byte channel chunk of the tap's source pixel under the
+// sphere padding rule, a per-lane DMA source recomputed when a tap starts (wave-uniform branch, 2^kshift k-steps apart); everything
+// behind the DMA issue is the GEMM.  X is NHWC in the split format (written by the DCAE's producers, dcae.hip).
+template <int BM, int TERMS, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
+  static_assert(!(CONV && TERMS != 3), "the conv gather is built for the split format (32 channels per k-step)");
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
   constexpr int NACC = RT * 8;                 // accumulators (f32x4) per lane
   constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
@@ -359,12 +371,30 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
     const unsigned char* a_src[NAI];
     const unsigned char* w_src[2];
+    int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
+    // the 16-byte slot this lane fills is the same for all its A instructions: swz(r) only looks at r & 15 = 8 (wave & 1) + lr
+    const int cslot = lp ^ swz(8 * (wave & 1) + lr);
+    auto conv_tap_base = [&](int i, int tap) {  // CONV: this lane's chunk of the source pixel of tap `tap` (channel chunk 0)
+      const int ky = tap / P.ks, kx = tap - ky * P.ks;
+      const int src = pix_b[i] + ldc_sphere_src_pixel(pix_hw[i] >> 16, pix_hw[i] & 0xffff, ky, kx, P.cH, P.cW, P.ks);
+      return reinterpret_cast<const unsigned char*>(A + static_cast<long long>(src) * lda) + (cslot << 4);
+    };
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int r = 8 * (wave + 8 * i) + lr;
       int gm = bm * BM + r;
       gm = gm < M ? gm : M - 1;
-      a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + ((lp ^ swz(r)) << 4);
+      if constexpr (CONV) {
+        const int hw = P.cH * P.cW;
+        const int bimg = gm / hw;
+        const int rem = gm - bimg * hw;
+        const int h = rem / P.cW;
+        pix_b[i] = bimg * hw;
+        pix_hw[i] = (h << 16) | (rem - h * P.cW);
+        a_src[i] = conv_tap_base(i, k0 >> P.kshift);
+      } else {
+        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + ((lp ^ swz(r)) << 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -386,8 +416,23 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
       if (kt >= 0) return;
 #endif
-      if (i < NAI) dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
-      else dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
+      if (i < NAI) {
+        if constexpr (CONV) {
+          // piece i is issued once per k-step in increasing kt (clamped repeats of the last one included), so its base is
+          // recomputed exactly when a tap starts
+          const int chunk = kt & ((1 << P.kshift) - 1);
+          if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
+          const unsigned char* src = a_src[i] + chunk * (BK * 4);
+          if (chunk * BK + BK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
+            if (chunk * BK + 8 * (cslot >> 1) >= P.cin) src = P.zero16;
+          }
+          dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
+        } else {
+          dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
+        }
+      } else {
+        dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
+      }
     };
 
     f32x4 acc[NACC];
@@ -564,7 +609,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     LDC_STAMP(2 + 4 * seg_)
 
     if (k0 == 0 && k1 == P.kt) {
-      tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+      tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
@@ -611,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane];
           }
         }
-        tile_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
+        tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
       }
     }
     u += k1 - k0;
@@ -623,9 +668,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   LDC_STAMP(15)
 }
 
-template <int BM, int TERMS>
+struct ConvParams {
+  int H, W, cin, ks, kshift;
+};
+
+template <int BM, int TERMS, bool CONV = false>
 int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace, long long workspace_bytes,
-              void* stream) {
+              void* stream, const ConvParams* cp = nullptr) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
   constexpr int CUS = 256;  // one workgroup per CU
@@ -661,8 +710,9 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
       P.vec4 = v4 ? 1 : 0;
       P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? (TERMS == 3 ? LDC_FMT_SPLIT : LDC_FMT_BF16) : 0;
-      if (P.c_split && !(v4 && d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_bs % 8 == 0 &&
-                         (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
+      // plain-bf16 rows: whole 8-column groups only; split rows: N % 4 == 0, the pad half of a last half-filled group is zeroed
+      if (P.c_split && !(v4 && (d.N % 8 == 0 || P.c_split == LDC_FMT_SPLIT) && d.ldc % 8 == 0 && d.ldc >= ((d.N + 7) & ~7) &&
+                         d.c_bs % 8 == 0 && (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
         return LDC_ERR_ALIGN;
     }
     if (epi != nullptr && epi[i].heads > 0) {
@@ -680,6 +730,11 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       P.eps = e.eps;
       P.qscale = e.qscale != 0.f ? e.qscale : 0.08838834764831845f * 1.4426950408889634f;
     }
+    if constexpr (CONV) {
+      P.cH = cp->H; P.cW = cp->W; P.cin = cp->cin; P.ks = cp->ks; P.kshift = cp->kshift;
+      // 16 zero bytes: the tail of the counter block (zeroed by ldc_gemm_grouped_workspace_init, written by nobody)
+      P.zero16 = static_cast<const unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES - 64;
+    }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
     P.kt = d.K / (TERMS == 3 ? BK : 2 * BK);
@@ -693,7 +748,9 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       // bytes and 18000 x 1536 x 7680 -10 %, but +3 % on 2250 x 4608 / 10752 x 1536, whose 14 MB A panel stays cached anyway.
       // LDC_BF16X3_RM (measurement aid, read per call): force it; 0 = one super-row
       P.rm = P.tm;
-      if (static_cast<double>(d.batch) * d.M * d.K * 4.0 >= 48e6) {
+      // (a conv's taps re-read the same pixels: its panel is M x ldx, and neighbouring row tiles share their halo rows)
+      const double a_bytes = CONV ? static_cast<double>(d.M) * d.lda * 4.0 : static_cast<double>(d.batch) * d.M * d.K * 4.0;
+      if (a_bytes >= 48e6) {
         const double t8 = static_cast<double>(d.batch) * P.tm * P.tn / 8.0;
         const double want = sqrt(t8 * BN / BM);
         int nsr = static_cast<int>(P.tm / (want > 1.0 ? want : 1.0) + 0.5);
@@ -710,7 +767,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     tiles += t;
     U += t * P.kt;
   }
-  if (tiles > LDC_GEMM_COUNTER_BYTES / 4) return LDC_ERR_UNSUPPORTED;  // in-launch reduction only
+  if (tiles > LDC_GEMM_COUNTER_BYTES / 4 - 16) return LDC_ERR_UNSUPPORTED;  // in-launch reduction only; last 64 B: zero page
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
   // grid size: as gemm_bf16x3_dma.hip (phase-aligned divisor of tiles * s when every problem has the same k-depth)
   long long G = CUS;
@@ -770,12 +827,12 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM, TERMS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM, TERMS, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<BM, TERMS>), dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<BM, TERMS, CONV>), dim3(a.G), dim3(512), lds, static_cast<hipStream_t>(stream), a);
   return ldc_launch_status();
 }
 
@@ -818,4 +875,47 @@ extern "C" int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, con
                                            long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(epi);
   return gemm_v3_dispatch(problems, epi, n, workspace, workspace_bytes, stream);
+}
+
+// SphereConv2d (dense, stride 1, k = 3 / 5; k = 1: pointwise conv / Linear over pixel rows with any cin % 8 == 0) as an implicit GEMM
+// on the pre-split kernel: X is NHWC in the split format [B*H*W][ldx] (LDC_FMT_SPLIT, pad columns behind cin up to the next
+// multiple of 8 zero), Wp = ldc_pack_weight_bf16x2 of the [cout][k*k][cin rounded up to 32 * 2^j] tap-major weight (zero behind
+// cin) - the weight format of ldc_sphere_conv_nhwc_bf16x3.  Y: fp32 rows, or (out_fmt = LDC_FMT_SPLIT) split rows for the next conv.
+extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H,
+                                          int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int out_fmt,
+                                          void* workspace, long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(X);
+  LDC_CHECK_PTR(Wp);
+  LDC_CHECK_PTR(Y);
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
+  if (ksize != 1 && ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
+  if (ksize > 1 && ((W & 1) || H < 2 || H < ksize / 2 || W / 2 < ksize / 2 || H > 32767 || W > 65535)) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
+  if ((ldx & 7) || ldx < ((cin + 7) & ~7) || ldy < cout) return LDC_ERR_ALIGN;
+  const long long M = static_cast<long long>(B) * H * W;
+  if (M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  ConvParams cp{H, W, cin, ksize, 0};
+  int ktpt = ldc_cdiv(cin, BK);  // k-steps per tap, rounded up to a power of two (the kernel shifts instead of dividing)
+  while ((1 << cp.kshift) < ktpt) ++cp.kshift;
+  ktpt = 1 << cp.kshift;
+  ldc_gemm_problem q{};
+  q.A = X;
+  q.W = static_cast<const float*>(Wp);
+  q.bias = bias;
+  q.R = R;
+  q.C = Y;
+  q.d.M = static_cast<int>(M);
+  q.d.N = cout;
+  q.d.K = ksize * ksize * ktpt * BK;
+  q.d.batch = 1;
+  q.d.lda = ldx;
+  q.d.ldw = q.d.K;
+  q.d.ldc = ldy;
+  q.d.ldr = ldr;
+  q.d.act = act;
+  q.d.flags = LDC_GEMM_A_SPLIT | (out_fmt == LDC_FMT_SPLIT ? LDC_GEMM_C_SPLIT : 0);
+  const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
+  static const char* const force_thr = getenv("LDC_CONV_SMALL_TILES");  // measurement aid, read once: the cross-over below
+  return tiles256 < (force_thr ? atoll(force_thr) : 400) ? launch_v3<128, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
+                                                         : launch_v3<256, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
 }

@@ -82,6 +82,13 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
+        "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
+        "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, F, I, P]),
+        "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+        "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+        "ldc_split_rows": (I, [P, P, L, I, I, I, P]),
+        "ldc_sphere_dwconv_nhwc_fmt": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+        "ldc_relu_linear_attn_nhwc_fmt": (I, [P, P, I, I, I, I, I, F, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
         "ldc_ensemble_scores": (I, [P, L, L, P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P]),
         "ldc_attn_packed_bytes": (L, [I, I, I]),
@@ -490,11 +497,25 @@ def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None,
            "ldc_sphere_conv_nhwc_bf16x3")
 
 
-def sphere_dwconv_nhwc(x, wt, y, *, B, H, W, C, ldx=None, ldy=None, bias=None, ksize=3, glu=False):
+def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE, out_fmt=FMT_F32):
+    """X: split rows (FMT_SPLIT, ldx % 8 == 0); Wp as sphere_conv_nhwc_bf16x3; Y fp32 rows or (out_fmt=FMT_SPLIT) split rows"""
+    _dev(X, Wp, Y, bias, R)
+    ws = _grouped_workspace(X.device)
+    _check(lib.ldc_sphere_conv_nhwc_split(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx, cout, ldy if ldy is not None else cout,
+                                          ldr, ksize, act, int(out_fmt), _p(ws), ws.numel() * 4, _stream()), "ldc_sphere_conv_nhwc_split")
+
+
+def split_rows(x, ys, *, rows, C, ldx=None, lds=None):
+    _dev(x, ys)
+    _check(lib.ldc_split_rows(_p(x), _p(ys), rows, C, ldx if ldx is not None else C, lds if lds is not None else -(-C // 8) * 8, _stream()),
+           "ldc_split_rows")
+
+
+def sphere_dwconv_nhwc(x, wt, y, *, B, H, W, C, ldx=None, ldy=None, bias=None, ksize=3, glu=False, out_fmt=FMT_F32):
     _dev(x, wt, y, bias)
     cy = C // 2 if glu else C
-    _check(lib.ldc_sphere_dwconv_nhwc(_p(x), _p(wt), _p(bias), _p(y), B, H, W, C, ldx if ldx is not None else C,
-                                      ldy if ldy is not None else cy, ksize, int(glu), _stream()), "ldc_sphere_dwconv_nhwc")
+    _check(lib.ldc_sphere_dwconv_nhwc_fmt(_p(x), _p(wt), _p(bias), _p(y), B, H, W, C, ldx if ldx is not None else C,
+                                          ldy if ldy is not None else cy, ksize, int(glu), int(out_fmt), _stream()), "ldc_sphere_dwconv_nhwc_fmt")
 
 
 def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
@@ -506,7 +527,7 @@ _rla_ws = {}
 _rla_keep = []
 
 
-def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
+def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F32):
     _dev(qkv, y)
     need = int(lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups))
     key = (str(qkv.device), torch.cuda.current_stream(qkv.device).cuda_stream)
@@ -515,24 +536,31 @@ def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps):
             _rla_keep.append(_rla_ws[key])  # a captured hipGraph may still point at the smaller one
         _rla_ws[key] = torch.empty(need // 4 + 1, device=qkv.device, dtype=torch.float32)
     ws = _rla_ws[key]
-    _check(lib.ldc_relu_linear_attn_nhwc(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, _p(ws), ws.numel() * 4, _stream()),
-           "ldc_relu_linear_attn_nhwc")
+    _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), _p(ws), ws.numel() * 4, _stream()),
+           "ldc_relu_linear_attn_nhwc_fmt")
 
 
-def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE):
-    _dev(x, w, b, resid, y)
-    _check(lib.ldc_rmsnorm_rows(_p(x), _p(w), _p(b), _p(resid), _p(y), rows, C, ldx if ldx is not None else C,
-                                ldr if ldr is not None else C, ldy if ldy is not None else C, eps, act, _stream()), "ldc_rmsnorm_rows")
+def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE, ys=None, lds=None):
+    """y: fp32 rows and / or ys: split rows (FMT_SPLIT, lds = C rounded up to 8 by default)"""
+    _dev(x, w, b, resid, y, ys)
+    _check(lib.ldc_rmsnorm_rows_split(_p(x), _p(w), _p(b), _p(resid), _p(y), _p(ys), rows, C, ldx if ldx is not None else C,
+                                      ldr if ldr is not None else C, ldy if ldy is not None else C,
+                                      (lds if lds is not None else -(-C // 8) * 8) if ys is not None else 0, eps, act, _stream()),
+           "ldc_rmsnorm_rows_split")
 
 
-def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin):
-    _dev(cv, x, y)
-    _check(lib.ldc_pixel_unshuffle_shortcut(_p(cv), _p(x), _p(y), B, H2, W2, cout, cin, _stream()), "ldc_pixel_unshuffle_shortcut")
+def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin, ys=None, lds=None):
+    _dev(cv, x, y, ys)
+    _check(lib.ldc_pixel_unshuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H2, W2, cout, cin,
+                                                  (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, _stream()),
+           "ldc_pixel_unshuffle_shortcut_split")
 
 
-def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin):
-    _dev(cv, x, y)
-    _check(lib.ldc_pixel_shuffle_shortcut(_p(cv), _p(x), _p(y), B, H, W, cout, cin, _stream()), "ldc_pixel_shuffle_shortcut")
+def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin, ys=None, lds=None):
+    _dev(cv, x, y, ys)
+    _check(lib.ldc_pixel_shuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H, W, cout, cin,
+                                                (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, _stream()),
+           "ldc_pixel_shuffle_shortcut_split")
 
 
 def chan_regroup(x, y, *, M, cin, cout):

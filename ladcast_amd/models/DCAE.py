@@ -246,9 +246,10 @@ class AutoencoderDC(ModelMixin):
         return out.clone()
 
     def set_gemm_precision(self, precision: str):
-        """'fp32' (default): every conv on the exact-fp32 matrix cores; 'bf16x3': the dense 3x3 SphereConv2d layers
-        (75 % of the FLOPs) as split-bf16 implicit GEMMs (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~4e-6 per layer) --
-        1x1 convs, depthwise convs, norms and the linear attention stay fp32."""
+        """'fp32' (default): every conv on the exact-fp32 matrix cores; 'bf16x3': the dense 3x3 SphereConv2d layers, the 1x1 convs and
+        the Linears (99 % of the FLOPs) as split-bf16 implicit GEMMs (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~4e-6 per layer) on
+        activations their producers write pre-split; depthwise / grouped convs, norms, residual stream and the linear attention
+        stay fp32."""
         if precision == "bf16":
             # the mixed-precision mode of the AR transformer (one bf16 MFMA per product): the conv kernels have no single-term
             # body yet, so the DCAE share of a mixed-precision run is computed with the split-bf16 convs - tighter, not looser,
@@ -311,35 +312,66 @@ class AutoencoderDC(ModelMixin):
         self._plan_gen += 1
 
     # -- NHWC building blocks ---------------------------------------------------------------------
-    def _conv(self, x, B, H, W, conv, act=hip.ACT_NONE, R=None, ldx=None):
+    # A stream tensor is a pair (x32, xs): fp32 rows [B*H*W, C] (residual adds, depthwise convs, norms) and - in the `bf16x3` mode -
+    # the same values as SPLIT rows [B*H*W, C rounded up to 8] (hip.FMT_SPLIT: what the dense convs / 1x1 convs / Linears read, written
+    # once by whoever produces the tensor: conv / norm / pixel-shuffle / attention / GLU epilogues).  fp32 mode: xs is None.
+    @property
+    def _split(self):
+        return self.gemm_precision == "bf16x3"
+
+    @staticmethod
+    def _c8(c):
+        return -(-c // 8) * 8
+
+    def _srows(self, M, C, dev):
+        return torch.empty(M, self._c8(C), device=dev, dtype=torch.float32) if self._split else None
+
+    def _conv(self, x, B, H, W, conv, act=hip.ACT_NONE, R=None, out_split=False):
+        """dense 3x3 SphereConv2d of the stream tensor x = (x32, xs); returns fp32 rows, or (out_split, bf16x3 mode) split rows"""
+        x32, xs = x
         cin_p = ceil4(conv.in_channels)
-        y = torch.empty(B * H * W, conv.out_channels, device=x.device, dtype=torch.float32)
-        fn = hip.sphere_conv_nhwc_bf16x3 if self.gemm_precision == "bf16x3" else hip.sphere_conv_nhwc
-        fn(x, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=ldx if ldx is not None else cin_p,
-           cout=conv.out_channels, bias=conv.bias, R=R, ldr=conv.out_channels if R is not None else 0, ksize=3, act=act)
+        cout = conv.out_channels
+        if self._split:
+            ldy = self._c8(cout) if out_split else cout
+            y = torch.empty(B * H * W, ldy, device=xs.device, dtype=torch.float32)
+            hip.sphere_conv_nhwc_split(xs, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=xs.shape[1], cout=cout, ldy=ldy,
+                                       bias=conv.bias, R=R, ldr=cout if R is not None else 0, ksize=3, act=act,
+                                       out_fmt=hip.FMT_SPLIT if out_split else hip.FMT_F32)
+            return y
+        y = torch.empty(B * H * W, cout, device=x32.device, dtype=torch.float32)
+        hip.sphere_conv_nhwc(x32, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=x32.shape[1], cout=cout, bias=conv.bias, R=R,
+                             ldr=cout if R is not None else 0, ksize=3, act=act)
         return y
 
     def _mm(self, x, key, w_fp32, y, B, H, W, N, K, ldc=None, bias=None, act=hip.ACT_NONE):
-        """pointwise conv / Linear over the B*H*W pixel rows: exact-fp32 GEMM, or (bf16x3 mode) the split-bf16 kernel as
-        a 1x1 conv (any K % 4 == 0)"""
-        if self.gemm_precision == "bf16x3":
-            hip.sphere_conv_nhwc_bf16x3(x, self._plan[key], y, B=B, H=H, W=W, cin=K, cout=N, ldy=ldc, bias=bias, ksize=1, act=act)
+        """pointwise conv / Linear over the B*H*W pixel rows of x = (x32, xs) into fp32 rows y: exact-fp32 GEMM, or (bf16x3 mode) the
+        pre-split conv kernel with ksize 1"""
+        x32, xs = x
+        if self._split:
+            hip.sphere_conv_nhwc_split(xs, self._plan[key], y, B=B, H=H, W=W, cin=K, ldx=xs.shape[1], cout=N, ldy=ldc, bias=bias, ksize=1,
+                                       act=act)
         else:
-            hip.gemm(x, w_fp32, y, M=B * H * W, N=N, K=K, ldc=ldc, bias=bias, act=act)
+            hip.gemm(x32, w_fp32, y, M=B * H * W, N=N, K=K, ldc=ldc, bias=bias, act=act)
+
+    def _norm(self, u, norm, resid, M, C, act=hip.ACT_NONE, want32=True):
+        """RMSNorm rows (+ residual, activation) -> stream tensor"""
+        y32 = torch.empty(M, C, device=u.device, dtype=torch.float32) if (want32 or not self._split) else None
+        ys = self._srows(M, C, u.device)
+        hip.rmsnorm_rows(u, norm.weight, y32, rows=M, C=C, eps=norm.eps, b=norm.bias, resid=resid, act=act, ys=ys)
+        return y32, ys
 
     def _resblock(self, blk, x, B, H, W):
-        t = self._conv(x, B, H, W, blk.conv1, act=blk.act)
+        t = self._conv(x, B, H, W, blk.conv1, act=blk.act, out_split=True)  # only conv2 reads it
+        t = (None, t) if self._split else (t, None)
         u = self._conv(t, B, H, W, blk.conv2)
-        C = blk.conv2.out_channels
-        y = torch.empty_like(u)
-        hip.rmsnorm_rows(u, blk.norm.weight, y, rows=B * H * W, C=C, eps=blk.norm.eps, b=blk.norm.bias, resid=x)
-        return y
+        return self._norm(u, blk.norm, x[0], B * H * W, blk.conv2.out_channels)
 
     def _evit(self, blk, x, B, H, W):
         M = B * H * W
         at = blk.attn
         C, inner, heads = at.to_q.in_features, at.inner, at.heads
-        dev = x.device
+        dev = x[0].device
+        split = self._split
         n_ms = len(at.to_qkv_multiscale)
         wide = 3 * inner * (1 + n_ms)
         qkv = torch.empty(M, wide, device=dev, dtype=torch.float32)
@@ -349,24 +381,23 @@ class AutoencoderDC(ModelMixin):
             hip.sphere_dwconv_nhwc(qkv, self._plan[id(ms.proj_in)], dw, B=B, H=H, W=W, C=3 * inner, ldx=wide, ksize=ms.proj_in.kernel_size[0])
             hip.grouped_conv1x1_nhwc(dw, self._plan[id(ms.proj_out)], qkv[:, 3 * inner * (1 + s) :], M=M, groups=3 * heads, ldx=3 * inner, ldy=wide)
         groups = wide // 96  # consecutive 96-channel groups of the concat, split (q, k, v) -- models/DCAE.py:239-243 (Q8)
-        att = torch.empty(M, groups * 32, device=dev, dtype=torch.float32)
-        hip.relu_linear_attn_nhwc(qkv, att, B=B, P=H * W, groups=groups, ldq=wide, ldy=groups * 32, eps=at.eps)
+        att = torch.empty(M, groups * 32, device=dev, dtype=torch.float32)  # only to_out reads it: split rows in the bf16x3 mode
+        hip.relu_linear_attn_nhwc(qkv, att, B=B, P=H * W, groups=groups, ldq=wide, ldy=groups * 32, eps=at.eps,
+                                  out_fmt=hip.FMT_SPLIT if split else hip.FMT_F32)
         o = torch.empty(M, C, device=dev, dtype=torch.float32)
-        self._mm(att, id(at.to_out), at.to_out.weight, o, B, H, W, N=C, K=groups * 32)
-        y = torch.empty_like(o)
-        hip.rmsnorm_rows(o, at.norm_out.weight, y, rows=M, C=C, eps=at.norm_out.eps, b=at.norm_out.bias, resid=x)
+        self._mm((None, att) if split else (att, None), id(at.to_out), at.to_out.weight, o, B, H, W, N=C, K=groups * 32)
+        y = self._norm(o, at.norm_out, x[0], M, C)
         # GLUMBConv, models/DCAE.py:304-324
         g = blk.conv_out
         hid2 = g.conv_inverted.out_channels
         h1 = torch.empty(M, hid2, device=dev, dtype=torch.float32)
         self._mm(y, id(g.conv_inverted), self._plan[id(g.conv_inverted)], h1, B, H, W, N=hid2, K=C, bias=g.conv_inverted.bias, act=hip.ACT_SILU)
-        h2 = torch.empty(M, hid2 // 2, device=dev, dtype=torch.float32)
-        hip.sphere_dwconv_nhwc(h1, self._plan[id(g.conv_depth)], h2, B=B, H=H, W=W, C=hid2, bias=g.conv_depth.bias, ksize=3, glu=True)
+        h2 = torch.empty(M, hid2 // 2, device=dev, dtype=torch.float32)  # only conv_point reads it
+        hip.sphere_dwconv_nhwc(h1, self._plan[id(g.conv_depth)], h2, B=B, H=H, W=W, C=hid2, bias=g.conv_depth.bias, ksize=3, glu=True,
+                               out_fmt=hip.FMT_SPLIT if split else hip.FMT_F32)
         h3 = torch.empty(M, C, device=dev, dtype=torch.float32)
-        self._mm(h2, id(g.conv_point), self._plan[id(g.conv_point)], h3, B, H, W, N=C, K=hid2 // 2)
-        out = torch.empty_like(h3)
-        hip.rmsnorm_rows(h3, g.norm.weight, out, rows=M, C=C, eps=g.norm.eps, b=g.norm.bias, resid=y)
-        return out
+        self._mm((None, h2) if split else (h2, None), id(g.conv_point), self._plan[id(g.conv_point)], h3, B, H, W, N=C, K=hid2 // 2)
+        return self._norm(h3, g.norm, y[0], M, C)
 
     def _run_blocks(self, blocks, x, B, H, W):
         for blk in blocks:
@@ -376,17 +407,27 @@ class AutoencoderDC(ModelMixin):
                 x = self._evit(blk, x, B, H, W)
             elif isinstance(blk, DCDownBlock2d):
                 cv = self._conv(x, B, H, W, blk.conv)
-                y = torch.empty(B * (H // 2) * (W // 2), blk.out_channels, device=x.device, dtype=torch.float32)
-                hip.pixel_unshuffle_shortcut(cv, x, y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels)
-                x, H, W = y, H // 2, W // 2
+                M2 = B * (H // 2) * (W // 2)
+                y = torch.empty(M2, blk.out_channels, device=cv.device, dtype=torch.float32)
+                ys = self._srows(M2, blk.out_channels, cv.device)
+                hip.pixel_unshuffle_shortcut(cv, x[0], y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys)
+                x, H, W = (y, ys), H // 2, W // 2
             elif isinstance(blk, DCUpBlock2d):
                 cv = self._conv(x, B, H, W, blk.conv)
-                y = torch.empty(B * 4 * H * W, blk.out_channels, device=x.device, dtype=torch.float32)
-                hip.pixel_shuffle_shortcut(cv, x, y, B=B, H=H, W=W, cout=blk.out_channels, cin=blk.in_channels)
-                x, H, W = y, 2 * H, 2 * W
+                y = torch.empty(B * 4 * H * W, blk.out_channels, device=cv.device, dtype=torch.float32)
+                ys = self._srows(B * 4 * H * W, blk.out_channels, cv.device)
+                hip.pixel_shuffle_shortcut(cv, x[0], y, B=B, H=H, W=W, cout=blk.out_channels, cin=blk.in_channels, ys=ys)
+                x, H, W = (y, ys), 2 * H, 2 * W
             else:
                 raise TypeError(type(blk))
         return x, H, W
+
+    def _stream(self, x32, M, C):
+        """fp32 rows -> stream tensor (bf16x3 mode: + the split copy)"""
+        xs = self._srows(M, C, x32.device)
+        if xs is not None:
+            hip.split_rows(x32, xs, rows=M, C=C, ldx=x32.shape[1], lds=xs.shape[1])
+        return x32, xs
 
     def _encode_launch(self, x, st=None):
         """kernel launches only (capturable): NCHW fp32 device tensors -> latent (B, lc, H/8, W/8)"""
@@ -400,11 +441,11 @@ class AutoencoderDC(ModelMixin):
         hip.chan_to_token(x, tok, B=B, C=C, N=H * W, ldo=cp, fill_cols=C if cs else cp)
         if cs:
             hip.chan_to_token(st, tok[:, C:], B=B, C=cs, N=H * W, ldo=cp, fill_cols=cp - C)
-        h = self._conv(tok, B, H, W, enc.conv_in)
-        h, H, W = self._run_blocks(enc.down_blocks, h, B, H, W)
+        h = self._conv(self._stream(tok, B * H * W, cp), B, H, W, enc.conv_in)
+        h, H, W = self._run_blocks(enc.down_blocks, self._stream(h, B * H * W, enc.conv_in.out_channels), B, H, W)
         lc = enc.conv_out.out_channels
         sc = torch.empty(B * H * W, lc, device=dev, dtype=torch.float32)
-        hip.chan_regroup(h, sc, M=B * H * W, cin=enc.conv_out.in_channels, cout=lc)  # out shortcut, :624-627
+        hip.chan_regroup(h[0], sc, M=B * H * W, cin=enc.conv_out.in_channels, cout=lc)  # out shortcut, :624-627
         z = self._conv(h, B, H, W, enc.conv_out, R=sc)
         out = torch.empty(B, lc, H, W, device=dev, dtype=torch.float32)
         hip.token_to_chan(z, out, B=B, C=lc, N=H * W, ldi=lc)
@@ -420,10 +461,9 @@ class AutoencoderDC(ModelMixin):
         c0 = dec.conv_in.out_channels
         rep = torch.empty(B * H * W, c0, device=dev, dtype=torch.float32)
         hip.chan_regroup(tok, rep, M=B * H * W, cin=C, cout=c0)
-        h = self._conv(tok, B, H, W, dec.conv_in, R=rep)  # in shortcut = repeat_interleave, :720-722
-        h, H, W = self._run_blocks(dec.up_blocks, h, B, H, W)
-        n = torch.empty_like(h)
-        hip.rmsnorm_rows(h, dec.norm_out.weight, n, rows=B * H * W, C=dec.norm_out.weight.numel(), eps=dec.norm_out.eps, b=dec.norm_out.bias, act=hip.ACT_RELU)
+        h = self._conv(self._stream(tok, B * H * W, C), B, H, W, dec.conv_in, R=rep)  # in shortcut = repeat_interleave, :720-722
+        h, H, W = self._run_blocks(dec.up_blocks, self._stream(h, B * H * W, c0), B, H, W)
+        n = self._norm(h[0], dec.norm_out, None, B * H * W, dec.norm_out.weight.numel(), act=hip.ACT_RELU, want32=False)  # only conv_out reads it
         y = self._conv(n, B, H, W, dec.conv_out)
         co = dec.conv_out.out_channels
         keep = co

@@ -233,6 +233,126 @@ def test_sphere_conv_bf16x3_vs_oracle(ci, co, k, B, H, W):
     assert rel_l2(got[:, :, 0], want[:, :, 0]) < 1e-5 and rel_l2(got[:, :, -1], want[:, :, -1]) < 1e-5  # pole rows
 
 
+def _unsplit(buf, rows, cols):
+    """split rows (every 32 bytes = [hi x8 | lo x8] bf16) -> (hi, lo) fp32 [rows, cols], cols = the padded width"""
+    w = buf.detach().cpu().contiguous().view(torch.int16).reshape(rows, cols // 8, 2, 8)
+    f = (w.to(torch.int32) << 16).view(torch.float32)
+    return f[:, :, 0].reshape(rows, cols), f[:, :, 1].reshape(rows, cols)
+
+
+def _split_ref(x):
+    hi = x.bfloat16().float()
+    return hi, (x - hi).bfloat16().float()
+
+
+def _check_split_rows(ys, want, C):
+    """ys: device split rows [rows, C8]; want: fp32 [rows, C] the producer's fp32 output - bitwise the hi / lo split of it, pad zero"""
+    rows, c8 = ys.shape
+    hi, lo = _unsplit(ys, rows, c8)
+    wh, wl = _split_ref(want.cpu())
+    assert torch.equal(hi[:, :C], wh) and torch.equal(lo[:, :C], wl)
+    assert (hi[:, C:] == 0).all() and (lo[:, C:] == 0).all()
+
+
+@pytest.mark.parametrize("ci,co,k,B,H,W", [(8, 8, 3, 2, 9, 16), (252, 252, 3, 1, 30, 60), (96, 252, 3, 1, 12, 24), (504, 252, 3, 2, 15, 30),
+                                            (12, 20, 5, 1, 7, 12), (1008, 1008, 3, 1, 15, 30), (252, 252, 3, 1, 120, 240), (84, 1008, 3, 3, 15, 30),
+                                            (1008, 3024, 1, 1, 15, 30), (2016, 504, 1, 2, 30, 60), (252, 92, 3, 5, 16, 32)])
+def test_sphere_conv_split_vs_oracle(ci, co, k, B, H, W):
+    """the pre-split implicit-GEMM SphereConv2d (ldc_sphere_conv_nhwc_split, the DCAE's bf16x3 path): split rows in (channel counts
+    4 mod 8 with zero pad columns), pole rows, wrap, several images per launch, bias + activation + residual, fp32 rows and split
+    rows out; 1e-5 like the bf16x3 GEMM.  k = 1: the pointwise convs / Linears."""
+    import ladcast_amd.hip as hip
+    from ladcast_amd.models.sphere_conv import pack_dense_weight_bf16x3
+    from oracle.sphere_conv import SphereConv2d as OSC
+
+    M = B * H * W
+    x, res = rnd(B, ci, H, W, seed=3), rnd(B, co, H, W, seed=4)
+    if k > 1:
+        o = OSC(ci, co, k, 1, k // 2, bias=True)
+        with torch.no_grad():
+            o.weight.copy_(rnd(*o.weight.shape, seed=1) / (ci * k * k) ** 0.5)
+            o.bias.copy_(rnd(co, seed=2))
+            want = torch.nn.functional.silu(o(x)) + res
+        w4, bias = o.weight, o.bias
+    else:
+        w4, bias = rnd(co, ci, 1, 1, seed=1) / ci ** 0.5, rnd(co, seed=2)
+        want = torch.nn.functional.silu(torch.einsum("oc,bchw->bohw", w4[:, :, 0, 0].double(), x.double()) + bias.double()[None, :, None, None]).float() + res
+    c8 = -(-ci // 8) * 8
+    xs = torch.full((M, c8), float("nan"), device="cuda")
+    hip.split_rows(x.cuda().permute(0, 2, 3, 1).reshape(M, ci).contiguous(), xs, rows=M, C=ci)
+    r = res.cuda().permute(0, 2, 3, 1).reshape(M, co).contiguous()
+    wp = pack_dense_weight_bf16x3(w4.detach().cuda())
+    y = torch.full((M, co), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_split(xs, wp, y, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, bias=bias.detach().cuda(), R=r, ldr=co, ksize=k, act=hip.ACT_SILU)
+    got = y.reshape(B, H, W, co).permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 1e-5
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 1e-5 and rel_l2(got[:, :, -1], want[:, :, -1]) < 1e-5  # pole rows
+    # split rows out: bitwise the split of the fp32 rows (same accumulators, same epilogue), pad columns zero
+    o8 = -(-co // 8) * 8
+    ys = torch.full((M, o8), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_split(xs, wp, ys, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, ldy=o8, bias=bias.detach().cuda(), R=r, ldr=co, ksize=k,
+                               act=hip.ACT_SILU, out_fmt=hip.FMT_SPLIT)
+    _check_split_rows(ys, y, co)
+
+
+def test_dcae_split_row_producers():
+    """every producer of a conv operand writes the split rows itself: bitwise the hi / lo split of its fp32 output, pad columns
+    (C = 4 mod 8) zero"""
+    import ladcast_amd.hip as hip
+
+    # RMSNorm rows: fp32 + split, split only
+    for C in (252, 504, 8):
+        xr, w, b, r = rnd(37, C, seed=5), rnd(C, seed=6), rnd(C, seed=7), rnd(37, C, seed=8)
+        c8 = -(-C // 8) * 8
+        y, ys, ys2 = torch.empty(37, C, device="cuda"), torch.full((37, c8), float("nan"), device="cuda"), torch.full((37, c8), float("nan"), device="cuda")
+        hip.rmsnorm_rows(xr.cuda(), w.cuda(), y, rows=37, C=C, eps=1e-5, b=b.cuda(), resid=r.cuda(), act=hip.ACT_RELU, ys=ys)
+        want = F.relu(xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w + b + r)
+        assert rel_l2(y.cpu(), want) < 1e-6
+        _check_split_rows(ys, y, C)
+        hip.rmsnorm_rows(xr.cuda(), w.cuda(), None, rows=37, C=C, eps=1e-5, b=b.cuda(), resid=r.cuda(), act=hip.ACT_RELU, ys=ys2)
+        assert torch.equal(ys2.view(torch.int32), ys.view(torch.int32))
+    # pixel (un)shuffle shortcuts
+    B, H, W, C = 2, 6, 8, 16
+    x = rnd(B, C, H, W, seed=1)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    for cout in (32, 20):  # 20: 4 mod 8 (pad), cin * 4 % cout == 0 needs C = 20 g / 4 -> use C = 20 for it
+        Cx = 16 if cout == 32 else 20
+        xx = rnd(B, Cx, H, W, seed=11)
+        cv = rnd(B, cout // 4, H, W, seed=2)
+        want = F.pixel_unshuffle(cv, 2) + F.pixel_unshuffle(xx, 2).unflatten(1, (-1, Cx * 4 // cout)).mean(dim=2)
+        M2 = B * (H // 2) * (W // 2)
+        y, ys = torch.empty(M2, cout, device="cuda"), torch.full((M2, -(-cout // 8) * 8), float("nan"), device="cuda")
+        hip.pixel_unshuffle_shortcut(cv.permute(0, 2, 3, 1).contiguous().cuda(), xx.permute(0, 2, 3, 1).contiguous().cuda(), y, B=B, H2=H // 2,
+                                     W2=W // 2, cout=cout, cin=Cx, ys=ys)
+        assert rel_l2(y.cpu().reshape(B, H // 2, W // 2, cout).permute(0, 3, 1, 2), want) < 1e-6
+        _check_split_rows(ys, y, cout)
+    for cout in (8, 12):
+        cv = rnd(B, cout * 4, H, W, seed=3)
+        Cx = 16 if cout == 8 else 24
+        xx = rnd(B, Cx, H, W, seed=12)
+        want = F.pixel_shuffle(cv, 2) + F.pixel_shuffle(xx.repeat_interleave(cout * 4 // Cx, dim=1), 2)
+        M4 = B * 4 * H * W
+        y, ys = torch.empty(M4, cout, device="cuda"), torch.full((M4, -(-cout // 8) * 8), float("nan"), device="cuda")
+        hip.pixel_shuffle_shortcut(cv.permute(0, 2, 3, 1).contiguous().cuda(), xx.permute(0, 2, 3, 1).contiguous().cuda(), y, B=B, H=H, W=W,
+                                   cout=cout, cin=Cx, ys=ys)
+        assert rel_l2(y.cpu().reshape(B, 2 * H, 2 * W, cout).permute(0, 3, 1, 2), want) < 1e-6
+        _check_split_rows(ys, y, cout)
+    # ReLU linear attention and the GLU depthwise conv: split rows = split of their fp32 rows
+    Bq, P, groups = 2, 450, 6
+    qkv = rnd(Bq, P, groups * 96, seed=1).cuda()
+    y, ys = torch.empty(Bq * P, groups * 32, device="cuda"), torch.full((Bq * P, groups * 32), float("nan"), device="cuda")
+    hip.relu_linear_attn_nhwc(qkv, y, B=Bq, P=P, groups=groups, ldq=groups * 96, ldy=groups * 32, eps=1e-15)
+    hip.relu_linear_attn_nhwc(qkv, ys, B=Bq, P=P, groups=groups, ldq=groups * 96, ldy=groups * 32, eps=1e-15, out_fmt=hip.FMT_SPLIT)
+    _check_split_rows(ys, y, groups * 32)
+    Cd = 64
+    xd, wd, bd = rnd(2 * 9 * 16, Cd, seed=4).cuda(), rnd(9, Cd, seed=5).cuda(), rnd(Cd, seed=6).cuda()
+    y, ys = torch.empty(2 * 9 * 16, Cd // 2, device="cuda"), torch.full((2 * 9 * 16, Cd // 2), float("nan"), device="cuda")
+    hip.sphere_dwconv_nhwc(xd, wd, y, B=2, H=9, W=16, C=Cd, bias=bd, ksize=3, glu=True)
+    hip.sphere_dwconv_nhwc(xd, wd, ys, B=2, H=9, W=16, C=Cd, bias=bd, ksize=3, glu=True, out_fmt=hip.FMT_SPLIT)
+    _check_split_rows(ys, y, Cd // 2)
+
+
 def test_dcae_bf16x3_mode_matches_oracle():
     """AutoencoderDC.set_gemm_precision('bf16x3'): dense 3x3 convs as split-bf16 implicit GEMMs; tiny config (both paths of
     the encoder / decoder) and one full 84 x 120 x 240 frame; tolerance 5e-5 (~40 conv layers at ~4e-6 each, fp32 budget 1e-4)"""

@@ -1,10 +1,10 @@
 """Print the kernel timeline of the last forward found in a rocprofv3 kernel trace csv (development aid)."""
-import csv, glob, sys
+import csv, glob, os, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "chan_to_token" in r["Kernel_Name"]]
-seq = rows[idx[-2]:]
+seq = rows[idx[int(os.environ.get("TRACE_START", "-2"))]:]  # TRACE_START=-1: the DCAE decode of tools/dcae_one.py
 t0 = int(seq[0]["Start_Timestamp"]); prev_end = t0
 agg = {}
 for r in seq:
