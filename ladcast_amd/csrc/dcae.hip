@@ -68,127 +68,234 @@ __global__ __launch_bounds__(256) void sphere_dwconv_kernel(const float* __restr
     *reinterpret_cast<float4*>(y + static_cast<long long>(pix) * ldy + c0) = a0;
 }
 
+// The same depthwise conv, register-tiled along the image row: one thread = one float4 of channels x 8 consecutive pixels.  For a
+// fixed output row the sphere padding rule is a per-kernel-row (source row, column shift, left-right flip), so kernel row ky needs
+// the contiguous (mod W) run of 8 + KS - 1 source pixels starting at w0 - p - shift, and a flipped kernel row reads it with kx
+// mirrored: 12 (10) float4 loads per kernel row feed 8 x KS multiply-adds, 4.7x (3.7x) fewer loads per output than one load per
+// tap and output - the untiled kernel is bound by exactly those (L1 / L2 request rate).  Needs W >= 8 + KS - 1 (one wrap).
+template <int KS, bool GLU>
+__global__ __launch_bounds__(256) void sphere_dwconv_row_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                                int C, int ldx, int ldy, int out_fmt, long long total) {
+  constexpr int P = KS / 2, PW = 8 + 2 * P;
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int half = C >> 1;
+  const int nvec = (GLU ? half : C) >> 2;
+  const int c0 = static_cast<int>(idx % nvec) * 4;
+  const long long seg = idx / nvec;
+  const int nseg = (W + 7) >> 3;
+  const int w0 = static_cast<int>(seg % nseg) * 8;
+  const long long bh = seg / nseg;
+  const int h = static_cast<int>(bh % H);
+  const float* img = x + (bh - h) * W * static_cast<long long>(ldx);  // first pixel of this image
+  float4 acc[8], gate[8];
+#pragma unroll
+  for (int gi = 0; gi < (GLU ? 2 : 1); ++gi) {
+    const int g = GLU ? 1 - gi : 0;  // GLU: the gate half first
+    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + g * half + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = b4;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {  // not unrolled: one kernel row's patch (12 float4) in registers at a time
+      int r = h + ky - P, shift = 0;
+      if (r < 0) {
+        r = -1 - r;
+        shift = W >> 1;
+      } else if (r >= H) {
+        r = 2 * H - 1 - r;
+        shift = W >> 1;
+      }
+      // a kernel row that reaches over the pole is applied left-right flipped: mirror the WEIGHT index, not the patch index
+      const bool flip = (h == 0 && ky < P) || (h == H - 1 && ky >= KS - P);
+      int col0 = w0 - P - shift;
+      if (col0 < 0) col0 += W;
+      const float* rowp = img + static_cast<long long>(r) * W * ldx + g * half + c0;
+      float4 pt[PW];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        int col = col0 + j;
+        if (col >= W) col -= W;
+        pt[j] = *reinterpret_cast<const float4*>(rowp + static_cast<long long>(col) * ldx);
+      }
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int kw = flip ? KS - 1 - kx : kx;
+        const float4 w4 = *reinterpret_cast<const float4*>(wt + static_cast<long long>(ky * KS + kw) * C + g * half + c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f4_fma(pt[i + kx], w4, acc[i]);
+      }
+    }
+    if (GLU && gi == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gate[i] = make_float4(ldc_silu(acc[i].x), ldc_silu(acc[i].y), ldc_silu(acc[i].z), ldc_silu(acc[i].w));
+    }
+  }
+  float* yrow = y + ((bh * W) + w0) * static_cast<long long>(ldy);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (w0 + i >= W) break;
+    float4 o = acc[i];
+    if (GLU) {
+      o.x *= gate[i].x;
+      o.y *= gate[i].y;
+      o.z *= gate[i].z;
+      o.w *= gate[i].w;
+    }
+    float* yr = yrow + static_cast<long long>(i) * ldy;
+    if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yr), c0, o.x, o.y, o.z, o.w);
+    else *reinterpret_cast<float4*>(yr + c0) = o;
+  }
+}
+
 // grouped 1x1 conv, 32 -> 32 channels per group: y[m][g*32+o] = sum_i W[g*32+o][i] * x[m][g*32+i]
-// block = 8 pixels x one group; the group's 32x32 weights and the 8x32 inputs sit in LDS.
+// block = 64 pixels x one group: thread (o, pixel phase) keeps its output channel's 32 weights in registers and reads the inputs
+// from LDS (one broadcast read per multiply-add) - the weights are fetched once per 64 pixels
 __global__ __launch_bounds__(256) void grouped_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                               float* __restrict__ y, int M, int ldx, int ldy) {
-  __shared__ float ws[32][33];
-  __shared__ float xs[8][32];
+  __shared__ float xs[64][32];
   const int g = blockIdx.y;
-  const int m0 = blockIdx.x * 8;
+  const int m0 = blockIdx.x * 64;
   const int t = threadIdx.x;
-  for (int i = t; i < 1024; i += 256) ws[i >> 5][i & 31] = wt[static_cast<long long>(g * 32 + (i >> 5)) * 32 + (i & 31)];
-  {
-    const int pm = t >> 5, ci = t & 31;
-    xs[pm][ci] = (m0 + pm < M) ? x[static_cast<long long>(m0 + pm) * ldx + g * 32 + ci] : 0.f;
+  const int pm = t >> 5, o = t & 31;
+  float w[32];
+#pragma unroll
+  for (int i = 0; i < 32; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(wt + static_cast<long long>(g * 32 + o) * 32 + i);
+    w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int m = m0 + 8 * s + pm;
+    xs[8 * s + pm][o] = (m < M) ? x[static_cast<long long>(m) * ldx + g * 32 + o] : 0.f;
   }
   __syncthreads();
-  const int pm = t >> 5, o = t & 31;
-  if (m0 + pm >= M) return;
-  float acc = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc = fmaf(ws[o][i], xs[pm][i], acc);
-  y[static_cast<long long>(m0 + pm) * ldy + g * 32 + o] = acc;
+  for (int s = 0; s < 8; ++s) {
+    const int m = m0 + 8 * s + pm;
+    if (m >= M) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc = fmaf(w[i], xs[8 * s + pm][i], acc);
+    y[static_cast<long long>(m) * ldy + g * 32 + o] = acc;
+  }
 }
 
 // ReLU linear attention of one (batch, 96-channel group): q = ch 0..31, k = 32..63, v = 64..95
 //   KV[c][j] = sum_p vpad[p][c] relu(k[p][j]), c = 0..32 (row 32 = ones);  out[p][c] = sum_j KV[c][j] relu(q[p][j])
 //   y[p][c] = out[p][c] / (out[p][32] + eps)                 (models/DCAE.py:158-175,239-249; fp32)
-// Two launches so that one frame (63 groups) still fills the chip: (1) partial KV over a slice of the pixels per
-// workgroup, (2) per 64 pixels: add the slices' partials in order (deterministic) and apply.
+// ONE launch, one 16-wave workgroup per (batch, group), both contractions on the fp32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32
+// products, fp32 accumulation - the reference's fp32 island stays fp32):
+//   phase 1: wave w takes the pixel pairs w, w + 16, ...: one MFMA per pair, A[c][k] = v[p_k][c], B[k][j] = relu(k[p_k][j]) - lanes
+//            0-31 / 32-63 hold the two pixels, one coalesced 128-byte load per operand; the ones row (sum of relu(k)) rides along as
+//            a per-lane sum.  The 16 partial 33 x 32 matrices are added in wave order through LDS (deterministic).
+//   phase 2: per 32 pixels, out^T[c][p] = sum_j KV[c][j] relu(q[p][j]) as 16 MFMAs: lane (p, half h) loads q[p][16 h .. 16 h + 15]
+//            (64 contiguous bytes) and MFMA kk contracts j = kk (h = 0) with j = 16 + kk (h = 1) - any pairing of j with the two
+//            k slots works when A uses the same one; the accumulator layout gives a lane 4 x 4 consecutive channels of its pixel
+//            -> float4 (or split-format) stores; the denominator is a 16-term dot product per lane + one cross-half add.
+// A frame has 30 / 62 groups: 30 - 62 busy CUs, each streaming its group's 0.2 - 0.9 MB once per phase (8 / 6 us at one 30 x 60 /
+// 15 x 30 frame, against 70 / 39 us for the earlier slice-partials / apply launches); from 5 - 9 frames on every CU has a workgroup.
 constexpr int KV_N = 33 * 32;
+constexpr int RLA_WAVES = 16;
 
-__global__ __launch_bounds__(256) void relu_linear_attn_kv_kernel(const float* __restrict__ qkv, float* __restrict__ part, int P,
-                                                                  int ldq, int pix_per_wg) {
-  __shared__ float tile[64][97];  // 64 pixels x 96 channels (+1 pad)
-  const int sl = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x;
+__global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const float* __restrict__ qkv, float* __restrict__ y, int P,
+                                                                          int ldq, int ldy, float eps, int out_fmt) {
+  extern __shared__ __attribute__((aligned(16))) float rla_smem[];
+  float* red = rla_smem;                      // [RLA_WAVES][KV_N] partial KV
+  float* kv = rla_smem + RLA_WAVES * KV_N;    // [33][32]
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int n = lane & 31, h = lane >> 5;
   const float* base = qkv + static_cast<long long>(b) * P * ldq + g * 96;
-  const int p_begin = sl * pix_per_wg;
-  const int p_end = min(P, p_begin + pix_per_wg);
-  // each thread owns up to 5 (c, j) entries of KV: e = t + 256*i < 1056
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
-    for (int i = t; i < 64 * 96; i += 256) {
-      const int pp = i / 96, ch = i - pp * 96;
-      float v = (p0 + pp < p_end) ? base[static_cast<long long>(p0 + pp) * ldq + ch] : 0.f;
-      if (ch >= 32 && ch < 64) v = fmaxf(v, 0.f);  // relu(k)
-      tile[pp][ch] = v;
-    }
-    __syncthreads();
-    const int np = min(64, p_end - p0);
+  // ---- phase 1 ----
+  f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = t + 256 * i;
-      if (e < KV_N) {
-        const int c = e >> 5, j = e & 31;
-        float s = acc[i];
-        if (c < 32) {
-          for (int pp = 0; pp < np; ++pp) s = fmaf(tile[pp][64 + c], tile[pp][32 + j], s);
-        } else {
-          for (int pp = 0; pp < np; ++pp) s += tile[pp][32 + j];
-        }
-        acc[i] = s;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ksum = 0.f;
+  const int npair = (P + 1) >> 1;
+  constexpr int UN = 16;  // pairs per trip: their 2 UN loads are in flight together (the loop is bound by memory latency, not by the MFMAs)
+  for (int i0 = wave; i0 < npair; i0 += UN * RLA_WAVES) {
+    float kk[UN], vv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = 2 * (i0 + u * RLA_WAVES) + h;
+      kk[u] = 0.f;
+      vv[u] = 0.f;
+      if (p < P) {
+        const float* row = base + static_cast<long long>(p) * ldq;
+        kk[u] = fmaxf(row[32 + n], 0.f);
+        vv[u] = row[64 + n];
       }
     }
-    __syncthreads();
-  }
-  float* dst = part + ((static_cast<long long>(b) * gridDim.y + g) * gridDim.x + sl) * KV_N;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int e = t + 256 * i;
-    if (e < KV_N) dst[e] = acc[i];
-  }
-}
-
-__global__ __launch_bounds__(256) void relu_linear_attn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ part,
-                                                                     float* __restrict__ y, int P, int ldq, int ldy, float eps,
-                                                                     int nslice, int out_fmt) {
-  __shared__ float kv[33][32];
-  const int g = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x;
-  const float* src = part + (static_cast<long long>(b) * gridDim.y + g) * nslice * KV_N;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int e = t + 256 * i;
-    if (e < KV_N) {
-      float s = 0.f;
-      for (int sl = 0; sl < nslice; ++sl) s += src[static_cast<long long>(sl) * KV_N + e];
-      kv[e >> 5][e & 31] = s;
+    for (int u = 0; u < UN; ++u) {
+      ksum += kk[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[u], kk[u], acc, 0, 0, 0);
     }
+  }
+  ksum += __shfl_xor(ksum, 32, 64);
+  {
+    float* mine = red + wave * KV_N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r >> 2) * 8 + h * 4 + (r & 3)) * 32 + n] = acc[r];  // KV[c][j = n]
+    if (h == 0) mine[32 * 32 + n] = ksum;
   }
   __syncthreads();
-  // 64 pixels per workgroup, 4 threads per pixel: thread (pixel, quarter) writes channels [8 quarter, 8 quarter + 8)
-  const int p = blockIdx.x * 64 + (t >> 2), qt = t & 3;
-  if (p >= P) return;
-  const float* qp = qkv + static_cast<long long>(b) * P * ldq + g * 96 + static_cast<long long>(p) * ldq;
-  float q[32];
+  for (int e = tid; e < KV_N; e += RLA_WAVES * 64) {
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; j += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(qp + j);
-    q[j] = fmaxf(v.x, 0.f);
-    q[j + 1] = fmaxf(v.y, 0.f);
-    q[j + 2] = fmaxf(v.z, 0.f);
-    q[j + 3] = fmaxf(v.w, 0.f);
+    for (int w = 0; w < RLA_WAVES; ++w) s += red[w * KV_N + e];
+    kv[e] = s;
   }
-  float den = 0.f;
+  __syncthreads();
+  // ---- phase 2 ----
+  float ka[16], kd[16];  // A operands: KV[c = n][16 h + kk]; denominator weights KV[32][16 h + kk]
 #pragma unroll
-  for (int j = 0; j < 32; ++j) den = fmaf(kv[32][j], q[j], den);
-  const float inv = 1.0f / (den + eps);
-  float* yrow = y + static_cast<long long>(b) * P * ldy + static_cast<long long>(p) * ldy;
-  const int ch = g * 32 + 8 * qt;  // this thread's 8 channels: one group of the split format
+  for (int kk = 0; kk < 16; ++kk) {
+    ka[kk] = kv[n * 32 + 16 * h + kk];
+    kd[kk] = kv[32 * 32 + 16 * h + kk];
+  }
+  const int ntile = (P + 31) >> 5;
+  auto load_q = [&](int t, float4 (&dst)[4]) {  // q[p][16 h .. 16 h + 15] of pixel p = 32 t + n (clamped)
+    const int p = 32 * t + n;
+    const float* qp = base + static_cast<long long>(p < P ? p : P - 1) * ldq + 16 * h;
 #pragma unroll
-  for (int c = 0; c < 8; c += 4) {
-    float o[4];
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const float4*>(qp + 4 * i);
+  };
+  float4 qn[4];
+  if (wave < ntile) load_q(wave, qn);
+  for (int t = wave; t < ntile; t += RLA_WAVES) {
+    const int p = 32 * t + n;
+    float q[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) s = fmaf(kv[8 * qt + c + u][j], q[j], s);
-      o[u] = s * inv;
+    for (int i = 0; i < 4; ++i) {
+      q[4 * i] = fmaxf(qn[i].x, 0.f);
+      q[4 * i + 1] = fmaxf(qn[i].y, 0.f);
+      q[4 * i + 2] = fmaxf(qn[i].z, 0.f);
+      q[4 * i + 3] = fmaxf(qn[i].w, 0.f);
     }
-    if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yrow), ch + c, o[0], o[1], o[2], o[3]);
-    else *reinterpret_cast<float4*>(yrow + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (t + RLA_WAVES < ntile) load_q(t + RLA_WAVES, qn);  // the next tile's loads fly under this tile's MFMAs
+    float den = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) den = fmaf(kd[kk], q[kk], den);
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.0f / (den + eps);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk], q[kk], o, 0, 0, 0);  // out^T[c][p = n]
+    if (p < P) {
+      float* yrow = y + (static_cast<long long>(b) * P + p) * ldy;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int ch = g * 32 + 8 * r4 + 4 * h;
+        const float o0 = o[4 * r4] * inv, o1 = o[4 * r4 + 1] * inv, o2 = o[4 * r4 + 2] * inv, o3 = o[4 * r4 + 3] * inv;
+        if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yrow), ch, o0, o1, o2, o3);
+        else *reinterpret_cast<float4*>(yrow + ch) = make_float4(o0, o1, o2, o3);
+      }
+    }
   }
 }
 
@@ -364,9 +471,18 @@ extern "C" int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const
   LDC_CHECK_ALIGN16(y);
   const long long pix = static_cast<long long>(B) * H * W;
   if (pix > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (W >= 8 + ksize - 1) {  // register-tiled kernel: 8 pixels of an image row per thread
+    const long long total = static_cast<long long>(B) * H * ldc_cdiv(W, 8) * ((glu ? C / 2 : C) / 4);
+    const dim3 tg(static_cast<unsigned>((total + 255) / 256));
+    if (ksize == 3 && glu) hipLaunchKernelGGL((sphere_dwconv_row_kernel<3, true>), tg, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt, total);
+    else if (ksize == 3) hipLaunchKernelGGL((sphere_dwconv_row_kernel<3, false>), tg, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt, total);
+    else if (glu) hipLaunchKernelGGL((sphere_dwconv_row_kernel<5, true>), tg, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt, total);
+    else hipLaunchKernelGGL((sphere_dwconv_row_kernel<5, false>), tg, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt, total);
+    return ldc_launch_status();
+  }
   const int nvec = (glu ? C / 2 : C) / 4;
   dim3 grid(ldc_cdiv(nvec, 256), static_cast<unsigned>(pix));
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (ksize == 3 && glu) hipLaunchKernelGGL((sphere_dwconv_kernel<3, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
   else if (ksize == 3) hipLaunchKernelGGL((sphere_dwconv_kernel<3, false>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
   else if (glu) hipLaunchKernelGGL((sphere_dwconv_kernel<5, true>), grid, dim3(256), 0, s, x, wt, bias, y, H, W, C, ldx, ldy, out_fmt);
@@ -380,23 +496,19 @@ extern "C" int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* 
   LDC_CHECK_PTR(wt);
   LDC_CHECK_PTR(y);
   if (M <= 0 || groups <= 0 || groups > 65535) return LDC_ERR_ARG;
-  dim3 grid(ldc_cdiv(M, 8), groups);
+  LDC_CHECK_ALIGN16(wt);
+  dim3 grid(ldc_cdiv(M, 64), groups);
   hipLaunchKernelGGL(grouped_conv1x1_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, wt, y,
                      static_cast<int>(M), ldx, ldy);
   return ldc_launch_status();
 }
 
-// pixel slices per (batch, group) of the KV pass: enough workgroups to fill the chip, at most one per 64 pixels
-static int relu_attn_slices(int B, int P, int groups) {
-  const int tiles = ldc_cdiv(P, 64);
-  long long want = 2048 / (static_cast<long long>(B) * groups);
-  if (want < 1) want = 1;
-  return static_cast<int>(want < tiles ? want : tiles);
-}
-
+// (the kernel needs no scratch since round 2: kept for callers that size a workspace; returns 0)
 extern "C" long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups) {
-  if (B <= 0 || P <= 0 || groups <= 0) return 0;
-  return static_cast<long long>(B) * groups * relu_attn_slices(B, P, groups) * KV_N * static_cast<long long>(sizeof(float));
+  (void)B;
+  (void)P;
+  (void)groups;
+  return 0;
 }
 
 extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
@@ -406,27 +518,26 @@ extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int 
 
 extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                                              int out_fmt, void* workspace, long long workspace_bytes, void* stream) {
+  (void)workspace;  // unused (may be NULL)
+  (void)workspace_bytes;
   LDC_CHECK_PTR(qkv);
   LDC_CHECK_PTR(y);
-  LDC_CHECK_PTR(workspace);
   if (B <= 0 || P <= 0 || groups <= 0) return LDC_ERR_ARG;
   if ((ldq & 3) || (ldy & 3)) return LDC_ERR_ALIGN;
-  if (groups > 65535 || B > 65535) return LDC_ERR_UNSUPPORTED;
+  if (B > 65535) return LDC_ERR_UNSUPPORTED;
   if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
   if (out_fmt == LDC_FMT_SPLIT && ((ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
-  if (workspace_bytes < ldc_relu_linear_attn_workspace_bytes(B, P, groups)) return LDC_ERR_ARG;
-  const int nslice = relu_attn_slices(B, P, groups);
-  const int pix_per_wg = ldc_cdiv(ldc_cdiv(P, 64), nslice) * 64;
-  const int nsl = ldc_cdiv(P, pix_per_wg);  // <= nslice; the apply pass adds exactly the slices that were written
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* part = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(relu_linear_attn_kv_kernel, dim3(nsl, groups, B), dim3(256), 0, s, qkv, part, P, ldq, pix_per_wg);
-  int st = ldc_launch_status();
-  if (st != LDC_OK) return st;
-  hipLaunchKernelGGL(relu_linear_attn_apply_kernel, dim3(ldc_cdiv(P, 64), groups, B), dim3(256), 0, s, qkv, part, y, P, ldq, ldy, eps,
-                     nsl, out_fmt);
+  const size_t lds = (RLA_WAVES + 1) * KV_N * sizeof(float);  // 71.8 KB
+  static const bool attr_set = [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relu_linear_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL(relu_linear_attn_kernel, dim3(groups, B), dim3(RLA_WAVES * 64), lds, static_cast<hipStream_t>(stream), qkv, y, P,
+                     ldq, ldy, eps, out_fmt);
   return ldc_launch_status();
 }
 

@@ -915,7 +915,9 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
   q.d.act = act;
   q.d.flags = LDC_GEMM_A_SPLIT | (out_fmt == LDC_FMT_SPLIT ? LDC_GEMM_C_SPLIT : 0);
   const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
-  static const char* const force_thr = getenv("LDC_CONV_SMALL_TILES");  // measurement aid, read once: the cross-over below
-  return tiles256 < (force_thr ? atoll(force_thr) : 400) ? launch_v3<128, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
+  // tile height: measured cross-over (tools/conv_bench.py) - 252 -> 252 at 120 x 240 (226 tiles of 256 rows): 101 us at 256 rows, 121 at
+  // 128; 504 -> 504 at 60 x 120 (116 tiles): 122 / 111; four frames of it (464): 350 / 437.  LDC_CONV_SMALL_TILES: measurement aid
+  static const char* const force_thr = getenv("LDC_CONV_SMALL_TILES");
+  return tiles256 < (force_thr ? atoll(force_thr) : 200) ? launch_v3<128, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
                                                          : launch_v3<256, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
 }

@@ -126,6 +126,58 @@ def test_linear_attention_and_grouped_conv():
     assert rel_l2(y.cpu(), want) < 2e-6
 
 
+@pytest.mark.parametrize("k,B,H,W,C", [(5, 2, 7, 12, 96), (5, 1, 15, 30, 192), (3, 2, 9, 16, 64), (5, 1, 30, 60, 1440), (5, 1, 3, 8, 32)])
+def test_multiscale_projection(k, B, H, W, C):
+    """SanaMultiscaleAttentionProjection (models/DCAE.py:77-88): depthwise sphere conv (register-tiled along the image row; W = 8: the
+    untiled kernel) + grouped 1x1 conv vs the oracle's two modules - pole rows (flipped kernel rows, W/2 roll), wrap, row widths that
+    are not a multiple of the 8-pixel segment, strided source and destination (the qkv concat)"""
+    import ladcast_amd.hip as hip
+    from oracle.sphere_conv import SphereConv2d as OSC
+
+    dw = OSC(C, C, k, 1, k // 2, groups=C, bias=False)
+    with torch.no_grad():
+        dw.weight.copy_(rnd(*dw.weight.shape, seed=1) / k)
+    wg = rnd(C, 32, 1, 1, seed=2) / 32 ** 0.5
+    x = rnd(B, C, H, W, seed=3)
+    with torch.no_grad():
+        want = F.conv2d(dw(x), wg, groups=C // 32)
+    M = B * H * W
+    xn = torch.full((M, C + 8), float("nan"), device="cuda")
+    xn[:, :C] = x.cuda().permute(0, 2, 3, 1).reshape(M, C)
+    y = torch.full((M, 2 * C), float("nan"), device="cuda")
+    d = torch.empty(M, C, device="cuda")
+    hip.sphere_dwconv_nhwc(xn, dw.weight.detach().reshape(C, k * k).t().contiguous().cuda(), d, B=B, H=H, W=W, C=C, ldx=C + 8, ksize=k)
+    hip.grouped_conv1x1_nhwc(d, wg.reshape(C, 32).contiguous().cuda(), y[:, C:], M=M, groups=C // 32, ldx=C, ldy=2 * C)
+    got = y[:, C:].reshape(B, H, W, C).permute(0, 3, 1, 2).cpu()
+    assert torch.isnan(y[:, :C]).all()
+    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 2e-6 and rel_l2(got[:, :, -1], want[:, :, -1]) < 2e-6 and rel_l2(got[:, :, 1], want[:, :, 1]) < 2e-6
+
+
+@pytest.mark.parametrize("k,B,H,W,C", [(3, 2, 9, 16, 64), (3, 1, 15, 30, 128), (3, 1, 7, 12, 192), (5, 1, 6, 8, 64)])
+def test_glu_depthwise(k, B, H, W, C):
+    """GLUMBConv's depthwise conv + gate (models/DCAE.py:311-313) vs the oracle (register-tiled kernel; W = 8 with k = 5: the untiled one)"""
+    import ladcast_amd.hip as hip
+    from oracle.sphere_conv import SphereConv2d as OSC
+
+    dw = OSC(C, C, k, 1, k // 2, groups=C, bias=True)
+    with torch.no_grad():
+        dw.weight.copy_(rnd(*dw.weight.shape, seed=1) / k)
+        dw.bias.copy_(rnd(C, seed=2))
+    x = rnd(B, C, H, W, seed=3)
+    with torch.no_grad():
+        d = dw(x)
+        want = d[:, : C // 2] * F.silu(d[:, C // 2 :])
+    M = B * H * W
+    xn = x.cuda().permute(0, 2, 3, 1).reshape(M, C).contiguous()
+    y = torch.full((M, C // 2), float("nan"), device="cuda")
+    hip.sphere_dwconv_nhwc(xn, dw.weight.detach().reshape(C, k * k).t().contiguous().cuda(), y, B=B, H=H, W=W, C=C, bias=dw.bias.detach().cuda(), ksize=k,
+                           glu=True)
+    got = y.reshape(B, H, W, C // 2).permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 2e-6 and rel_l2(got[:, :, -1], want[:, :, -1]) < 2e-6
+
+
 def _pair(cfg):
     from ladcast_amd.models import AutoencoderDC
 
