@@ -19,6 +19,7 @@ from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler  
 from tests.synth import make_ar, rel_l2, synth_known, tiny_ar_config  # noqa: E402
 
 TOL = 1e-4
+TOL_BF16 = 2e-2  # the `bf16` mode is outside the 1e-4 budget by design: one bf16 rounding (2^-9) per operand
 
 
 def to_hip(oracle_model, cfg):
@@ -61,8 +62,8 @@ def _fmt(c):
 
 def test_full_375m_chunk_matches_oracle():
     """BASELINE configs[1], literally: 375M, 1 member, 20 solver steps, one R = 4 chunk - the 39-forward Heun sampler (`edm`) and
-    the 20-forward DPM-Solver++(2M) loop (`pipeline`), exact-fp32 and split-bf16 arithmetic, against the CPU oracle; the
-    per-evaluation error of the network INPUT (state drift) and OUTPUT is printed."""
+    the 20-forward DPM-Solver++(2M) loop (`pipeline`), exact-fp32, split-bf16 and single-term bf16 arithmetic, against the CPU
+    oracle; the per-evaluation error of the network INPUT (state drift) and OUTPUT is printed."""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 
@@ -75,7 +76,9 @@ def test_full_375m_chunk_matches_oracle():
         want = OP.ensemble_AR_sampler(OP.AutoRegressive2DPipeline(ro, OracleScheduler()), 1, 4, 20, known_latents=known, timestamps=ts, sampler_type=sampler)
         t_cpu = time.perf_counter() - t0
         assert len(ro.outs) == n_fwd
-        for mode in ("fp32", "bf16x3"):
+        for mode in ("fp32", "bf16x3", "bf16"):
+            # bf16: the single-term mixed-precision mode (BASELINE configs[4]); its stated tolerance is 2e-2 per chunk (test_gpu_model.py)
+            tol = TOL_BF16 if mode == "bf16" else TOL
             g.set_gemm_precision(mode)
             rg = Rec(g)
             got = ensemble_AR_sampler(AutoRegressive2DPipeline(rg, EDMDPMSolverMultistepScheduler()), 1, 4, 20, known_latents=known.cuda(),
@@ -85,8 +88,8 @@ def test_full_375m_chunk_matches_oracle():
             print(f"\n375M {sampler} chunk ({n_fwd} forwards, oracle {t_cpu:.0f} s) [{mode}]: sample rel-L2 {e:.2e}")
             print(f"  network-input  error per evaluation: {_fmt(e_in)}")
             print(f"  network-output error per evaluation: {_fmt(e_out)}")
-            assert e < TOL, (sampler, mode, e)
-            assert max(e_in) < TOL and max(e_out) < TOL, (sampler, mode, max(e_in), max(e_out))
+            assert e < tol, (sampler, mode, e)
+            assert max(e_in) < tol and max(e_out) < tol, (sampler, mode, max(e_in), max(e_out))
             # the graph-replayed chunk (what bench.py times) gives the same sample bit for bit
             g.enable_hip_graph(True)
             got_g = ensemble_AR_sampler(AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), 1, 4, 20, known_latents=known.cuda(),
