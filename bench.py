@@ -57,8 +57,8 @@ def dcae_workload(args):
 
     torch.manual_seed(1234)
     g = AutoencoderDC.from_config(CONFIG_DCAE_84).cuda().eval()
-    res = {"workload": "DCAE (DC_AE_84_pretrain) encode + decode, 84 x 120 x 240 frames + 5 static channels, fp32 MFMA, random-init seed 1234"}
-    for prec in ("fp32", "bf16x3"):  # bf16x3: the dense 3x3 convs as split-bf16 implicit GEMMs (AutoencoderDC.set_gemm_precision)
+    res = {"workload": "DCAE (DC_AE_84_pretrain) encode + decode, 84 x 120 x 240 frames + 5 static channels, per precision mode (fp32 MFMA | bf16x3 split | bf16 single-term), random-init seed 1234"}
+    for prec in ("fp32", "bf16x3", "bf16"):  # AutoencoderDC.set_gemm_precision: exact fp32 | split-bf16 | single-term bf16 convs / Linears
         g.set_gemm_precision(prec)
         for frames in (1, 4, 8, 32):
             x = torch.randn(frames, 84, 120, 240, device="cuda"); st = torch.randn(1, 5, 120, 240, device="cuda")

@@ -383,26 +383,29 @@ int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const float* bia
                                 void* workspace, long long workspace_bytes, void* stream);
 
 /* The same convolution on PRE-SPLIT activations (the DCAE's `bf16x3` path since round 2): X holds NHWC rows in the split format
- * (LDC_FMT_SPLIT: columns 8g..8g+7 in 32 bytes [hi x8 | lo x8]; ldx % 8 == 0, ldx >= cin rounded up to 8, pad columns zero),
- * written by the producers below, so the conv's main loop is the pre-split GEMM kernel (gemm_bf16x3_v3.hip: 16x16x32 MFMA, no
+ * (in_fmt = LDC_FMT_SPLIT: columns 8g..8g+7 in 32 bytes [hi x8 | lo x8]; ldx % 8 == 0, ldx >= cin rounded up to 8, pad columns
+ * zero), written by the producers below, so the conv's main loop is the pre-split GEMM kernel (gemm_bf16x3_v3.hip: 16x16x32 MFMA, no
  * VALU in the loop) with the sphere gather as per-lane LDS-DMA source addresses.  Wp: the weight format of
  * ldc_sphere_conv_nhwc_bf16x3.  out_fmt: LDC_FMT_F32 (Y fp32 rows) or LDC_FMT_SPLIT (Y split rows for the next conv, ldy % 8 == 0,
  * ldy >= cout rounded up to 8; cout % 4 == 0, the pad half of a last half-filled group is written as zeros).  cin % 8 need not
- * hold (252: the last group's pad columns are zero in X and in Wp).  ksize 1 / 3 / 5.  Replaces models/sphere_conv.py:62-192 +
- * the nn.Conv2d / nn.Linear 1x1 layers of models/DCAE.py:96-324. */
+ * hold (252: the last group's pad columns are zero in X and in Wp).  ksize 1 / 3 / 5.
+ * in_fmt = LDC_FMT_BF16 is the single-term `bf16` mode of the same conv (see LDC_GEMM_BF16_1TERM): X plain bf16 rows (same ldx, in
+ * floats), Wp = ldc_pack_weight_bf16 of the [cout][k*k][cin rounded up to 64 * 2^j] tap-major weight, out_fmt LDC_FMT_F32 | LDC_FMT_BF16.
+ * Replaces models/sphere_conv.py:62-192 + the nn.Conv2d / nn.Linear 1x1 layers of models/DCAE.py:96-324. */
 int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W,
-                               int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int out_fmt, void* workspace,
-                               long long workspace_bytes, void* stream);
-/* Producers of split rows.  `ys` = split copy (lds % 8 == 0, >= C rounded up to 8, 32-byte aligned; pad columns zeroed), `y` =
- * fp32 copy (the residual stream / inputs of depthwise convs); either may be NULL, not both. */
+                               int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int in_fmt, int out_fmt,
+                               void* workspace, long long workspace_bytes, void* stream);
+/* Producers of operand rows.  `ys` = operand copy in format `fmt` (LDC_FMT_SPLIT | LDC_FMT_BF16; lds % 8 == 0, >= C rounded up to
+ * 8, 32-byte aligned; pad columns zeroed), `y` = fp32 copy (the residual stream / inputs of depthwise convs); either may be NULL,
+ * not both. */
 int ldc_rmsnorm_rows_split(const float* x, const float* w, const float* b, const float* resid, float* y, float* ys, long long rows,
-                           int C, int ldx, int ldr, int ldy, int lds, float eps, int act, void* stream);
+                           int C, int ldx, int ldr, int ldy, int lds, int fmt, float eps, int act, void* stream);
 int ldc_pixel_unshuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H2, int W2, int cout,
-                                       int cin, int lds, void* stream);
+                                       int cin, int lds, int fmt, void* stream);
 int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H, int W, int cout, int cin,
-                                     int lds, void* stream);
-int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, void* stream);
-/* ldc_sphere_dwconv_nhwc / ldc_relu_linear_attn_nhwc with the output format as an argument (LDC_FMT_F32 | LDC_FMT_SPLIT). */
+                                     int lds, int fmt, void* stream);
+int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, int fmt, void* stream);
+/* ldc_sphere_dwconv_nhwc / ldc_relu_linear_attn_nhwc with the output format as an argument (LDC_FMT_F32 | _SPLIT | _BF16). */
 int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int C, int ldx,
                                int ldy, int ksize, int glu, int out_fmt, void* stream);
 int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps, int out_fmt,

@@ -82,6 +82,16 @@ __device__ __forceinline__ void ldc_zero_split4(unsigned char* row, int c) {
   *reinterpret_cast<uint2*>(g + 16) = make_uint2(0u, 0u);
 }
 
+// the same two helpers with the operand format as an argument: LDC_FMT_SPLIT, or LDC_FMT_BF16 (plain bf16 row: 8 bytes at byte 2 c)
+__device__ __forceinline__ void ldc_store_fmt4(unsigned char* row, int c, int fmt, float x0, float x1, float x2, float x3) {
+  if (fmt == LDC_FMT_BF16) *reinterpret_cast<uint2*>(row + 2 * c) = make_uint2(ldc_pack_pair(x0, x1), ldc_pack_pair(x2, x3));
+  else ldc_store_split4(row, c, x0, x1, x2, x3);
+}
+__device__ __forceinline__ void ldc_zero_fmt4(unsigned char* row, int c, int fmt) {
+  if (fmt == LDC_FMT_BF16) *reinterpret_cast<uint2*>(row + 2 * c) = make_uint2(0u, 0u);
+  else ldc_zero_split4(row, c);
+}
+
 // Source pixel (row-major index inside one image) of tap (ky, kx) of a ks x ks SphereConv2d at output pixel (h, w): rows past a
 // pole are mirrored and rolled by W / 2, columns wrap, and at the two pole rows the kernel rows that reach over the pole are
 // flipped left-right (models/sphere_conv.py:62-129,174-192).  Same rule as gemm_f32.hip / dcae.hip; the wrap is one conditional

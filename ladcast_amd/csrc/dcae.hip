@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void sphere_dwconv_kernel(const float* __restr
     a0.z *= ldc_silu(a1.z);
     a0.w *= ldc_silu(a1.w);
   }
-  if (out_fmt == LDC_FMT_SPLIT)  // operand rows of the next pointwise conv (gemm_bf16x3_v3.hip)
-    ldc_store_split4(reinterpret_cast<unsigned char*>(y + static_cast<long long>(pix) * ldy), c0, a0.x, a0.y, a0.z, a0.w);
+  if (out_fmt != LDC_FMT_F32)  // operand rows of the next pointwise conv (gemm_bf16x3_v3.hip)
+    ldc_store_fmt4(reinterpret_cast<unsigned char*>(y + static_cast<long long>(pix) * ldy), c0, out_fmt, a0.x, a0.y, a0.z, a0.w);
   else
     *reinterpret_cast<float4*>(y + static_cast<long long>(pix) * ldy + c0) = a0;
 }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sphere_dwconv_row_kernel(const float* __r
       o.w *= gate[i].w;
     }
     float* yr = yrow + static_cast<long long>(i) * ldy;
-    if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yr), c0, o.x, o.y, o.z, o.w);
+    if (out_fmt != LDC_FMT_F32) ldc_store_fmt4(reinterpret_cast<unsigned char*>(yr), c0, out_fmt, o.x, o.y, o.z, o.w);
     else *reinterpret_cast<float4*>(yr + c0) = o;
   }
 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const 
       for (int r4 = 0; r4 < 4; ++r4) {
         const int ch = g * 32 + 8 * r4 + 4 * h;
         const float o0 = o[4 * r4] * inv, o1 = o[4 * r4 + 1] * inv, o2 = o[4 * r4 + 2] * inv, o3 = o[4 * r4 + 3] * inv;
-        if (out_fmt == LDC_FMT_SPLIT) ldc_store_split4(reinterpret_cast<unsigned char*>(yrow), ch, o0, o1, o2, o3);
+        if (out_fmt != LDC_FMT_F32) ldc_store_fmt4(reinterpret_cast<unsigned char*>(yrow), ch, out_fmt, o0, o1, o2, o3);
         else *reinterpret_cast<float4*>(yrow + ch) = make_float4(o0, o1, o2, o3);
       }
     }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const 
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, const float* __restrict__ resid,
                                                            float* __restrict__ y, float* __restrict__ ys, long long rows, int C,
-                                                           int ldx, int ldr, int ldy, int lds, float eps, int act) {
+                                                           int ldx, int ldr, int ldy, int lds, int fmt, float eps, int act) {
   const int lane = threadIdx.x & 63;
   const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
       o.w = ldc_apply_act(o.w, act);
       if (yr) reinterpret_cast<float4*>(yr)[c] = o;
       if (sr) {
-        ldc_store_split4(sr, 4 * c, o.x, o.y, o.z, o.w);
-        if ((C & 4) && c == nv4 - 1) ldc_zero_split4(sr, 4 * c + 4);
+        ldc_store_fmt4(sr, 4 * c, fmt, o.x, o.y, o.z, o.w);
+        if ((C & 4) && c == nv4 - 1) ldc_zero_fmt4(sr, 4 * c + 4, fmt);
       }
     }
   }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
 
 // fp32 rows -> split rows (the conv_in outputs, whose epilogue writes the fp32 stream)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, float* __restrict__ ys, long long rows, int C,
-                                                         int ldx, int lds) {
+                                                         int ldx, int lds, int fmt) {
   const int nv4 = C >> 2;
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= rows * nv4) return;
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   const int c = static_cast<int>(idx - row * nv4);
   const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * c);
   unsigned char* sr = reinterpret_cast<unsigned char*>(ys + row * lds);
-  ldc_store_split4(sr, 4 * c, v.x, v.y, v.z, v.w);
-  if ((C & 4) && c == nv4 - 1) ldc_zero_split4(sr, 4 * c + 4);
+  ldc_store_fmt4(sr, 4 * c, fmt, v.x, v.y, v.z, v.w);
+  if ((C & 4) && c == nv4 - 1) ldc_zero_fmt4(sr, 4 * c + 4, fmt);
 }
 
 // DCDownBlock2d tail: y[b,h2,w2,co] = cv[b,2h2+i,2w2+j,c] (co = 4c+2i+j)  +  mean_g xs[co*G+g],
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void pixel_unshuffle_shortcut_kernel(const float* __restrict__ cv,
                                                                        const float* __restrict__ x, float* __restrict__ y,
                                                                        float* __restrict__ ys, int H2, int W2, int cout, int cin,
-                                                                       int G, int lds, long long total4) {
+                                                                       int G, int lds, int fmt, long long total4) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= total4) return;
   const int cq = cout >> 2;
@@ -399,15 +399,15 @@ __global__ __launch_bounds__(256) void pixel_unshuffle_shortcut_kernel(const flo
   if (y) *reinterpret_cast<float4*>(y + pix * cout + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
   if (ys) {
     unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
-    ldc_store_split4(sr, 4 * c, o[0], o[1], o[2], o[3]);
-    if ((cout & 4) && c == cq - 1) ldc_zero_split4(sr, 4 * c + 4);
+    ldc_store_fmt4(sr, 4 * c, fmt, o[0], o[1], o[2], o[3]);
+    if ((cout & 4) && c == cq - 1) ldc_zero_fmt4(sr, 4 * c + 4, fmt);
   }
 }
 
 // DCUpBlock2d tail: y[b,2h+i,2w+j,c] = cv[b,h,w,4c+2i+j] + x[b,h,w,(4c+2i+j)/rep]   (models/DCAE.py:526-532)
 __global__ __launch_bounds__(256) void pixel_shuffle_shortcut_kernel(const float* __restrict__ cv, const float* __restrict__ x,
                                                                      float* __restrict__ y, float* __restrict__ ys, int H, int W,
-                                                                     int cout, int cin, int rep, int lds, long long total4) {
+                                                                     int cout, int cin, int rep, int lds, int fmt, long long total4) {
   const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= total4) return;
   const int cq = cout >> 2;
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle_shortcut_kernel(const float
   if (y) *reinterpret_cast<float4*>(y + pix * cout + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
   if (ys) {
     unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
-    ldc_store_split4(sr, 4 * c4, o[0], o[1], o[2], o[3]);
-    if ((cout & 4) && c4 == cq - 1) ldc_zero_split4(sr, 4 * c4 + 4);
+    ldc_store_fmt4(sr, 4 * c4, fmt, o[0], o[1], o[2], o[3]);
+    if ((cout & 4) && c4 == cq - 1) ldc_zero_fmt4(sr, 4 * c4 + 4, fmt);
   }
 }
 
@@ -464,8 +464,8 @@ extern "C" int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return LDC_ERR_ARG;
   if ((ksize != 3 && ksize != 5) || (W & 1) || H < 2 || H < ksize / 2) return LDC_ERR_UNSUPPORTED;
   if ((C & 3) || (ldx & 3) || (ldy & 3) || (glu && (C & 7))) return LDC_ERR_ALIGN;
-  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
-  if (out_fmt == LDC_FMT_SPLIT && (((glu ? C / 2 : C) & 7) || (ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT && out_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt != LDC_FMT_F32 && (((glu ? C / 2 : C) & 7) || (ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(wt);
   LDC_CHECK_ALIGN16(y);
@@ -525,8 +525,8 @@ extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, 
   if (B <= 0 || P <= 0 || groups <= 0) return LDC_ERR_ARG;
   if ((ldq & 3) || (ldy & 3)) return LDC_ERR_ALIGN;
   if (B > 65535) return LDC_ERR_UNSUPPORTED;
-  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
-  if (out_fmt == LDC_FMT_SPLIT && ((ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT && out_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt != LDC_FMT_F32 && ((ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
   const size_t lds = (RLA_WAVES + 1) * KV_N * sizeof(float);  // 71.8 KB
@@ -544,15 +544,17 @@ extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, 
 extern "C" int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y,
                                 long long rows, int C, int ldx, int ldr, int ldy, float eps, int act, void* stream) {
   LDC_CHECK_PTR(y);
-  return ldc_rmsnorm_rows_split(x, w, b, resid, y, nullptr, rows, C, ldx, ldr, ldy, 0, eps, act, stream);
+  return ldc_rmsnorm_rows_split(x, w, b, resid, y, nullptr, rows, C, ldx, ldr, ldy, 0, LDC_FMT_SPLIT, eps, act, stream);
 }
 
-// y (fp32 rows) and / or ys (split rows, lds >= C rounded up to 8, pad columns zeroed): at least one
+// y (fp32 rows) and / or ys (operand rows in format fmt = LDC_FMT_SPLIT | LDC_FMT_BF16, lds >= C rounded up to 8, pad columns zeroed)
 extern "C" int ldc_rmsnorm_rows_split(const float* x, const float* w, const float* b, const float* resid, float* y, float* ys,
-                                      long long rows, int C, int ldx, int ldr, int ldy, int lds, float eps, int act, void* stream) {
+                                      long long rows, int C, int ldx, int ldr, int ldy, int lds, int fmt, float eps, int act,
+                                      void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(w);
   if (y == nullptr && ys == nullptr) return LDC_ERR_ARG;
+  if (ys && fmt != LDC_FMT_SPLIT && fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
   if (rows <= 0 || C <= 0) return LDC_ERR_ARG;
   if ((C & 3) || C > 1024 || (ldx & 3) || (y && (ldy & 3)) || (resid && (ldr & 3))) return LDC_ERR_UNSUPPORTED;
   if (ys && ((lds & 7) || lds < ((C + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u))) return LDC_ERR_ALIGN;
@@ -560,65 +562,67 @@ extern "C" int ldc_rmsnorm_rows_split(const float* x, const float* w, const floa
   LDC_CHECK_ALIGN16(w);
   if (y) LDC_CHECK_ALIGN16(y);
   hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(ldc_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b,
-                     resid, y, ys, rows, C, ldx, ldr, ldy, lds, eps, act);
+                     resid, y, ys, rows, C, ldx, ldr, ldy, lds, fmt, eps, act);
   return ldc_launch_status();
 }
 
-extern "C" int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, void* stream) {
+extern "C" int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, int fmt, void* stream) {
   LDC_CHECK_PTR(x);
   LDC_CHECK_PTR(ys);
   if (rows <= 0 || C <= 0) return LDC_ERR_ARG;
+  if (fmt != LDC_FMT_SPLIT && fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
   if ((C & 3) || (ldx & 3) || (lds & 7) || lds < ((C + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u)) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   hipLaunchKernelGGL(split_rows_kernel, dim3(ldc_cdiv(rows * (C >> 2), 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ys,
-                     rows, C, ldx, lds);
+                     rows, C, ldx, lds, fmt);
   return ldc_launch_status();
 }
 
 extern "C" int ldc_pixel_unshuffle_shortcut(const float* cv, const float* x, float* y, int B, int H2, int W2, int cout,
                                             int cin, void* stream) {
   LDC_CHECK_PTR(y);
-  return ldc_pixel_unshuffle_shortcut_split(cv, x, y, nullptr, B, H2, W2, cout, cin, 0, stream);
+  return ldc_pixel_unshuffle_shortcut_split(cv, x, y, nullptr, B, H2, W2, cout, cin, 0, LDC_FMT_SPLIT, stream);
 }
 
-static int split_out_ok(const float* y, const float* ys, int cout, int lds) {
+static int split_out_ok(const float* y, const float* ys, int cout, int lds, int fmt) {
   if (y == nullptr && ys == nullptr) return LDC_ERR_ARG;
+  if (ys && fmt != LDC_FMT_SPLIT && fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
   if (y && (reinterpret_cast<uintptr_t>(y) & 15u)) return LDC_ERR_ALIGN;
   if (ys && ((lds & 7) || lds < ((cout + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u))) return LDC_ERR_ALIGN;
   return LDC_OK;
 }
 
 extern "C" int ldc_pixel_unshuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H2, int W2,
-                                                  int cout, int cin, int lds, void* stream) {
+                                                  int cout, int cin, int lds, int fmt, void* stream) {
   LDC_CHECK_PTR(cv);
   LDC_CHECK_PTR(x);
   if (B <= 0 || H2 <= 0 || W2 <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
   if ((cout & 3) || (4 * cin) % cout) return LDC_ERR_UNSUPPORTED;
-  const int ok = split_out_ok(y, ys, cout, lds);
+  const int ok = split_out_ok(y, ys, cout, lds, fmt);
   if (ok != LDC_OK) return ok;
   const long long total4 = static_cast<long long>(B) * H2 * W2 * (cout >> 2);
   hipLaunchKernelGGL(pixel_unshuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), cv, x, y, ys, H2, W2, cout, cin, 4 * cin / cout, lds, total4);
+                     static_cast<hipStream_t>(stream), cv, x, y, ys, H2, W2, cout, cin, 4 * cin / cout, lds, fmt, total4);
   return ldc_launch_status();
 }
 
 extern "C" int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B, int H, int W, int cout,
                                           int cin, void* stream) {
   LDC_CHECK_PTR(y);
-  return ldc_pixel_shuffle_shortcut_split(cv, x, y, nullptr, B, H, W, cout, cin, 0, stream);
+  return ldc_pixel_shuffle_shortcut_split(cv, x, y, nullptr, B, H, W, cout, cin, 0, LDC_FMT_SPLIT, stream);
 }
 
 extern "C" int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H, int W, int cout,
-                                                int cin, int lds, void* stream) {
+                                                int cin, int lds, int fmt, void* stream) {
   LDC_CHECK_PTR(cv);
   LDC_CHECK_PTR(x);
   if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
   if ((cout & 3) || (4 * cout) % cin) return LDC_ERR_UNSUPPORTED;
-  const int ok = split_out_ok(y, ys, cout, lds);
+  const int ok = split_out_ok(y, ys, cout, lds, fmt);
   if (ok != LDC_OK) return ok;
   const long long total4 = static_cast<long long>(B) * 4 * H * W * (cout >> 2);
   hipLaunchKernelGGL(pixel_shuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), cv, x, y, ys, H, W, cout, cin, 4 * cout / cin, lds, total4);
+                     static_cast<hipStream_t>(stream), cv, x, y, ys, H, W, cout, cin, 4 * cout / cin, lds, fmt, total4);
   return ldc_launch_status();
 }
 

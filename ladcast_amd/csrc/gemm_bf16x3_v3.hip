@@ -211,7 +211,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
   const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
   const int act = P.d.act;
   const int n_lane = bn * BN + 4 * (lane >> 4);
-  const int Nw = P.c_split == LDC_FMT_SPLIT ? ((N + 7) & ~7) : N;  // split rows are written in whole 8-column groups
+  const int Nw = P.c_split ? ((N + 7) & ~7) : N;  // operand rows are written in whole 8-column groups (pad columns zero)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
     for (int ct = 0; ct < 8; ++ct) {
       const int n = n_lane + 16 * ct;
       if (n >= Nw) continue;
-      const bool pad = n >= N;  // split rows with N = 4 mod 8: the pad half of the last group is written as zeros
+      const bool pad = n >= N;  // operand rows with N = 4 mod 8: the pad half of the last group is written as zeros
       const f32x4 av = acc[rt * 8 + ct];
       if (P.vec4) {
         float4 v = make_float4(av[0], av[1], av[2], av[3]);
@@ -293,10 +293,11 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 // MFMAs per column tile, (first chunks) + (second chunks), instead of three: two thirds of the MFMAs for twice the k.
 // CONV: the A rows are gathered - row m of k-step (tap, chunk) is the 128-byte channel chunk of the tap's source pixel under the
 // sphere padding rule, a per-lane DMA source recomputed when a tap starts (wave-uniform branch, 2^kshift k-steps apart); everything
-// behind the DMA issue is the GEMM.  X is NHWC in the split format (written by the DCAE's producers, dcae.hip).
+// behind the DMA issue is the GEMM.  X is NHWC in the split format (TERMS = 3: 32 channels per k-step) or plain bf16 rows (TERMS = 1:
+// 64 channels per k-step), written by the DCAE's producers (dcae.hip).
 template <int BM, int TERMS, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
-  static_assert(!(CONV && TERMS != 3), "the conv gather is built for the split format (32 channels per k-step)");
+  constexpr int CPK = TERMS == 3 ? BK : 2 * BK;  // CONV: channels per 128-byte k-step (split groups / plain bf16)
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
   constexpr int NACC = RT * 8;                 // accumulators (f32x4) per lane
   constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
@@ -423,8 +424,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
           const int chunk = kt & ((1 << P.kshift) - 1);
           if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
           const unsigned char* src = a_src[i] + chunk * (BK * 4);
-          if (chunk * BK + BK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
-            if (chunk * BK + 8 * (cslot >> 1) >= P.cin) src = P.zero16;
+          if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
+            // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
+            if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
           }
           dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
         } else {
@@ -710,8 +712,8 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
       P.vec4 = v4 ? 1 : 0;
       P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? (TERMS == 3 ? LDC_FMT_SPLIT : LDC_FMT_BF16) : 0;
-      // plain-bf16 rows: whole 8-column groups only; split rows: N % 4 == 0, the pad half of a last half-filled group is zeroed
-      if (P.c_split && !(v4 && (d.N % 8 == 0 || P.c_split == LDC_FMT_SPLIT) && d.ldc % 8 == 0 && d.ldc >= ((d.N + 7) & ~7) &&
+      // operand rows out: N % 4 == 0 (v4), the pad half of a last half-filled 8-column group is zeroed
+      if (P.c_split && !(v4 && d.ldc % 8 == 0 && d.ldc >= ((d.N + 7) & ~7) &&
                          d.c_bs % 8 == 0 && (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
         return LDC_ERR_ALIGN;
     }
@@ -877,25 +879,30 @@ extern "C" int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, con
   return gemm_v3_dispatch(problems, epi, n, workspace, workspace_bytes, stream);
 }
 
-// SphereConv2d (dense, stride 1, k = 3 / 5; k = 1: pointwise conv / Linear over pixel rows with any cin % 8 == 0) as an implicit GEMM
-// on the pre-split kernel: X is NHWC in the split format [B*H*W][ldx] (LDC_FMT_SPLIT, pad columns behind cin up to the next
-// multiple of 8 zero), Wp = ldc_pack_weight_bf16x2 of the [cout][k*k][cin rounded up to 32 * 2^j] tap-major weight (zero behind
-// cin) - the weight format of ldc_sphere_conv_nhwc_bf16x3.  Y: fp32 rows, or (out_fmt = LDC_FMT_SPLIT) split rows for the next conv.
+// SphereConv2d (dense, stride 1, k = 3 / 5; k = 1: pointwise conv / Linear over pixel rows) as an implicit GEMM on the pre-split kernel.
+// in_fmt = LDC_FMT_SPLIT: X is NHWC split rows [B*H*W][ldx] (pad columns behind cin up to the next multiple of 8 zero), Wp =
+// ldc_pack_weight_bf16x2 of the [cout][k*k][cin rounded up to 32 * 2^j] tap-major weight (zero behind cin) - the weight format of
+// ldc_sphere_conv_nhwc_bf16x3; Y: fp32 rows or (out_fmt = LDC_FMT_SPLIT) split rows for the next conv.
+// in_fmt = LDC_FMT_BF16 (the single-term `bf16` mode): X is plain bf16 rows (same row stride ldx in floats), Wp = ldc_pack_weight_bf16
+// of the [cout][k*k][cin rounded up to 64 * 2^j] weight; Y: fp32 rows or (out_fmt = LDC_FMT_BF16) plain bf16 rows.
 extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H,
-                                          int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int out_fmt,
-                                          void* workspace, long long workspace_bytes, void* stream) {
+                                          int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int in_fmt,
+                                          int out_fmt, void* workspace, long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(X);
   LDC_CHECK_PTR(Wp);
   LDC_CHECK_PTR(Y);
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
   if (ksize != 1 && ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
   if (ksize > 1 && ((W & 1) || H < 2 || H < ksize / 2 || W / 2 < ksize / 2 || H > 32767 || W > 65535)) return LDC_ERR_UNSUPPORTED;
-  if (out_fmt != LDC_FMT_F32 && out_fmt != LDC_FMT_SPLIT) return LDC_ERR_UNSUPPORTED;
+  if (in_fmt != LDC_FMT_SPLIT && in_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
+  if (out_fmt != LDC_FMT_F32 && out_fmt != in_fmt) return LDC_ERR_UNSUPPORTED;
   if ((ldx & 7) || ldx < ((cin + 7) & ~7) || ldy < cout) return LDC_ERR_ALIGN;
   const long long M = static_cast<long long>(B) * H * W;
   if (M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  const bool one = in_fmt == LDC_FMT_BF16;
+  const int cpk = one ? 2 * BK : BK;  // channels per k-step
   ConvParams cp{H, W, cin, ksize, 0};
-  int ktpt = ldc_cdiv(cin, BK);  // k-steps per tap, rounded up to a power of two (the kernel shifts instead of dividing)
+  int ktpt = ldc_cdiv(cin, cpk);  // k-steps per tap, rounded up to a power of two (the kernel shifts instead of dividing)
   while ((1 << cp.kshift) < ktpt) ++cp.kshift;
   ktpt = 1 << cp.kshift;
   ldc_gemm_problem q{};
@@ -906,18 +913,22 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
   q.C = Y;
   q.d.M = static_cast<int>(M);
   q.d.N = cout;
-  q.d.K = ksize * ksize * ktpt * BK;
+  q.d.K = ksize * ksize * ktpt * cpk;
   q.d.batch = 1;
   q.d.lda = ldx;
   q.d.ldw = q.d.K;
   q.d.ldc = ldy;
   q.d.ldr = ldr;
   q.d.act = act;
-  q.d.flags = LDC_GEMM_A_SPLIT | (out_fmt == LDC_FMT_SPLIT ? LDC_GEMM_C_SPLIT : 0);
+  q.d.flags = LDC_GEMM_A_SPLIT | (out_fmt != LDC_FMT_F32 ? LDC_GEMM_C_SPLIT : 0) | (one ? LDC_GEMM_BF16_1TERM : 0);
   const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
   // tile height: measured cross-over (tools/conv_bench.py) - 252 -> 252 at 120 x 240 (226 tiles of 256 rows): 101 us at 256 rows, 121 at
   // 128; 504 -> 504 at 60 x 120 (116 tiles): 122 / 111; four frames of it (464): 350 / 437.  LDC_CONV_SMALL_TILES: measurement aid
   static const char* const force_thr = getenv("LDC_CONV_SMALL_TILES");
-  return tiles256 < (force_thr ? atoll(force_thr) : 200) ? launch_v3<128, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
-                                                         : launch_v3<256, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
+  const bool small = tiles256 < (force_thr ? atoll(force_thr) : 200);
+  if (one)
+    return small ? launch_v3<128, 1, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
+                 : launch_v3<256, 1, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
+  return small ? launch_v3<128, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)
+               : launch_v3<256, 3, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
 }

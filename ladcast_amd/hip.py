@@ -82,11 +82,11 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
-        "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
-        "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, F, I, P]),
-        "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, P]),
-        "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, P]),
-        "ldc_split_rows": (I, [P, P, L, I, I, I, P]),
+        "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
+        "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
+        "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+        "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+        "ldc_split_rows": (I, [P, P, L, I, I, I, I, P]),
         "ldc_sphere_dwconv_nhwc_fmt": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
         "ldc_relu_linear_attn_nhwc_fmt": (I, [P, P, I, I, I, I, I, F, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
@@ -479,13 +479,13 @@ def sphere_conv_nhwc(X, Wt, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=N
                                     ldy if ldy is not None else cout, ldr, ksize, act, _stream()), "ldc_sphere_conv_nhwc")
 
 
-def conv_cin_padded(cin):
-    """channels per tap of a packed split-bf16 conv weight: 32 * 2^j >= cin"""
-    kt = -(-cin // 32)
+def conv_cin_padded(cin, cpk=32):
+    """channels per tap of a packed conv weight: cpk * 2^j >= cin (cpk = channels per k-step: 32 split-bf16, 64 plain bf16)"""
+    kt = -(-cin // cpk)
     p2 = 1
     while p2 < kt:
         p2 *= 2
-    return 32 * p2
+    return cpk * p2
 
 
 def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE):
@@ -497,17 +497,19 @@ def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None,
            "ldc_sphere_conv_nhwc_bf16x3")
 
 
-def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE, out_fmt=FMT_F32):
-    """X: split rows (FMT_SPLIT, ldx % 8 == 0); Wp as sphere_conv_nhwc_bf16x3; Y fp32 rows or (out_fmt=FMT_SPLIT) split rows"""
+def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE, in_fmt=FMT_SPLIT,
+                           out_fmt=FMT_F32):
+    """X: operand rows (FMT_SPLIT: Wp as sphere_conv_nhwc_bf16x3 | FMT_BF16: Wp = pack_weight_bf16 of the taps padded to 64 * 2^j channels;
+    ldx % 8 == 0); Y fp32 rows or (out_fmt = in_fmt) operand rows"""
     _dev(X, Wp, Y, bias, R)
     ws = _grouped_workspace(X.device)
     _check(lib.ldc_sphere_conv_nhwc_split(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx, cout, ldy if ldy is not None else cout,
-                                          ldr, ksize, act, int(out_fmt), _p(ws), ws.numel() * 4, _stream()), "ldc_sphere_conv_nhwc_split")
+                                          ldr, ksize, act, int(in_fmt), int(out_fmt), _p(ws), ws.numel() * 4, _stream()), "ldc_sphere_conv_nhwc_split")
 
 
-def split_rows(x, ys, *, rows, C, ldx=None, lds=None):
+def split_rows(x, ys, *, rows, C, ldx=None, lds=None, fmt=FMT_SPLIT):
     _dev(x, ys)
-    _check(lib.ldc_split_rows(_p(x), _p(ys), rows, C, ldx if ldx is not None else C, lds if lds is not None else -(-C // 8) * 8, _stream()),
+    _check(lib.ldc_split_rows(_p(x), _p(ys), rows, C, ldx if ldx is not None else C, lds if lds is not None else -(-C // 8) * 8, int(fmt), _stream()),
            "ldc_split_rows")
 
 
@@ -540,26 +542,26 @@ def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F3
            "ldc_relu_linear_attn_nhwc_fmt")
 
 
-def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE, ys=None, lds=None):
-    """y: fp32 rows and / or ys: split rows (FMT_SPLIT, lds = C rounded up to 8 by default)"""
+def rmsnorm_rows(x, w, y, *, rows, C, eps, b=None, resid=None, ldx=None, ldr=None, ldy=None, act=ACT_NONE, ys=None, lds=None, fmt=FMT_SPLIT):
+    """y: fp32 rows and / or ys: operand rows (fmt = FMT_SPLIT | FMT_BF16, lds = C rounded up to 8 by default)"""
     _dev(x, w, b, resid, y, ys)
     _check(lib.ldc_rmsnorm_rows_split(_p(x), _p(w), _p(b), _p(resid), _p(y), _p(ys), rows, C, ldx if ldx is not None else C,
                                       ldr if ldr is not None else C, ldy if ldy is not None else C,
-                                      (lds if lds is not None else -(-C // 8) * 8) if ys is not None else 0, eps, act, _stream()),
+                                      (lds if lds is not None else -(-C // 8) * 8) if ys is not None else 0, int(fmt), eps, act, _stream()),
            "ldc_rmsnorm_rows_split")
 
 
-def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin, ys=None, lds=None):
+def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin, ys=None, lds=None, fmt=FMT_SPLIT):
     _dev(cv, x, y, ys)
     _check(lib.ldc_pixel_unshuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H2, W2, cout, cin,
-                                                  (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, _stream()),
+                                                  (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, int(fmt), _stream()),
            "ldc_pixel_unshuffle_shortcut_split")
 
 
-def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin, ys=None, lds=None):
+def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin, ys=None, lds=None, fmt=FMT_SPLIT):
     _dev(cv, x, y, ys)
     _check(lib.ldc_pixel_shuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H, W, cout, cin,
-                                                (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, _stream()),
+                                                (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, int(fmt), _stream()),
            "ldc_pixel_shuffle_shortcut_split")
 
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import hip
 from .modeling_utils import ModelMixin
-from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_dense_weight_bf16x3, pack_depthwise_weight
+from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_dense_weight_bf16, pack_dense_weight_bf16x3, pack_depthwise_weight
 
 
 class EncoderOutput(SimpleNamespace):
@@ -249,13 +249,10 @@ class AutoencoderDC(ModelMixin):
         """'fp32' (default): every conv on the exact-fp32 matrix cores; 'bf16x3': the dense 3x3 SphereConv2d layers, the 1x1 convs and
         the Linears (99 % of the FLOPs) as split-bf16 implicit GEMMs (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~4e-6 per layer) on
         activations their producers write pre-split; depthwise / grouped convs, norms, residual stream and the linear attention
-        stay fp32."""
-        if precision == "bf16":
-            # the mixed-precision mode of the AR transformer (one bf16 MFMA per product): the conv kernels have no single-term
-            # body yet, so the DCAE share of a mixed-precision run is computed with the split-bf16 convs - tighter, not looser,
-            # than asked; the reference's fp32 islands (ReLU linear attention, models/DCAE.py:162,180) are fp32 in every mode
-            precision = "bf16x3"
-        if precision not in ("fp32", "bf16x3"):
+        stay fp32.  'bf16': the mixed-precision mode of BASELINE configs[4] - the same convs with ONE bf16 MFMA per product on plain
+        bf16 operand rows (what torch.autocast(bfloat16) does to a conv's operands; outputs, accumulation and the reference's fp32
+        islands, models/DCAE.py:162,180, stay fp32); stated tolerance 2e-2 per encode / decode against the fp32 oracle."""
+        if precision not in ("fp32", "bf16x3", "bf16"):
             raise ValueError("gemm precision must be 'fp32', 'bf16x3' or 'bf16'")
         if precision != self.gemm_precision:
             self.gemm_precision = precision
@@ -292,22 +289,23 @@ class AutoencoderDC(ModelMixin):
         if not next(self.parameters()).is_cuda:
             raise RuntimeError("AutoencoderDC must live on a HIP device (no CPU fallback)")
         plan = {}
-        split = self.gemm_precision == "bf16x3"
+        split = self.gemm_precision != "fp32"
+        pack = pack_dense_weight_bf16 if self.gemm_precision == "bf16" else pack_dense_weight_bf16x3  # operand format of the mode
         for mod in self.modules():
             if isinstance(mod, SphereConv2d):
                 if mod.groups == 1:
                     k3 = mod.kernel_size[0] == 3
-                    plan[id(mod)] = pack_dense_weight_bf16x3(mod.weight) if (split and k3) else pack_dense_weight(mod.weight)
+                    plan[id(mod)] = pack(mod.weight) if (split and k3) else pack_dense_weight(mod.weight)
                 else:
                     plan[id(mod)] = pack_depthwise_weight(mod.weight)
             elif isinstance(mod, nn.Conv2d):  # 1x1 convs
                 w = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
-                plan[id(mod)] = pack_dense_weight_bf16x3(w[:, :, None, None]) if (split and mod.groups == 1) else w
+                plan[id(mod)] = pack(w[:, :, None, None]) if (split and mod.groups == 1) else w
             elif isinstance(mod, SanaMultiscaleLinearAttention):
                 w = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], dim=0).contiguous()
-                plan[id(mod)] = pack_dense_weight_bf16x3(w[:, :, None, None]) if split else w
+                plan[id(mod)] = pack(w[:, :, None, None]) if split else w
                 if split:
-                    plan[id(mod.to_out)] = pack_dense_weight_bf16x3(mod.to_out.weight[:, :, None, None])
+                    plan[id(mod.to_out)] = pack(mod.to_out.weight[:, :, None, None])
         self._plan = plan
         self._plan_gen += 1
 
@@ -317,7 +315,11 @@ class AutoencoderDC(ModelMixin):
     # once by whoever produces the tensor: conv / norm / pixel-shuffle / attention / GLU epilogues).  fp32 mode: xs is None.
     @property
     def _split(self):
-        return self.gemm_precision == "bf16x3"
+        return self.gemm_precision != "fp32"
+
+    @property
+    def _fmt(self):  # format of the operand rows the dense convs read
+        return hip.FMT_BF16 if self.gemm_precision == "bf16" else hip.FMT_SPLIT
 
     @staticmethod
     def _c8(c):
@@ -335,8 +337,8 @@ class AutoencoderDC(ModelMixin):
             ldy = self._c8(cout) if out_split else cout
             y = torch.empty(B * H * W, ldy, device=xs.device, dtype=torch.float32)
             hip.sphere_conv_nhwc_split(xs, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=xs.shape[1], cout=cout, ldy=ldy,
-                                       bias=conv.bias, R=R, ldr=cout if R is not None else 0, ksize=3, act=act,
-                                       out_fmt=hip.FMT_SPLIT if out_split else hip.FMT_F32)
+                                       bias=conv.bias, R=R, ldr=cout if R is not None else 0, ksize=3, act=act, in_fmt=self._fmt,
+                                       out_fmt=self._fmt if out_split else hip.FMT_F32)
             return y
         y = torch.empty(B * H * W, cout, device=x32.device, dtype=torch.float32)
         hip.sphere_conv_nhwc(x32, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=x32.shape[1], cout=cout, bias=conv.bias, R=R,
@@ -349,7 +351,7 @@ class AutoencoderDC(ModelMixin):
         x32, xs = x
         if self._split:
             hip.sphere_conv_nhwc_split(xs, self._plan[key], y, B=B, H=H, W=W, cin=K, ldx=xs.shape[1], cout=N, ldy=ldc, bias=bias, ksize=1,
-                                       act=act)
+                                       act=act, in_fmt=self._fmt)
         else:
             hip.gemm(x32, w_fp32, y, M=B * H * W, N=N, K=K, ldc=ldc, bias=bias, act=act)
 
@@ -357,7 +359,7 @@ class AutoencoderDC(ModelMixin):
         """RMSNorm rows (+ residual, activation) -> stream tensor"""
         y32 = torch.empty(M, C, device=u.device, dtype=torch.float32) if (want32 or not self._split) else None
         ys = self._srows(M, C, u.device)
-        hip.rmsnorm_rows(u, norm.weight, y32, rows=M, C=C, eps=norm.eps, b=norm.bias, resid=resid, act=act, ys=ys)
+        hip.rmsnorm_rows(u, norm.weight, y32, rows=M, C=C, eps=norm.eps, b=norm.bias, resid=resid, act=act, ys=ys, fmt=self._fmt)
         return y32, ys
 
     def _resblock(self, blk, x, B, H, W):
@@ -383,7 +385,7 @@ class AutoencoderDC(ModelMixin):
         groups = wide // 96  # consecutive 96-channel groups of the concat, split (q, k, v) -- models/DCAE.py:239-243 (Q8)
         att = torch.empty(M, groups * 32, device=dev, dtype=torch.float32)  # only to_out reads it: split rows in the bf16x3 mode
         hip.relu_linear_attn_nhwc(qkv, att, B=B, P=H * W, groups=groups, ldq=wide, ldy=groups * 32, eps=at.eps,
-                                  out_fmt=hip.FMT_SPLIT if split else hip.FMT_F32)
+                                  out_fmt=self._fmt if split else hip.FMT_F32)
         o = torch.empty(M, C, device=dev, dtype=torch.float32)
         self._mm((None, att) if split else (att, None), id(at.to_out), at.to_out.weight, o, B, H, W, N=C, K=groups * 32)
         y = self._norm(o, at.norm_out, x[0], M, C)
@@ -394,7 +396,7 @@ class AutoencoderDC(ModelMixin):
         self._mm(y, id(g.conv_inverted), self._plan[id(g.conv_inverted)], h1, B, H, W, N=hid2, K=C, bias=g.conv_inverted.bias, act=hip.ACT_SILU)
         h2 = torch.empty(M, hid2 // 2, device=dev, dtype=torch.float32)  # only conv_point reads it
         hip.sphere_dwconv_nhwc(h1, self._plan[id(g.conv_depth)], h2, B=B, H=H, W=W, C=hid2, bias=g.conv_depth.bias, ksize=3, glu=True,
-                               out_fmt=hip.FMT_SPLIT if split else hip.FMT_F32)
+                               out_fmt=self._fmt if split else hip.FMT_F32)
         h3 = torch.empty(M, C, device=dev, dtype=torch.float32)
         self._mm((None, h2) if split else (h2, None), id(g.conv_point), self._plan[id(g.conv_point)], h3, B, H, W, N=C, K=hid2 // 2)
         return self._norm(h3, g.norm, y[0], M, C)
@@ -410,13 +412,13 @@ class AutoencoderDC(ModelMixin):
                 M2 = B * (H // 2) * (W // 2)
                 y = torch.empty(M2, blk.out_channels, device=cv.device, dtype=torch.float32)
                 ys = self._srows(M2, blk.out_channels, cv.device)
-                hip.pixel_unshuffle_shortcut(cv, x[0], y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys)
+                hip.pixel_unshuffle_shortcut(cv, x[0], y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys, fmt=self._fmt)
                 x, H, W = (y, ys), H // 2, W // 2
             elif isinstance(blk, DCUpBlock2d):
                 cv = self._conv(x, B, H, W, blk.conv)
                 y = torch.empty(B * 4 * H * W, blk.out_channels, device=cv.device, dtype=torch.float32)
                 ys = self._srows(B * 4 * H * W, blk.out_channels, cv.device)
-                hip.pixel_shuffle_shortcut(cv, x[0], y, B=B, H=H, W=W, cout=blk.out_channels, cin=blk.in_channels, ys=ys)
+                hip.pixel_shuffle_shortcut(cv, x[0], y, B=B, H=H, W=W, cout=blk.out_channels, cin=blk.in_channels, ys=ys, fmt=self._fmt)
                 x, H, W = (y, ys), 2 * H, 2 * W
             else:
                 raise TypeError(type(blk))
@@ -426,7 +428,7 @@ class AutoencoderDC(ModelMixin):
         """fp32 rows -> stream tensor (bf16x3 mode: + the split copy)"""
         xs = self._srows(M, C, x32.device)
         if xs is not None:
-            hip.split_rows(x32, xs, rows=M, C=C, ldx=x32.shape[1], lds=xs.shape[1])
+            hip.split_rows(x32, xs, rows=M, C=C, ldx=x32.shape[1], lds=xs.shape[1], fmt=self._fmt)
         return x32, xs
 
     def _encode_launch(self, x, st=None):
