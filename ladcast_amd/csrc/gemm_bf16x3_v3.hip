@@ -779,13 +779,19 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     long long best = 0;
     if (same_kt) {
       const int kt = a.pr[0].kt;
-      for (int sfac = 1; sfac <= 4; ++sfac) {
+      // more workgroups win unless they are bought with many more pieces per tile (a hand-off each): 2 % per extra split factor.
+      // 288 tiles x 320 k-steps (the 1.6B model's single-block out projection): 192 ranges at s = 2, 240 at s = 5 - 279 -> 269 us
+      double best_score = 0.0;
+      for (int sfac = 1; sfac <= 8; ++sfac) {
         if (kt % sfac || (sfac > 1 && kt / sfac < 8)) continue;  // whole tiles (sfac 1) at any depth
         const long long items = tiles * sfac;
         long long gd = items < CUS ? items : CUS;
         while (gd > 1 && items % gd) --gd;
-        const long long score = gd * (34 - sfac);
-        if (score > best * (34 - 1) / 33 && gd > best) best = gd;
+        const double score = static_cast<double>(gd) * (1.0 - 0.02 * (sfac - 1));
+        if (score > best_score) {
+          best_score = score;
+          best = gd;
+        }
       }
     }
     long long few = 0;  // few tiles (the 84-column output head: 15 tiles): aligned split-K over more workgroups
