@@ -356,8 +356,9 @@ int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* y, long lon
  * y[B][P][groups*32] (models/DCAE.py:158-175,239-253; fp32, eps 1e-15). */
 int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                               void* workspace, long long workspace_bytes, void* stream);
-/* workspace: ldc_relu_linear_attn_workspace_bytes(B, P, groups) bytes of device scratch (partial KV sums of the pixel
- * slices: one frame has only ~63 groups, so the KV pass is cut along the pixels to fill the chip). */
+/* One launch: a 16-wave workgroup per (batch, group), both contractions on the fp32 matrix core (exact fp32 products), the partial
+ * KV of the waves added in wave order (bitwise reproducible).  workspace: unused since round 2 (may be NULL;
+ * ldc_relu_linear_attn_workspace_bytes returns 0) - the argument stays for callers of the earlier slice-partials form. */
 long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups);
 /* y = act(RMSNorm_C(x) * w + b (+ resid)) per pixel row (models/DCAE.py:259-260,317-322,371-377,729-730). */
 int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y, long long rows,

@@ -525,20 +525,11 @@ def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
     _check(lib.ldc_grouped_conv1x1_nhwc(_p(x), _p(wt), _p(y), M, groups, ldx, ldy, _stream()), "ldc_grouped_conv1x1_nhwc")
 
 
-_rla_ws = {}
-_rla_keep = []
-
-
 def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F32):
+    """ReLU linear attention over consecutive 96-channel (q | k | v) groups; one launch, no scratch (ldc_relu_linear_attn_workspace_bytes
+    is 0 since round 2)"""
     _dev(qkv, y)
-    need = int(lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups))
-    key = (str(qkv.device), torch.cuda.current_stream(qkv.device).cuda_stream)
-    if key not in _rla_ws or _rla_ws[key].numel() * 4 < need:
-        if key in _rla_ws:
-            _rla_keep.append(_rla_ws[key])  # a captured hipGraph may still point at the smaller one
-        _rla_ws[key] = torch.empty(need // 4 + 1, device=qkv.device, dtype=torch.float32)
-    ws = _rla_ws[key]
-    _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), _p(ws), ws.numel() * 4, _stream()),
+    _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), None, 0, _stream()),
            "ldc_relu_linear_attn_nhwc_fmt")
 
 
