@@ -317,6 +317,9 @@ int ldc_chan_affine(const float* x, float* y, const float* mean, const float* st
  * ------------------------------------------------------------------------- */
 int ldc_edm_scale_f64_to_f32(const double* x, double c_in, float* out, long long n, void* stream);
 int ldc_edm_init_state(const float* noise, double sigma0, double* x, long long n, void* stream);
+/* stochastic churn of the non-deterministic sampler (pipelines/edm_sampler.py:67-76): x_hat = x_cur + coef * noise (fp64),
+ * coef = sqrt(t_hat^2 - t_cur^2) * S_noise computed in fp32 on the host as the reference does */
+int ldc_edm_churn(const double* x_cur, const double* noise, double coef, double* x_hat, long long n, void* stream);
 /* den = c_skip*x + c_out*F; d = (x-den)/t_hat; x_next = x + dt*d */
 int ldc_edm_euler(const double* x_hat, const float* F, double c_skip, double c_out, double t_hat,
                   double dt, double* x_next, double* d_cur, long long n, void* stream);

@@ -16,6 +16,13 @@ __global__ void edm_init_kernel(const float* __restrict__ noise, double sigma0, 
   if (i < n) x[i] = static_cast<double>(noise[i]) * sigma0;
 }
 
+// stochastic churn (pipelines/edm_sampler.py:67-76): x_hat = x_cur + coef * noise, fp64, coef = sqrt(t_hat^2 - t_cur^2) * S_noise
+__global__ void edm_churn_kernel(const double* __restrict__ x_cur, const double* __restrict__ noise, double coef,
+                                 double* __restrict__ x_hat, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) x_hat[i] = x_cur[i] + coef * noise[i];
+}
+
 __global__ void edm_euler_kernel(const double* __restrict__ x_hat, const float* __restrict__ F, double c_skip,
                                  double c_out, double t_hat, double dt, double* __restrict__ x_next,
                                  double* __restrict__ d_cur, long long n) {
@@ -91,6 +98,12 @@ extern "C" int ldc_edm_init_state(const float* noise, double sigma0, double* x, 
   LDC_CHECK_PTR(noise);
   LDC_CHECK_PTR(x);
   LDC_LAUNCH_1D(edm_init_kernel, n, noise, sigma0, x);
+}
+extern "C" int ldc_edm_churn(const double* x_cur, const double* noise, double coef, double* x_hat, long long n, void* stream) {
+  LDC_CHECK_PTR(x_cur);
+  LDC_CHECK_PTR(noise);
+  LDC_CHECK_PTR(x_hat);
+  LDC_LAUNCH_1D(edm_churn_kernel, n, x_cur, noise, coef, x_hat);
 }
 extern "C" int ldc_edm_euler(const double* x_hat, const float* F, double c_skip, double c_out, double t_hat, double dt,
                              double* x_next, double* d_cur, long long n, void* stream) {

@@ -108,6 +108,7 @@ def _load():
         "ldc_edm_scale_f64_to_f32": (I, [P, D, P, L, P]),
         "ldc_edm_init_state": (I, [P, D, P, L, P]),
         "ldc_edm_euler": (I, [P, P, D, D, D, D, P, P, L, P]),
+        "ldc_edm_churn": (I, [P, P, c_double, P, L, P]),
         "ldc_edm_heun": (I, [P, P, P, P, D, D, D, D, L, P]),
         "ldc_f64_to_f32": (I, [P, P, L, P]),
         "ldc_dpm_step": (I, [P, P, P, P, P, F, F, F, F, F, I, L, P]),
@@ -439,6 +440,14 @@ def edm_scale_f64_to_f32(x, c_in, out):
 def edm_init_state(noise, sigma0, x):
     _dev(noise, x)
     _check(lib.ldc_edm_init_state(_p(noise), sigma0, _p(x), x.numel(), _stream()), "ldc_edm_init_state")
+
+
+def edm_churn(x_cur, noise, coef, x_hat):
+    """x_hat = x_cur + coef * noise (fp64; the stochastic branch of the EDM sampler)"""
+    _dev(x_cur, noise, x_hat)
+    if noise.dtype != torch.float64 or x_cur.dtype != torch.float64:
+        raise TypeError("edm_churn works on the fp64 sampler state")
+    _check(lib.ldc_edm_churn(_p(x_cur), _p(noise), coef, _p(x_hat), x_cur.numel(), _stream()), "ldc_edm_churn")
 
 
 def edm_euler(x_hat, F, c_skip, c_out, t_hat, dt, x_next, d_cur):

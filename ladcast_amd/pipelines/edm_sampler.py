@@ -1,4 +1,4 @@
-"""``edm_AR_sampler`` -- deterministic EDM Heun sampler (pipelines/edm_sampler.py:10-120) with
+"""``edm_AR_sampler`` -- EDM Heun sampler (pipelines/edm_sampler.py:10-120; deterministic, and the stochastic-churn branch) with
 the fp64 state kept on the device and every update fused into one HIP kernel per half-step.
 
 Per solver step the reference issues ~15 separate fp64 torch ops (clone, scale, cast, c_skip /
@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Union
 
+import numpy as np
 import torch
 
 from .. import hip
@@ -42,8 +43,6 @@ def edm_AR_sampler(
             f" size of {batch_size}. Make sure the batch size matches the length of the generators."
         )
     assert known_latents is not None, "known_latents must be provided"
-    if not deterministic:
-        raise NotImplementedError("S_churn > 0 is never used by the reference rollout (pipelines/utils.py:716-727)")
     if isinstance(device, str):
         device = torch.device(device)
 
@@ -62,6 +61,14 @@ def edm_AR_sampler(
     # copies around 39 per-forward graphs (2.5 % of the chunk), and the host's speed stops mattering (8 ranks on one box).
     # Used when the model runs in hipGraph mode and exposes its launch-only forward; same kernels, same numbers.
     chunk_graph = bool(getattr(net, "use_hip_graph", False)) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs")
+    if not deterministic:
+        # stochastic churn (:67-76; never enabled by the reference's own rollout driver, pipelines/utils.py:716-727): the noise comes
+        # from the caller's `randn_like` at every step, so the chunk is launched eagerly - nothing to capture once and replay
+        out = torch.empty(shape, device=device, dtype=torch.float32)
+        fwd = lambda x, t, k, te_: net(x, t, k, time_elapsed=timestamps).sample  # noqa: E731
+        _heun_chunk_stochastic(fwd, noise_scheduler, t_steps, latents, known, out, shape, device, num_inference_steps, randn_like, S_churn, S_min,
+                               S_max, S_noise)
+        return out
     if chunk_graph:
         te = net.time_elapsed_embedding(timestamps)  # eager, cached per chunk; the graph reads its persistent buffer
         plan_id = net.plan_identity()  # a re-packed / re-loaded model gets new graphs
@@ -117,4 +124,37 @@ def _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, te, out,
             hip.edm_scale_f64_to_f32(x_next, float(noise_scheduler._c_in(t_next)), x_in)
             F = fwd(x_in, c_noise[i + 1 : i + 2], known, te)
             hip.edm_heun(x_hat, x_next, F, d_cur, float(c_skip), float(c_out), float(t_next), float(t_next - t_cur))
+    hip.f64_to_f32(x_next, out)
+
+
+def _heun_chunk_stochastic(fwd, noise_scheduler, t_steps, latents, known, out, shape, device, num_inference_steps, randn_like, S_churn, S_min,
+                           S_max, S_noise):
+    """pipelines/edm_sampler.py:60-113 with `deterministic=False`: before every step the state is pushed back up to the noise level
+    t_hat = t_cur + gamma t_cur with fresh noise from `randn_like` (called with the fp64 device state, every step - also when
+    gamma = 0 - so the caller's random stream advances as in the reference), and the step runs from t_hat.  All scalars are
+    formed on the host with the reference's own expressions (fp32 0-dim tensor arithmetic) and widened to double."""
+    x_cur = torch.empty(shape, device=device, dtype=torch.float64)
+    x_hat = torch.empty_like(x_cur)
+    x_next = torch.empty_like(x_cur)
+    d_cur = torch.empty_like(x_cur)
+    x_in = torch.empty(shape, device=device, dtype=torch.float32)
+    hip.edm_init_state(latents, float(t_steps[0]), x_next)
+    for i in range(num_inference_steps):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_cur, x_next = x_next, x_cur
+        gamma = min(S_churn / num_inference_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
+        t_hat = torch.as_tensor(t_cur + gamma * t_cur)
+        noise = randn_like(x_cur)
+        if noise.dtype != torch.float64 or noise.device != x_cur.device:
+            noise = noise.to(device=x_cur.device, dtype=torch.float64)
+        hip.edm_churn(x_cur, noise.contiguous(), float((t_hat**2 - t_cur**2).sqrt() * S_noise), x_hat)
+        c_skip, c_out = noise_scheduler._c_skip_out(t_hat)
+        hip.edm_scale_f64_to_f32(x_hat, float(noise_scheduler._c_in(t_hat)), x_in)
+        F = fwd(x_in, noise_scheduler.precondition_noise(t_hat.reshape(1)).to(device), known, None)
+        hip.edm_euler(x_hat, F, float(c_skip), float(c_out), float(t_hat), float(t_next - t_hat), x_next, d_cur)
+        if i < num_inference_steps - 1:
+            c_skip, c_out = noise_scheduler._c_skip_out(t_next)
+            hip.edm_scale_f64_to_f32(x_next, float(noise_scheduler._c_in(t_next)), x_in)
+            F = fwd(x_in, noise_scheduler.precondition_noise(t_next.reshape(1)).to(device), known, None)
+            hip.edm_heun(x_hat, x_next, F, d_cur, float(c_skip), float(c_out), float(t_next), float(t_next - t_hat))
     hip.f64_to_f32(x_next, out)

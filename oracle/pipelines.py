@@ -90,15 +90,13 @@ def edm_AR_sampler(
     generator=None,
     device="cpu",
 ):
-    """Deterministic EDM Heun sampler, fp64 state (pipelines/edm_sampler.py:10-120)."""
+    """EDM Heun sampler, fp64 state (pipelines/edm_sampler.py:10-120), incl. the stochastic-churn branch (:67-76)."""
     if isinstance(generator, list) and len(generator) != batch_size:
         raise ValueError(
             f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
             f" size of {batch_size}. Make sure the batch size matches the length of the generators."
         )
     assert known_latents is not None, "known_latents must be provided"
-    if not deterministic:
-        raise NotImplementedError("stochastic churn is never enabled on the reference path")
     device = torch.device(device) if isinstance(device, str) else device
     shape = (batch_size, net.config.out_channels, return_seq_len, *known_latents.shape[-2:])
     latents = randn_tensor(shape, generator=generator, device=device, dtype=net.dtype)
@@ -106,7 +104,13 @@ def edm_AR_sampler(
     t_steps = noise_scheduler.sigmas.to(device)
     x_next = latents.to(torch.float64) * t_steps[0]
     for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
-        x_hat, t_hat = x_next, t_cur
+        x_cur = x_next
+        if not deterministic:  # :67-76: push the state back up to t_hat = (1 + gamma) t_cur with fresh noise
+            gamma = min(S_churn / num_inference_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
+            t_hat = torch.as_tensor(t_cur + gamma * t_cur)
+            x_hat = x_cur + (t_hat**2 - t_cur**2).sqrt() * S_noise * randn_like(x_cur)
+        else:
+            x_hat, t_hat = x_cur, t_cur
         c_noise = noise_scheduler.precondition_noise(t_hat)
         x_in = noise_scheduler.precondition_inputs(x_hat.clone(), t_hat)
         den = net(x_in.to(torch.float32), c_noise.reshape(-1).to(torch.float32), known_latents, time_elapsed=timestamps).sample

@@ -197,6 +197,13 @@ def sampler_fixtures():
                                          timestamps=ts, generator=gens(3)).numpy()
     out["edm_n1"] = ns["edm_AR_sampler"](net, EDMDPMSolverMultistepScheduler(), batch_size=1, return_seq_len=4, num_inference_steps=1, known_latents=known1,
                                          timestamps=None, generator=gens(1)).numpy()
+    # stochastic churn (deterministic=False): the caller's randn_like feeds every step; gamma = S_churn / N (a Python float) and the
+    # capped sqrt(2) - 1 (a numpy scalar) - the two ways the reference's expression evaluates - with S_min / S_max cutting steps out
+    for name, churn in (("edm_churn_lo", 1.5), ("edm_churn_cap", 40.0)):
+        gc = torch.Generator("cpu").manual_seed(77)
+        out[name] = ns["edm_AR_sampler"](net, EDMDPMSolverMultistepScheduler(), batch_size=3, return_seq_len=2, num_inference_steps=5, known_latents=known3,
+                                         timestamps=ts, generator=gens(3), deterministic=False, S_churn=churn, S_min=0.05, S_max=50.0, S_noise=1.003,
+                                         randn_like=lambda x: torch.randn(x.shape, generator=gc, dtype=x.dtype)).numpy()
     out["pipe_n6"] = RefPipe()(batch_size=3, return_seq_len=2, known_latents=known3, timestamps=ts, generator=gens(3), num_inference_steps=6, return_dict=False)[0].numpy()
     out["pipe_n20"] = RefPipe()(batch_size=1, return_seq_len=1, known_latents=known1, timestamps=ts, generator=gens(1), num_inference_steps=20).fields.numpy()
     out["ens_edm"] = ns["ensemble_AR_sampler"](RefPipe(), 5, 3, 4, known_latents=known1, timestamps=ts, batch_size=2, sampler_type="edm").numpy()

@@ -187,6 +187,35 @@ def test_tiny_sampler_chunk_matches_oracle(tiny_pair, sampler_type):
     assert rel_l2(part.cpu(), got[2:3].cpu()) < 1e-5
 
 
+def test_stochastic_churn_chunk_matches_oracle(tiny_pair):
+    """edm_AR_sampler(deterministic=False, S_churn, S_min, S_max, S_noise, randn_like) (pipelines/edm_sampler.py:67-76) with the real
+    (tiny) network: same noise stream on both sides (a seeded CPU generator behind the caller's randn_like), hipGraph mode on (the
+    stochastic chunk is launched eagerly whatever the mode) - within the chunk budget of the oracle; and the noise is really used"""
+    from ladcast_amd.pipelines import edm_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o, g = tiny_pair
+    known, ts = synth_known(2), torch.tensor([2018010100])
+    kw = dict(batch_size=2, return_seq_len=4, num_inference_steps=6, timestamps=None, deterministic=False, S_churn=3.0, S_min=0.01, S_max=60.0,
+              S_noise=1.007)
+
+    def noise_fn(seed):
+        gc = torch.Generator("cpu").manual_seed(seed)
+        return lambda x: torch.randn(x.shape, generator=gc, dtype=x.dtype).to(x.device)
+
+    gens = lambda: [torch.Generator("cpu").manual_seed(k) for k in range(2)]  # noqa: E731
+    want = OP.edm_AR_sampler(o, OracleScheduler(), known_latents=known, generator=gens(), randn_like=noise_fn(5), **kw)
+    g.enable_hip_graph(True)
+    try:
+        got = edm_AR_sampler(g, EDMDPMSolverMultistepScheduler(), known_latents=known.cuda(), generator=gens(), randn_like=noise_fn(5), device="cuda", **kw)
+        other = edm_AR_sampler(g, EDMDPMSolverMultistepScheduler(), known_latents=known.cuda(), generator=gens(), randn_like=noise_fn(6), device="cuda", **kw)
+    finally:
+        g.enable_hip_graph(False)
+    assert rel_l2(got.cpu(), want) < TOL
+    assert rel_l2(other.cpu(), want) > 1e-2  # another noise stream, another sample
+    del ts
+
+
 def test_bf16x3_mode_stays_inside_the_parity_budget(tiny_pair):
     """split-bf16 GEMM mode: per-forward and per-chunk rel-L2 vs the fp32 CPU oracle.  Budget: 1e-4 (north star);
     measured on CPU emulation: 4e-6 / 2e-6 (tests/split_precision_study.py)."""

@@ -36,6 +36,12 @@ def test_product_samplers_reproduce_the_reference_code(golden_dir):
     got = edm_AR_sampler(net, EDMDPMSolverMultistepScheduler(), batch_size=1, return_seq_len=4, num_inference_steps=1, known_latents=known1, timestamps=None,
                          generator=_gens(1), device="cuda")
     assert _rel(got, z["edm_n1"]) < 1e-6
+    for name, churn in (("edm_churn_lo", 1.5), ("edm_churn_cap", 40.0)):  # the stochastic-churn branch, noise from the caller's randn_like
+        gc = torch.Generator("cpu").manual_seed(77)
+        got = edm_AR_sampler(net, EDMDPMSolverMultistepScheduler(), batch_size=3, return_seq_len=2, num_inference_steps=5, known_latents=known3,
+                             timestamps=ts, generator=_gens(3), deterministic=False, S_churn=churn, S_min=0.05, S_max=50.0, S_noise=1.003,
+                             randn_like=lambda x: torch.randn(x.shape, generator=gc, dtype=x.dtype).to(x.device), device="cuda")
+        assert _rel(got, z[name]) < 1e-6
     pipe = AutoRegressive2DPipeline(net, EDMDPMSolverMultistepScheduler())
     got = pipe(batch_size=3, return_seq_len=2, known_latents=known3, timestamps=ts, generator=_gens(3), num_inference_steps=6, return_dict=False)[0]
     assert _rel(got, z["pipe_n6"]) < 1e-6

@@ -33,6 +33,15 @@ def test_sampler_loops_equal_the_reference_code(golden_dir):
     got = OP.edm_AR_sampler(net, EDMDPMSolverMultistepScheduler(), batch_size=1, return_seq_len=4, num_inference_steps=1, known_latents=known1, timestamps=None,
                             generator=_gens(1))
     assert torch.equal(got, z["edm_n1"])  # one step: Euler only (t_next = 0)
+    # the stochastic-churn branch (deterministic=False, pipelines/edm_sampler.py:67-76): gamma as a Python float and as the capped
+    # numpy scalar, steps outside [S_min, S_max] un-churned, the caller's randn_like consumed at every step
+    for name, churn in (("edm_churn_lo", 1.5), ("edm_churn_cap", 40.0)):
+        gc = torch.Generator("cpu").manual_seed(77)
+        got = OP.edm_AR_sampler(net, EDMDPMSolverMultistepScheduler(), batch_size=3, return_seq_len=2, num_inference_steps=5, known_latents=known3,
+                                timestamps=ts, generator=_gens(3), deterministic=False, S_churn=churn, S_min=0.05, S_max=50.0, S_noise=1.003,
+                                randn_like=lambda x: torch.randn(x.shape, generator=gc, dtype=x.dtype))
+        assert torch.equal(got, z[name])
+    assert not torch.equal(z["edm_churn_lo"], z["edm_n5"]) and not torch.equal(z["edm_churn_lo"], z["edm_churn_cap"])
     pipe = OP.AutoRegressive2DPipeline(net, EDMDPMSolverMultistepScheduler())
     got = pipe(batch_size=3, return_seq_len=2, known_latents=known3, timestamps=ts, generator=_gens(3), num_inference_steps=6, return_dict=False)[0]
     assert torch.equal(got, z["pipe_n6"])
