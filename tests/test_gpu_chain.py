@@ -99,6 +99,31 @@ def test_full_375m_chunk_matches_oracle():
         g.set_gemm_precision("fp32")
 
 
+def test_chunk_replays_are_bitwise_reproducible():
+    """Soak: the captured 375M Heun chunk (39 forwards x 52 launches: stream-K GEMMs with in-launch hand-offs, the split attention,
+    the sampler updates) replayed 25 times from the same noise and conditioning, in the split-bf16 and the single-term mode, with
+    another workload's chunks in between (different noise -> different data in every workspace and LDS region): every replay of
+    the first workload returns the same bits.  A race, a stale-LDS read or an un-re-armed counter shows up here as a flipped bit."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    g = to_hip(make_ar(dict(CONFIG_375M)), dict(CONFIG_375M))
+    known, ts = synth_known(1).cuda(), torch.tensor([2018010100]).cuda()
+    other = (synth_known(1) * 1.7 + 0.3).cuda()
+    pipe = AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())
+    for mode in ("bf16x3", "bf16"):
+        g.set_gemm_precision(mode).enable_hip_graph(True)
+        ref = ensemble_AR_sampler(pipe, 1, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm", device="cuda")
+        assert torch.isfinite(ref).all()
+        for it in range(25):
+            if it % 3 == 0:
+                ensemble_AR_sampler(pipe, 1, 4, 20, known_latents=other, timestamps=ts, sampler_type="edm", device="cuda", member_ids=[it + 1])
+            got = ensemble_AR_sampler(pipe, 1, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm", device="cuda")
+            assert torch.equal(got, ref), (mode, it)
+        g.enable_hip_graph(False)
+    g.set_gemm_precision("fp32")
+
+
 def test_ten_chunk_chain_bf16x3_error_growth():
     """BASELINE configs[2]'s share of one GPU in shape: 2 members x 40 lead steps = 10 chained chunks of R = 4 (20 Heun steps each,
     390 forwards per member), tiny widths so the CPU oracle finishes in about a minute.  Each chunk starts from the previous
