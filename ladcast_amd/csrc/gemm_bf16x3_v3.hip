@@ -364,6 +364,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const int bn = r_in / h_sr;
     const int bm = sr * P.rm + (r_in - bn * h_sr);
     const int M = P.d.M, N = P.d.N, K = P.d.K;
+    // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
+    // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
+    const bool wave_rows = bm * BM + 16 * RT * wave < M;
     const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
     const int lda = P.d.lda;
     const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   LDC_SB;
     // the 3 RT MFMAs of column tile CT with A fragments (AH, AL); with two row tiles their accumulation chains alternate
 #define LDC_CT(CT, WH, WL, AH, AL)                                               \
-  {                                                                              \
+  if (wave_rows) {                                                               \
     if constexpr (TERMS == 1) {                                                  \
       LDC_MM(acc[(CT)], WH, AH[0])                                               \
       if constexpr (RT == 2) {                                                   \
