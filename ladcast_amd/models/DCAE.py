@@ -54,6 +54,10 @@ class SanaMultiscaleAttentionProjection(nn.Module):
         self.proj_out = nn.Conv2d(ch, ch, 1, 1, 0, groups=3 * num_attention_heads, bias=False)
 
 
+class SanaMultiscaleAttnProcessor2_0:
+    """marker of the built-in (fused) linear-attention path, models/DCAE.py:200-267; never called"""
+
+
 class SanaMultiscaleLinearAttention(nn.Module):
     def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15):
         super().__init__()
@@ -70,7 +74,21 @@ class SanaMultiscaleLinearAttention(nn.Module):
         self.to_qkv_multiscale = nn.ModuleList([SanaMultiscaleAttentionProjection(inner, self.heads, ks) for ks in kernel_sizes])
         self.to_out = nn.Linear(inner * (1 + len(kernel_sizes)), out_channels, bias=False)
         self.norm_out = _RMSNormP(out_channels, 1e-5)  # diffusers get_normalization("rms_norm") default eps
-        self.processor = None
+        self._processor = SanaMultiscaleAttnProcessor2_0()
+
+    # models/DCAE.py:156: the reference keeps its processor in a plain attribute.  Here the block runs fused (ldc_relu_linear_attn_nhwc_fmt
+    # between the conv GEMMs); a foreign processor is REFUSED, not ignored.
+    @property
+    def processor(self):
+        return self._processor
+
+    @processor.setter
+    def processor(self, value):
+        if not isinstance(value, SanaMultiscaleAttnProcessor2_0):
+            raise NotImplementedError(
+                "the DCAE's multiscale linear attention runs fused on the HIP path (ldc_sphere_conv_nhwc_split + ldc_relu_linear_attn_nhwc_fmt); "
+                "a user-supplied processor is not supported - change the arithmetic through the C ABI (include/ladcast_hip.h)")
+        self._processor = value
 
 
 class GLUMBConv(nn.Module):

@@ -48,6 +48,24 @@ class _RMSNormP(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(dim))
 
+    def forward(self, x):
+        """torch arithmetic, reached ONLY from a user-supplied attention processor (`set_attn_processor`): diffusers RMSNorm - fp32
+        statistics, x * rsqrt(mean(x^2) + eps) * weight.  The built-in path runs this inside ldc_qk_rmsnorm_rope / the QKV epilogue."""
+        var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        return x * torch.rsqrt(var + self.eps) * self.weight
+
+
+class LaDCastAttnProcessor2_0:
+    """The built-in attention processor (models/LaDCast_3D_model.py:64-221).  Here it is a MARKER: an attention layer whose
+    processor is an instance of this class (the default) runs the fused HIP path - QKV GEMM with the norm / rotary / split epilogue,
+    `ldc_attn_fwd*`, output projections as GEMM epilogues - and `__call__` is never invoked.  Any other object installed through
+    `set_attn_processor` / `Attention.set_processor` is CALLED with the reference's protocol, on torch tensors (slow path, fp32 mode
+    only; see `LaDCastTransformer3DModel.set_attn_processor`)."""
+
+    def __call__(self, *a, **k):
+        raise RuntimeError("the built-in processor is fused into the HIP forward and is not callable on its own; "
+                           "use the C ABI (ldc_gemm_grouped_bf16x3_qkv + ldc_attn_fwd_split, or ldc_qk_rmsnorm_rope + ldc_attn_fwd)")
+
 
 class _TimestepEmbeddingP(nn.Module):
     def __init__(self, in_channels, dim):
@@ -99,15 +117,27 @@ class _AttentionP(nn.Module):
             self.norm_added_q = _RMSNormP(head_dim, eps)
             self.norm_added_k = _RMSNormP(head_dim, eps)
             self.to_add_out = nn.Linear(inner, dim)
+        else:  # diffusers Attention: absent projections are None attributes (the reference's processor tests `attn.add_q_proj is None`)
+            self.add_q_proj = self.add_k_proj = self.add_v_proj = None
+            self.norm_added_q = self.norm_added_k = None
+            self.to_add_out = None
         if not pre_only:
             self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Identity()])
-        self.processor = None
+        else:
+            self.to_out = None
+        self.processor = LaDCastAttnProcessor2_0()
 
     def set_processor(self, processor):
         self.processor = processor
 
     def get_processor(self):
         return self.processor
+
+    @property
+    def foreign_processor(self):
+        """the user-supplied processor of this layer, or None while the built-in (fused) one is installed"""
+        p = self.processor
+        return None if p is None or isinstance(p, LaDCastAttnProcessor2_0) else p
 
 
 class _PatchEmbedP(nn.Module):
@@ -279,6 +309,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         """Capture the ~110 kernel launches of one forward into a hipGraph per input shape and replay it
         (the launches are otherwise host-bound: ~8 us of Python per launch against 5-15 us kernels).
         Inputs are copied into static buffers; the returned sample is a fresh tensor."""
+        if flag and self._foreign_processors():
+            raise NotImplementedError("hipGraph capture is for the built-in attention path; a user-supplied attention processor runs eagerly")
         self.use_hip_graph = bool(flag)
         if not flag:
             self._graphs = {}
@@ -331,6 +363,14 @@ class LaDCastTransformer3DModel(ModelMixin):
         return out
 
     def set_attn_processor(self, processor):
+        """models/LaDCast_3D_model.py:793-827.  An instance of `LaDCastAttnProcessor2_0` (the default) selects the fused HIP attention
+        path.  ANY OTHER processor is honoured, never ignored: the layer's attention stage (q/k/v projections, q/k norm, rotary
+        embedding, SDPA and - dual blocks - the output projections) is then the processor's own torch code, called with the reference's
+        protocol `proc(attn, hidden_states, encoder_hidden_states=, attention_mask=, image_rotary_emb=, cond_image_rotary_emb=)`
+        (only the keywords its signature accepts, as diffusers' `Attention.forward` does) on fp32 device tensors, `attn` being this
+        model's parameter container (diffusers attribute names, `nn.Linear` projections, callable RMSNorms).  That is a slow path by
+        nature (torch kernels, ~3x the launches); it needs `set_gemm_precision("fp32")` and eager launching, and the forward raises
+        `NotImplementedError` otherwise.  The fast way to change the attention arithmetic is the C ABI."""
         mods = {f"{n}.processor": m for n, m in self.named_modules() if isinstance(m, _AttentionP)}
         if isinstance(processor, dict):
             if len(processor) != len(mods):
@@ -343,6 +383,28 @@ class LaDCastTransformer3DModel(ModelMixin):
         else:
             for m in mods.values():
                 m.set_processor(processor)
+        if self._foreign_processors():
+            if self.use_hip_graph:
+                self.enable_hip_graph(False)  # captured graphs hold the fused path
+            self._graphs = {}
+
+    def _foreign_processors(self):
+        return [m for m in self.modules() if isinstance(m, _AttentionP) and m.foreign_processor is not None]
+
+    def _call_processor(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb, cond_image_rotary_emb):
+        """diffusers `Attention.forward`: hand the processor the keyword arguments its `__call__` signature accepts"""
+        import inspect
+
+        proc = attn.foreign_processor
+        kw = dict(encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, image_rotary_emb=image_rotary_emb,
+                  cond_image_rotary_emb=cond_image_rotary_emb)
+        params = inspect.signature(proc.__call__).parameters
+        if not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values()):
+            kw = {k: v for k, v in kw.items() if k in params}
+        out = proc(attn, hidden_states, **kw)
+        if not (isinstance(out, tuple) and len(out) == 2):
+            raise TypeError("an attention processor must return (hidden_states, encoder_hidden_states) (models/LaDCast_3D_model.py:78-86,221)")
+        return out
 
     # -- plan: fused weights ---------------------------------------------------------------
     def _apply(self, fn, *a, **k):  # any .to()/.cuda() invalidates the fused copies + caches
@@ -377,7 +439,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             if isinstance(mod, _AttentionP):
                 e = SimpleNamespace()
                 e.wqkv, e.bqkv = self._fuse_qkv(mod.to_q, mod.to_k, mod.to_v)
-                if hasattr(mod, "add_q_proj"):
+                if mod.add_q_proj is not None:
                     e.wqkv_c, e.bqkv_c = self._fuse_qkv(mod.add_q_proj, mod.add_k_proj, mod.add_v_proj)
                 plan.attn[id(mod)] = e
         d = self.inner_dim
@@ -712,6 +774,18 @@ class LaDCastTransformer3DModel(ModelMixin):
             if Hh * Ww != self.attn_lat_weights.numel():
                 raise ValueError("scale_attn_by_lat is hard-wired to the 15 x 30 latent grid (models/LaDCast_3D_model.py:684-692)")
             kb_all, kb_cond = self._key_bias(R + T_in, dev), self._key_bias(T_in, dev)
+        # user-supplied attention processors (set_attn_processor): called on torch views of the fp32 buffers, eager launches only
+        foreign = bool(self._foreign_processors())
+        m_all = m_cond = None
+        if foreign:
+            if split:
+                raise NotImplementedError("a user-supplied attention processor runs on the fp32 path: call set_gemm_precision('fp32') "
+                                          "(or change the attention arithmetic through the C ABI, include/ladcast_hip.h)")
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("a user-supplied attention processor cannot be captured into a hipGraph")
+            if self.scale_attn_by_lat:  # the reference's (1, 1, 1, keys) float mask (:873-880)
+                w = self.attn_lat_weights.to(dev)
+                m_all, m_cond = w.repeat(1, 1, 1, T_in + R), w.repeat(1, 1, 1, T_in)
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
@@ -727,9 +801,13 @@ class LaDCastTransformer3DModel(ModelMixin):
         for blk in ref.token_refiner.refiner_blocks:
             pa = plan.attn[id(blk.attn)]
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=fmt)
-            run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
-                    [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
-            self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
+            if blk.attn.foreign_processor is not None:  # :280-286
+                a, _ = self._call_processor(blk.attn, nh_c, None, m_cond, (cc, cs), None)
+                ws.att[:, Nx:].copy_(a)
+            else:
+                run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
+                        [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
+                self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
             hip.gate_residual_layernorm(h_c, ws.att[:, Nx:], ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
@@ -757,17 +835,23 @@ class LaDCastTransformer3DModel(ModelMixin):
             # norm1 + norm1_context: the two streams are adjacent rows of ws.h -> one launch, two modulation sets
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, D:], shift=mx, split_row=Nx, scale2=mc[:, D:], shift2=mc,
                               mod_bs=NM, mode=0, eps=1e-6, out_split=fmt)
-            run_qkv([
-                G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
-                G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
-            ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
-            self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=fmt, key_bias=kb_all)
-            o, oc = blk.attn.to_out[0], blk.attn.to_add_out
-            run([
-                G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
-                G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD, flags=AS),
-            ])
+            if blk.attn.foreign_processor is not None:  # :531-545: the processor also applies to_out / to_add_out; gated residual here
+                a, ca = self._call_processor(blk.attn, nh_x, nh_c, m_all, (pc, ps), (cc, cs))
+                a, ca = a.contiguous(), ca.contiguous()
+                hip.gate_residual(h_x, a, mx[:, 2 * D :], h_x, B=B, rows=Nx, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=Nx * D, gate_bs=NM)
+                hip.gate_residual(h_c, ca, mc[:, 2 * D :], h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=Nc * D, gate_bs=NM)
+            else:
+                run_qkv([
+                    G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
+                    G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
+                ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
+                self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
+                                (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=fmt, key_bias=kb_all)
+                o, oc = blk.attn.to_out[0], blk.attn.to_add_out
+                run([
+                    G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
+                    G(ws.att[:, Nx:], oc.weight, h_c, M=Nc, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=oc.bias, gate=mc[:, 2 * D :], gate_bs=NM, R=h_c, ldr=D, r_bs=SD, flags=AS),
+                ])
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mx[:, 4 * D :], shift=mx[:, 3 * D :], split_row=Nx,
                               scale2=mc[:, 4 * D :], shift2=mc[:, 3 * D :], mod_bs=NM, mode=0, eps=1e-7, out_split=fmt)
             up, down = [], []
@@ -790,13 +874,20 @@ class LaDCastTransformer3DModel(ModelMixin):
             # columns [D, 5 D) of the [attn | mlp] concat rows; in the plain-bf16 row format that is byte offset 2 D, not 4 D
             cat_mlp = ws.cat.view(torch.bfloat16)[:, :, D:] if plan.one_term else ws.cat[:, :, D:]
             hip.layernorm_mod(ws.h, ws.nh, B=B, rows=S, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=mod[:, D:], shift=mod, mod_bs=NM, mode=0, eps=1e-6, out_split=fmt)
-            run_qkv([
-                G(ws.nh, blk.proj_mlp.weight, cat_mlp, M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
-                  flags=AS | CS),
-                G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
-            ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
-            self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                            (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=fmt, key_bias=kb_all)
+            if blk.attn.foreign_processor is not None:  # :443-457: pre_only attention, its output is the first D columns of the concat rows
+                run([G(ws.nh, blk.proj_mlp.weight, cat_mlp, M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias,
+                       act=hip.ACT_GELU_TANH, flags=AS | CS)])
+                a, ca = self._call_processor(blk.attn, ws.nh[:, :Nx], ws.nh[:, Nx:], m_all, (pc, ps), (cc, cs))
+                ws.cat[:, :Nx, :D].copy_(a)
+                ws.cat[:, Nx:, :D].copy_(ca)
+            else:
+                run_qkv([
+                    G(ws.nh, blk.proj_mlp.weight, cat_mlp, M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
+                      flags=AS | CS),
+                    G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
+                ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
+                self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
+                                (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=fmt, key_bias=kb_all)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD, flags=AS)
 

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .autocast import fp32_island
 from .layers import (
     AdaLayerNormContinuous,
     AdaLayerNormZero,
@@ -406,7 +407,8 @@ class LaDCastTransformer3DModel(nn.Module):
     ):
         b, _, r, h, w = hidden_states.shape
         t_in = conditioning_tensors.shape[2]
-        image_rope, cond_rope = self.rope_tables(r, t_in, h, w, device=hidden_states.device)
+        with fp32_island():  # models/embeddings.py:282 (the rotary tables are built inside an fp32 island)
+            image_rope, cond_rope = self.rope_tables(r, t_in, h, w, device=hidden_states.device)
 
         x = self.x_embedder(hidden_states)
         ctx = self.context_embedder(conditioning_tensors)
@@ -416,12 +418,14 @@ class LaDCastTransformer3DModel(nn.Module):
             cond_mask = self.attn_lat_weights.repeat(1, 1, 1, t_in).to(hidden_states.device)
         ctx = self.context_refiner(ctx, timestep, image_rotary_emb=cond_rope, attention_mask=cond_mask)
 
-        temb = self.time_text_embed(timestep, ctx.mean(dim=1))
-        if time_elapsed is not None and self.time_elapsed_embed is not None:
-            te = get_year_sincos_embedding(time_elapsed, embedding_dim=256)
-            te = self.time_elapsed_embed(te.to(hidden_states.device))
-            scale, shift = te.chunk(2, dim=-1)
-            temb = temb * (1 + scale) + shift
+        # :953-969 - the one fp32 island of the transformer under mixed precision (oracle/autocast.py); a no-op in the fp32 oracle
+        with fp32_island():
+            temb = self.time_text_embed(timestep, ctx.mean(dim=1).float())
+            if time_elapsed is not None and self.time_elapsed_embed is not None:
+                te = get_year_sincos_embedding(time_elapsed, embedding_dim=256)
+                te = self.time_elapsed_embed(te.to(hidden_states.device))
+                scale, shift = te.chunk(2, dim=-1)
+                temb = temb * (1 + scale) + shift
 
         for blk in self.transformer_blocks:
             x, ctx = blk(x, ctx, temb, pred_mask, image_rope, cond_rope)

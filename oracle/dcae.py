@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .autocast import fp32_island
 from .layers import RMSNorm
 from .sphere_conv import SphereConv2d
 
@@ -71,13 +72,16 @@ class SanaMultiscaleLinearAttention(nn.Module):
         hs = torch.cat(multi, dim=1)
         if h * w <= self.attention_head_dim:
             raise NotImplementedError("quadratic branch is never taken at 15x30 / 30x60")
+        original_dtype = hs.dtype  # bf16 under the reference's mixed precision (oracle/autocast.py); fp32 otherwise
         hs = hs.to(torch.float32).reshape(b, -1, 3 * self.attention_head_dim, h * w)
         q, k, v = hs.chunk(3, dim=2)
         q, k = F.relu(q), F.relu(k)
         v = F.pad(v, (0, 0, 0, 1), mode="constant", value=1)
-        scores = torch.matmul(v, k.transpose(-1, -2))
-        out = torch.matmul(scores, q)
-        out = out[:, :, :-1] / (out[:, :, -1:] + self.eps)
+        with fp32_island():  # models/DCAE.py:162-175
+            scores = torch.matmul(v.to(torch.float32), k.transpose(-1, -2).to(torch.float32))
+            out = torch.matmul(scores.to(torch.float32), q.to(torch.float32))
+            out = out[:, :, :-1] / (out[:, :, -1:] + self.eps)
+        out = out.to(original_dtype)  # models/DCAE.py:249
         out = out.reshape(b, -1, h, w)
         out = self.to_out(out.movedim(1, -1)).movedim(-1, 1)
         out = _chan_rmsnorm(self.norm_out, out)

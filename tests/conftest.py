@@ -15,3 +15,85 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- session-wide oracle runs shared by the full-size GPU tests (the CPU oracle is most of the GPU suite's wall time) ----
+@pytest.fixture(scope="session")
+def full_dcae_oracle():
+    """BASELINE configs[0] on the oracle, once per session: the full-size DCAE, one synthetic 84 x 120 x 240 frame + static
+    fields, its latent and the decoded frame.  Returns a namespace (model, f, st, z, y)."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from oracle.dcae import CONFIG_DCAE_84
+    from tests.synth import make_dcae, synth_field
+
+    o = make_dcae(dict(CONFIG_DCAE_84))
+    f, st = synth_field(1, 84, 120, 240), synth_field(1, 5, 120, 240, seed=1)
+    with torch.no_grad():
+        z = o.encode(f, static_conditioning_tensor=st).latent
+        y = o.decode(z).sample
+    return SimpleNamespace(model=o, cfg=dict(CONFIG_DCAE_84), f=f, st=st, z=z, y=y)
+
+
+@pytest.fixture(scope="session")
+def oracle_375m():
+    """the oracle's 375M transformer with the seeded synthetic weights (1.5 GB), built once per session"""
+    from oracle.ar_model import CONFIG_375M
+    from tests.synth import make_ar
+
+    return make_ar(dict(CONFIG_375M))
+
+
+class RecordingNet:
+    """records the input state and the output of every network evaluation of a sampler run (eager launches only: it hides
+    the model's hipGraph surface on purpose)"""
+
+    _HIDE = ("use_hip_graph", "forward_launch_only", "_graphs", "capture_stream")
+
+    def __init__(self, net):
+        self._net, self.ins, self.outs = net, [], []
+
+    def __getattr__(self, k):
+        if k in RecordingNet._HIDE:
+            raise AttributeError(k)
+        return getattr(self._net, k)
+
+    def __call__(self, x, *a, **kw):
+        o = self._net(x, *a, **kw)
+        y = o[0] if isinstance(o, tuple) else o.sample
+        self.ins.append(x.detach().float().cpu().clone())
+        self.outs.append(y.detach().float().cpu().clone())
+        return o
+
+
+@pytest.fixture(scope="session")
+def fullsize_chunk_oracle(full_dcae_oracle, oracle_375m):
+    """BASELINE configs[1] (and the single-GPU share of configs[4]) on the oracle, once per session: the synthetic frame's latent,
+    normalised with its own per-channel statistics (target std 0.5), is the known latent of ONE 20-step Heun chunk of the 375M
+    model (39 recorded forwards, 1 member, R = 4); the 4 predicted latent frames are de-normalised and decoded by the oracle DCAE.
+    Namespace: ar (oracle model), targs, known (1, 84, 1, 15, 30), ts, want (1, 84, 4, 15, 30) normalised samples, ins / outs per
+    evaluation, decoded (1, 84, 4, 120, 240), seconds."""
+    import time
+    from types import SimpleNamespace
+
+    import torch
+
+    from oracle import pipelines as OP
+    from oracle.ar_model import CONFIG_375M
+    from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler
+    d = full_dcae_oracle
+    z = d.z[0]  # (84, 15, 30)
+    mu, sd = z.mean(dim=(1, 2)), z.std(dim=(1, 2))
+    targs = {"mean": mu.tolist(), "std": sd.tolist(), "target_std": 0.5}
+    known = OP.get_transform_3D("normalize", targs)(z[:, None].clone())[None]  # (1, 84, 1, 15, 30)
+    ts = torch.tensor([2018010100])
+    ar = oracle_375m
+    rec = RecordingNet(ar)
+    t0 = time.perf_counter()
+    want = OP.ensemble_AR_sampler(OP.AutoRegressive2DPipeline(rec, OracleScheduler()), 1, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm")
+    lat = OP.get_inv_transform_3D("normalize", targs)(want.permute(1, 0, 2, 3, 4).reshape(84, 4, 15, 30)).reshape(84, 1, 4, 15, 30).permute(1, 0, 2, 3, 4)
+    decoded = OP.decode_latent_ens(d.model, lat)
+    return SimpleNamespace(ar=ar, cfg=dict(CONFIG_375M), targs=targs, known=known, ts=ts, want=want, ins=rec.ins, outs=rec.outs, latents=lat,
+                           decoded=decoded, seconds=time.perf_counter() - t0)

@@ -56,3 +56,33 @@ def synth_field(batch, channels, h, w, seed=0):
 def rel_l2(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm()).item()
+
+
+class DuckDDIMScheduler:
+    """A DDIM-shaped scheduler with NOTHING but the four members the reference's pipeline loop touches (pipelines/pipeline_AR.py:
+    85-102): `set_timesteps(n)`, `.timesteps`, `scale_model_input(sample, t)`, `step(model_output, t, sample, return_dict=False)`.
+    Deterministic DDIM (eta = 0, epsilon prediction, linear betas, integer timesteps); no `.config`, no `.sigmas`, no
+    `init_noise_sigma`, no device argument - anything else the loop reached for would raise AttributeError.  Plain torch,
+    device-agnostic: the same object drives the HIP model and the CPU oracle."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=2e-2):
+        self.T = num_train_timesteps
+        self.alphas_cumprod = torch.cumprod(1.0 - torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float64), dim=0)
+        self.calls = []
+
+    def set_timesteps(self, num_inference_steps):
+        self.stride = self.T // num_inference_steps
+        self.timesteps = torch.arange(num_inference_steps - 1, -1, -1, dtype=torch.int64) * self.stride
+
+    def scale_model_input(self, sample, t):
+        self.calls.append(("scale", int(t)))
+        return sample
+
+    def step(self, model_output, t, sample, return_dict=True, **kw):
+        t = int(t.reshape(-1)[0])  # the loop hands over t expanded to the batch, on the model's device
+        self.calls.append(("step", t))
+        a_t = self.alphas_cumprod[t].item()
+        a_prev = self.alphas_cumprod[t - self.stride].item() if t - self.stride >= 0 else 1.0
+        x0 = (sample - (1.0 - a_t) ** 0.5 * model_output) / a_t**0.5
+        prev = a_prev**0.5 * x0 + (1.0 - a_prev) ** 0.5 * model_output
+        return (prev,) if not return_dict else {"prev_sample": prev}

@@ -162,3 +162,76 @@ def test_driver_input_preparation_follows_the_reference():
     assert args == {"mean": [0.0], "std": [1.0], "target_std": 0.5}
     with pytest.raises(ValueError):
         run_rollout(None, [], None, None, args, total_lead_time_hour=7, step_size_hour=6)
+
+
+def test_pipeline_loop_takes_a_duck_typed_ddim_scheduler():
+    """north star: "the DDIM/DDPM scheduler loop ... diffusers-style scheduler surface" (pipelines/pipeline_AR.py:19-21,85-102): the
+    loop is duck-typed.  A DDIM-shaped scheduler exposing only set_timesteps / timesteps / scale_model_input / step drives the
+    PRODUCT's pipeline class (host loop; elementwise toy network on the CPU) and the oracle's: identical call sequence, identical
+    bits.  (tests/test_gpu_model.py runs the same scheduler through the HIP model.)"""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline
+    from oracle.pipelines import AutoRegressive2DPipeline as OraclePipeline
+    from tests.golden.make_golden import ToyNet
+    from tests.synth import DuckDDIMScheduler, synth_known
+
+    known, ts = synth_known(2), torch.tensor([2018010106])
+    outs, calls = [], []
+    for cls in (AutoRegressive2DPipeline, OraclePipeline):
+        sch = DuckDDIMScheduler()
+        pipe = cls(ToyNet(84), sch)
+        gen = [torch.Generator().manual_seed(k) for k in range(2)]
+        outs.append(pipe(batch_size=2, return_seq_len=4, known_latents=known, timestamps=ts, generator=gen, num_inference_steps=7, return_dict=False)[0])
+        calls.append(sch.calls)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+    assert calls[0] == calls[1] and len(calls[0]) == 14 and calls[0][0] == ("scale", 852) and calls[0][-1] == ("step", 0)
+    # the dict form of the output object
+    pipe = AutoRegressive2DPipeline(ToyNet(84), DuckDDIMScheduler())
+    out = pipe(batch_size=1, return_seq_len=2, known_latents=synth_known(1), timestamps=ts, generator=torch.Generator().manual_seed(0), num_inference_steps=3)
+    assert out.fields.shape == (1, 84, 2, 15, 30)
+
+
+def test_attention_processor_surface_is_honest():
+    """models/LaDCast_3D_model.py:763-827: the default processors are `LaDCastAttnProcessor2_0` markers of the fused path; a foreign
+    processor is registered (and will be CALLED by the forward - tests/test_gpu_model.py), it switches hipGraph capture off / refuses
+    it; the attention containers follow diffusers' attribute conventions (absent projections are None); the DCAE refuses a foreign
+    linear-attention processor instead of ignoring it."""
+    from ladcast_amd.models import AutoencoderDC, LaDCastAttnProcessor2_0, LaDCastTransformer3DModel, SanaMultiscaleAttnProcessor2_0
+    from tests.synth import tiny_ar_config, tiny_dcae_config
+
+    m = LaDCastTransformer3DModel.from_config(tiny_ar_config(heads=2, layers=1, single=1, refiner=1))
+    procs = m.attn_processors
+    assert sorted(procs) == ["context_refiner.token_refiner.refiner_blocks.0.attn.processor", "single_transformer_blocks.0.attn.processor",
+                             "transformer_blocks.0.attn.processor"]
+    assert all(isinstance(p, LaDCastAttnProcessor2_0) for p in procs.values()) and not m._foreign_processors()
+    single, dual = m.single_transformer_blocks[0].attn, m.transformer_blocks[0].attn
+    assert single.add_q_proj is None and single.to_out is None and single.to_add_out is None and single.norm_added_q is None
+    assert dual.add_q_proj is not None and dual.to_out is not None and dual.to_add_out is not None
+    x = torch.randn(2, 3, 5, 128)
+    want = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-7)
+    assert torch.allclose(dual.norm_q(x), want)  # callable for foreign processors
+
+    class Foreign:
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None):
+            return hidden_states, encoder_hidden_states
+
+    with pytest.raises(ValueError):
+        m.set_attn_processor({"x": Foreign()})
+    m.enable_hip_graph(True)
+    m.set_attn_processor(Foreign())
+    assert len(m._foreign_processors()) == 3 and not m.use_hip_graph
+    with pytest.raises(NotImplementedError):
+        m.enable_hip_graph(True)
+    m.set_attn_processor({k: (Foreign() if "single" in k else LaDCastAttnProcessor2_0()) for k in procs})
+    assert len(m._foreign_processors()) == 1
+    m.set_attn_processor(LaDCastAttnProcessor2_0())
+    assert not m._foreign_processors()
+    m.enable_hip_graph(True)
+    with pytest.raises(RuntimeError):
+        LaDCastAttnProcessor2_0()(None, None)  # the fused processor is a marker, never called
+
+    ae = AutoencoderDC.from_config(tiny_dcae_config())
+    attn = next(mod for mod in ae.modules() if hasattr(mod, "to_qkv_multiscale"))
+    assert isinstance(attn.processor, SanaMultiscaleAttnProcessor2_0)
+    with pytest.raises(NotImplementedError):
+        attn.processor = Foreign()
+    attn.processor = SanaMultiscaleAttnProcessor2_0()
