@@ -9,9 +9,12 @@ autoregressive sampler chunk (BASELINE.json configs[1]: 375M AR transformer, 1 e
 GPU, 20 solver steps, 1 lead step) -- IC latent resident in HBM in, lead-step latents out.  With
 the shipped return_seq_len = 4 the reference computes one 4-frame chunk for a 1-lead-step request and
 keeps ``pred_selection = 1`` frame (pipelines/utils.py:535-536); the metric counts that 1 lead step.
-Weak scaling: every rank owns ``--members-per-gpu`` members (global ids {k : k mod N == rank}, seeded by
+Weak scaling (default): every rank owns ``--members-per-gpu`` members (global ids {k : k mod N == rank}, seeded by
 member id as pipelines/utils.py:703-706), no data-path collective except one RCCL gather of the
-result latents at the end of each step.
+result latents at the end of each step.  Strong scaling: ``--ensemble-size E`` fixes the ensemble at E members
+whatever N is and deals them to the ranks (same rule; ranks may own different counts, or none) - BASELINE
+configs[2] is ``--ensemble-size 16 --lead-steps 40``, the workload of north_star's ">= 6x at 8 GPUs vs 1";
+``--ensemble-size 1`` at N = 1 is the default line.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).
 """
@@ -125,7 +128,7 @@ class KernelTimer:
 
     def install(self, hip):
         self._hip = hip
-        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped, "attn_fwd_packed": hip.attn_fwd_packed,
+        self._orig = {"gemm": hip.gemm, "attn_fwd": hip.attn_fwd, "gemm_grouped": hip.gemm_grouped,
                       "gemm_grouped_qkv": hip.gemm_grouped_qkv, "attn_fwd_split": hip.attn_fwd_split}
         timer = self
 
@@ -159,13 +162,6 @@ class KernelTimer:
             e.record()
             timer.records.setdefault("attn_fwd_f32_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
-        def attn_fwd_packed(packed, O, **kw):  # the attention itself; the pack pass (norm + RoPE + split) is not MFMA work
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            timer._orig["attn_fwd_packed"](packed, O, **kw)
-            e.record()
-            timer.records.setdefault("attn_fwd_packed_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
-
         def gemm_grouped_qkv(problems, epilogues):  # QKV projections with the attention-operand epilogue: the same kernel, same FLOPs
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -181,12 +177,11 @@ class KernelTimer:
             e.record()
             timer.records.setdefault("attn_fwd_split_kernel", []).append((s, e, 4.0 * kw["B"] * kw["H"] * kw["S"] * kw["S"] * 128))
 
-        hip.gemm, hip.attn_fwd, hip.gemm_grouped, hip.attn_fwd_packed = gemm, attn_fwd, gemm_grouped, attn_fwd_packed
+        hip.gemm, hip.attn_fwd, hip.gemm_grouped = gemm, attn_fwd, gemm_grouped
         hip.gemm_grouped_qkv, hip.attn_fwd_split = gemm_grouped_qkv, attn_fwd_split
 
     def uninstall(self):
         self._hip.gemm, self._hip.attn_fwd, self._hip.gemm_grouped = self._orig["gemm"], self._orig["attn_fwd"], self._orig["gemm_grouped"]
-        self._hip.attn_fwd_packed = self._orig["attn_fwd_packed"]
         self._hip.gemm_grouped_qkv, self._hip.attn_fwd_split = self._orig["gemm_grouped_qkv"], self._orig["attn_fwd_split"]
 
     def clear(self):
@@ -249,6 +244,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="375M", choices=list(CONFIGS))
     ap.add_argument("--members-per-gpu", type=int, default=1)
+    ap.add_argument("--ensemble-size", type=int, default=0, help="STRONG scaling: a fixed ensemble of E members dealt to the N ranks (member k on rank "
+                    "k mod N; evaluate/pred_rollout.py:349-358,398-400 is the split / gather it replaces); 0 = weak scaling with --members-per-gpu")
     ap.add_argument("--return-seq-len", type=int, default=4)
     ap.add_argument("--lead-steps", type=int, default=1, help="lead steps requested per rollout call (1 chunk covers up to return_seq_len)")
     ap.add_argument("--solver-steps", type=int, default=20)
@@ -304,10 +301,13 @@ def main():
     model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval().set_gemm_precision(args.precision)
     model.enable_hip_graph(not args.no_graph)
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
-    m = args.members_per_gpu
     from ladcast_amd.pipelines.distributed import shard_members
+    from ladcast_amd.precision import tolerance
 
-    member_ids = shard_members(m * world, rank, world)  # rank r owns members {k : k mod world == r}
+    strong = args.ensemble_size > 0
+    total_members = args.ensemble_size if strong else args.members_per_gpu * world
+    member_ids = shard_members(total_members, rank, world)  # rank r owns members {k : k mod world == r}
+    m = len(member_ids)  # this rank's members: --members-per-gpu (weak) or its share of the fixed ensemble (strong; may be 0)
     R, lead = args.return_seq_len, args.lead_steps
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).to(dev)  # IC latent, resident in HBM
     targs = {"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5}
@@ -346,7 +346,7 @@ def main():
             known_latents_override=ic, member_ids=member_ids,
         )
         if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
-            out = gather_members(out.to(dev) if args.backend == "nccl" else out, m * world, member_dim=1)
+            out = gather_members(out.to(dev) if args.backend == "nccl" else out, total_members, member_dim=1)
         return out
 
     def fence():
@@ -386,7 +386,7 @@ def main():
             t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        sustained = dict(steps=n_sus, seconds=round(dt, 3), ms_per_step=round(1e3 * dt / n_sus, 3), value=round(m * world * lead * n_sus / dt, 4))
+        sustained = dict(steps=n_sus, seconds=round(dt, 3), ms_per_step=round(1e3 * dt / n_sus, 3), value=round(total_members * lead * n_sus / dt, 4))
     other_sampler = None
     if not args.no_kernel_timers and rank == 0 and world == 1:
         # Secondary number (not `value`): the same workload with the reference's other sampler -- BASELINE's metric says
@@ -460,7 +460,6 @@ def main():
         chunks = -(-lead // R)
         fwd_per_chunk = (2 * args.solver_steps - 1) if args.sampler == "edm" else args.solver_steps
         gflops, aflops = model_flops_per_forward(cfg, R)
-        total_members = m * world
         value = total_members * lead * args.steps / elapsed
         roof = None
         split = args.precision == "bf16x3"
@@ -471,19 +470,24 @@ def main():
             k = ks[dom]
             kname = dom
             peak = PEAK_BF16_MFMA_TFLOPS if bf16_cores else PEAK_F32_MFMA_TFLOPS
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_stale = None, None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
-                    ent = json.load(open(pmc)).get(kname, {})
+                    from ladcast_amd.build_id import csrc_sha16
+
+                    doc = json.load(open(pmc))
+                    ent = doc.get(kname, {})
                     traffic = ent.get("hbm_bytes_per_launch")
                     if traffic is not None:
-                        traffic_source = ("profiles/pmc_summary.json (committed rocprofv3 --pmc passes of this command, build "
-                                          f"{ent.get('build', 'see profiles/README.md')}); not re-measured in this run")
+                        built = (doc.get("_build") or {}).get("csrc_sha16")
+                        traffic_stale = built != csrc_sha16()  # the kernels changed since the counter passes (or the file predates build ids)
+                        traffic_source = ("profiles/pmc_summary.json: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command on kernel "
+                                          f"sources {built}; this run's sources are {csrc_sha16()}; not re-measured in this run")
                 except Exception:
                     traffic = None
             roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s",
-                        frac=round(k["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_source, launches=k["launches"],
+                        frac=round(k["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale, launches=k["launches"],
                         avg_launch_us=round(k["avg_us"], 2),
                         flops_per_launch=k["work_per_launch"],
                         note="one launch = one grouped stream-K GEMM call; achieved = ALGORITHMIC 2*M*N*K summed over the call's problems / "
@@ -496,16 +500,19 @@ def main():
                                         "2*FETCH+WRITE KiB); served mostly by the 256 MiB Infinity Cache: panels are re-read per XCD")
         line = {
             "metric": "ensemble-member-steps/sec", "value": round(value, 4), "unit": "member-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": {"bf16x3": "bf16x3(split-fp32 operands, f32 accumulate; softmax/norms f32, sampler state f64)", "fp32": "f32",
-                      "bf16": "bf16(single-term bf16 operands, f32 accumulate and outputs; temb/norms/softmax f32, sampler state f64; tolerance 5e-3 per forward)"}[args.precision],
+                      "bf16": "bf16(single-term bf16 operands, f32 accumulate and outputs; temb/norms/softmax f32, sampler state f64; stated tolerance "
+                              f"{tolerance('bf16', 'forward'):g} per forward, ladcast_amd/precision.py)"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": ("cfg5-style END-TO-END (DCAE encode -> AR -> DCAE decode of every lead step), " if args.decode else "") +
-                            f"cfg2: {args.model} AR transformer, {m} member/GPU, {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
+                            f"cfg2: {args.model} AR transformer, " + (f"a FIXED ensemble of {total_members} member(s) over {world} GPU(s)" if strong else f"{m} member/GPU") +
+                            f", {args.solver_steps} solver steps ({args.sampler}: {fwd_per_chunk} forwards/chunk), "
                             f"{lead} lead step(s) = {chunks} chunk(s) of return_seq_len {R}, latent 84x15x30, fp32 weights random-init seed 1234, arithmetic {args.precision}",
-                "sampler": args.sampler, "members_per_gpu": m, "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
+                "sampler": args.sampler, "members_per_gpu": m if not strong else None, "ensemble_size": total_members,
+                "members_on_rank": [len(shard_members(total_members, r, world)) for r in range(world)], "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
                 "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
@@ -518,7 +525,7 @@ def main():
             "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
             "roofline": roof,
         }
-        for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS),                           ("attn_fwd_packed_kernel", PEAK_BF16_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):
+        for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):
             if an in ks:
                 k = ks[an]
                 line["attention_kernel"] = dict(kernel=an, achieved=round(k["tflops"], 2), peak=apeak, unit="TFLOP/s", frac=round(k["tflops"] / apeak, 4),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 1
+#define LDC_ABI_VERSION 2
 
 #define LDC_OK 0
 #define LDC_ERR_ARG (-1)       /* null pointer / non-positive size */
@@ -93,7 +93,8 @@ int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const f
 
 /* Same contraction for up to LDC_GEMM_MAX_PROBLEMS independent problems in ONE persistent launch
  * with stream-K scheduling (work = (tile, 32-deep k-step) units cut into equal contiguous ranges,
- * 2 workgroups per CU) plus a fix-up launch for the tiles whose K range was split.  Built for the
+ * 2 workgroups per CU); tiles whose K range was split are summed INSIDE the launch by the piece that
+ * arrives last, in workgroup order (bitwise reproducible; no second launch since ABI 2).  Built for the
  * small grids of the AR transformer (e.g. the pred- and cond-stream projections of a dual block,
  * models/LaDCast_3D_model.py:92-94,175-177,558-563).  `workspace` is caller-owned device scratch of
  * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned), initialised ONCE with
@@ -174,24 +175,11 @@ int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, vo
 int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
                  int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream);
 
-/* Split-bf16 attention in two steps, for callers that also need the q/k RMSNorm + rotary embedding:
- *   ldc_attn_pack_bf16x3     reads Q, K, V (same views as ldc_attn_fwd), applies to q and k the per-head
- *                            RMSNorm(128, eps, weight) and the adjacent-pair rotary embedding of ldc_qk_rmsnorm_rope
- *                            (token rows [0, split_row) use wq0/wk0/cos0/sin0, rows [split_row, S) use
- *                            wq1/wk1/cos1/sin1 with table row = row - split_row; NULL weights = no norm,
- *                            NULL tables = no RoPE), splits every operand into bf16 hi + lo ONCE and writes
- *                            them as ready-made LDS tile images into `packed` (ldc_attn_packed_bytes bytes);
- *   ldc_attn_fwd_packed_bf16x3  the attention itself on those images (tiles brought in by LDS-DMA).
- * Together they replace attn.norm_q/norm_k/norm_added_q/norm_added_k + apply_rotary_emb +
- * F.scaled_dot_product_attention, models/LaDCast_3D_model.py:103-169,183-203.  Q, K, V are not modified. */
-long long ldc_attn_packed_bytes(int B, int S, int H);
-int ldc_attn_pack_bf16x3(const float* Q, const float* K, const float* V, int B, int S, int H, int ld_qkv,
-                         long long qkv_bs, int split_row, const float* wq0, const float* wk0,
-                         const float* cos0, const float* sin0, const float* wq1, const float* wk1,
-                         const float* cos1, const float* sin1, float eps, void* packed, void* stream);
-int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H, int ldo, long long o_bs,
-                               int out_split, void* stream);
-/* `out_split` is a bit set: LDC_ATTN_OUT_SPLIT = O is written in the split activation format of LDC_GEMM_A_SPLIT (ldo, o_bs
+/* (ABI 2: the second-generation split attention - ldc_attn_pack_bf16x3 / ldc_attn_fwd_packed_bf16x3 / ldc_attn_packed_bytes, a
+ * pack pass writing LDS tile images + the attention on them - was removed; ldc_attn_qkv_prepare_split / the fused QKV epilogue +
+ * ldc_attn_fwd_split below serve every caller it had.)
+ *
+ * `flags` of ldc_attn_fwd_split is a bit set: LDC_ATTN_OUT_SPLIT = O is written in the split activation format of LDC_GEMM_A_SPLIT (ldo, o_bs
  * multiples of 8); LDC_ATTN_BF16_1TERM = single-term bf16 products (Qh.Kh, Ph.Vh; fp32 scores, softmax and accumulation):
  * the attention of the "bf16" mixed-precision mode (see LDC_GEMM_BF16_1TERM). */
 #define LDC_ATTN_OUT_SPLIT 1
@@ -205,8 +193,8 @@ int ldc_attn_fwd_packed_bf16x3(const void* packed, float* O, int B, int S, int H
  *           RMSNorm + rotary embedding already applied and q multiplied by log2(e) / sqrt(128);
  *     v   : [hi x128 | lo x128] bf16.
  *   Producers: the QKV projection itself (ldc_gemm_grouped_bf16x3_qkv below: GEMM epilogue) or, from an fp32 buffer in place,
- *   ldc_attn_qkv_prepare_split (same segment / weight / table arguments as ldc_attn_pack_bf16x3).
- *   ldc_attn_fwd_split: O = softmax(q.k^T) v per (batch, head); `flags` as ldc_attn_fwd_packed_bf16x3's `out_split`.
+ *   ldc_attn_qkv_prepare_split (token rows [0, split_row) use wq0 / wk0 / cos0 / sin0, rows [split_row, S) use wq1 / wk1 / cos1 / sin1 with table row = row - split_row; NULL weights = no norm, NULL tables = no RoPE).
+ *   ldc_attn_fwd_split: O = softmax(q.k^T) v per (batch, head); `flags`: the bit set above.
  * Replaces attn.norm_q/norm_k/norm_added_q/norm_added_k + apply_rotary_emb + F.scaled_dot_product_attention,
  * models/LaDCast_3D_model.py:103-169,183-203. */
 /* The QKV projection with those operand rows as its OUTPUT: ldc_gemm_grouped_bf16x3 (pre-split activations, K % 32 == 0) whose

@@ -230,7 +230,9 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         }
+#ifndef LDC_EPI_DIAG_NOACT  // diagnostic builds only (make stamps DIAG=...): what the activation costs
         v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
+#endif
         if (gate && !pad) {
           const float4 gv = *reinterpret_cast<const float4*>(gate + n);
           v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
@@ -253,9 +255,17 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);  // [0]: even rows keep hi, odd rows get lo(even)
           const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);  // [1]: even rows get hi(odd), odd rows keep lo
           unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
+#ifdef LDC_EPI_DIAG_NOSTORE  // diagnostic builds only: the epilogue without its stores (values kept live)
+          asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]), "v"(grp));
+#else
           *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+#endif
         } else {
+#ifdef LDC_EPI_DIAG_NOSTORE
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(crow));
+#else
           *reinterpret_cast<float4*>(crow + n) = v;
+#endif
         }
       } else {
 #pragma unroll
@@ -342,51 +352,60 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
   const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
 
-  long long u = u_begin;
-  while (u < u_end) {
-    const int pi = find_problem_by_unit(a, u);
-    const DevProblem& P = a.pr[pi];
-    const long long local = u - P.unit0;
-    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
-    const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
-    const long long left = u_end - u;
-    const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
+  // One SEGMENT = the k-steps [k0, k1) of one output tile (a whole tile when the unit ranges are tile-aligned).  Its decoded
+  // coordinates are wave-uniform scalars; `cur` is the segment whose main loop runs, and - round 3 - the NEXT segment is decoded and
+  // its first two ring stages are put in flight BEFORE the current segment's epilogue / hand-off, so that the DMA latency (a cold
+  // weight panel: ~2 us) runs under the epilogue's own loads, arithmetic and stores instead of after them.
+  struct Seg {
+    int pi, tile, k0, k1, b, bm, bn;
+  };
+  auto decode = [&](long long u_) {
+    Seg sg;
+    sg.pi = find_problem_by_unit(a, u_);
+    const DevProblem& P = a.pr[sg.pi];
+    const long long local = u_ - P.unit0;
+    sg.tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
+    sg.k0 = static_cast<int>(local - static_cast<long long>(sg.tile) * P.kt);
+    const long long left = u_end - u_;
+    sg.k1 = (P.kt - sg.k0 <= left) ? P.kt : sg.k0 + static_cast<int>(left);
     // tile order (speed only): batch, then super-rows of rm row tiles, then column panels, row tile fastest.  An XCD owns a
     // contiguous run of units, i.e. about rm row panels x (tiles per XCD / rm) column panels: with rm = tm (one super-row)
     // every XCD streams ALL of A and 1/8 of W; a squarer block fetches fewer bytes through the fabric (launch_v3 picks rm)
     const int per_b = P.tm * P.tn;
-    const int b = tile / per_b;
-    const int t_in = tile - b * per_b;
+    sg.b = sg.tile / per_b;
+    const int t_in = sg.tile - sg.b * per_b;
     const int strip = P.rm * P.tn;
     const int sr = t_in / strip;
     const int r_in = t_in - sr * strip;
     const int h_sr = (P.tm - sr * P.rm) < P.rm ? (P.tm - sr * P.rm) : P.rm;
-    const int bn = r_in / h_sr;
-    const int bm = sr * P.rm + (r_in - bn * h_sr);
-    const int M = P.d.M, N = P.d.N, K = P.d.K;
-    // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
-    // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
-    const bool wave_rows = bm * BM + 16 * RT * wave < M;
-    const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
-    const int lda = P.d.lda;
-    const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
+    sg.bn = r_in / h_sr;
+    sg.bm = sr * P.rm + (r_in - sg.bn * h_sr);
+    return sg;
+  };
+  Seg cur = decode(u_begin);
 
-    // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
-    // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
-    const unsigned char* a_src[NAI];
-    const unsigned char* w_src[2];
-    int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
-    // the 16-byte slot this lane fills is the same for all its A instructions: swz(r) only looks at r & 15 = 8 (wave & 1) + lr
-    const int cslot = lp ^ swz(8 * (wave & 1) + lr);
-    auto conv_tap_base = [&](int i, int tap) {  // CONV: this lane's chunk of the source pixel of tap `tap` (channel chunk 0)
-      const int ky = tap / P.ks, kx = tap - ky * P.ks;
-      const int src = pix_b[i] + ldc_sphere_src_pixel(pix_hw[i] >> 16, pix_hw[i] & 0xffff, ky, kx, P.cH, P.cW, P.ks);
-      return reinterpret_cast<const unsigned char*>(A + static_cast<long long>(src) * lda) + (cslot << 4);
-    };
+  // per-lane DMA sources of `cur` (k-step 0); rows past the edge are clamped (their outputs are never stored).
+  // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
+  const unsigned char* a_src[NAI];
+  const unsigned char* w_src[2];
+  int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
+  // the 16-byte slot this lane fills is the same for all its A instructions: swz(r) only looks at r & 15 = 8 (wave & 1) + lr
+  const int cslot = lp ^ swz(8 * (wave & 1) + lr);
+  auto conv_tap_base = [&](int i, int tap) {  // CONV: this lane's chunk of the source pixel of tap `tap` (channel chunk 0)
+    const DevProblem& P = a.pr[cur.pi];
+    const int ky = tap / P.ks, kx = tap - ky * P.ks;
+    const int src = pix_b[i] + ldc_sphere_src_pixel(pix_hw[i] >> 16, pix_hw[i] & 0xffff, ky, kx, P.cH, P.cW, P.ks);
+    return reinterpret_cast<const unsigned char*>(P.A + static_cast<long long>(cur.b) * P.d.a_bs + static_cast<long long>(src) * P.d.lda) + (cslot << 4);
+  };
+  auto set_sources = [&]() {
+    const DevProblem& P = a.pr[cur.pi];
+    const int M = P.d.M, N = P.d.N;
+    const float* __restrict__ A = P.A + static_cast<long long>(cur.b) * P.d.a_bs;
+    const long long w_row_bytes = static_cast<long long>(P.d.K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int r = 8 * (wave + 8 * i) + lr;
-      int gm = bm * BM + r;
+      int gm = cur.bm * BM + r;
       gm = gm < M ? gm : M - 1;
       if constexpr (CONV) {
         const int hw = P.cH * P.cW;
@@ -395,50 +414,71 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
         const int h = rem / P.cW;
         pix_b[i] = bimg * hw;
         pix_hw[i] = (h << 16) | (rem - h * P.cW);
-        a_src[i] = conv_tap_base(i, k0 >> P.kshift);
+        a_src[i] = conv_tap_base(i, cur.k0 >> P.kshift);
       } else {
-        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + ((lp ^ swz(r)) << 4);
+        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * P.d.lda) + ((lp ^ swz(r)) << 4);
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 8 * (wave + 8 * i) + lr;
-      int gn = bn * BN + r;
+      int gn = cur.bn * BN + r;
       gn = gn < N ? gn : N - 1;
       w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
     }
-    // k-steps past the end of the segment are clamped to its last one and land in a per-wave dump slot behind the ring:
-    // the loop body then has no branch around a DMA, every vmcnt is static, and nothing stale can land in the ring (or
-    // on the hand-off flag word in it) after the segment
-    auto issue_one = [&](int kt_, int stage, int i) {
-      const bool live = kt_ < k1;
-      unsigned char* sA = smem + stage * STAGE_B;
-      unsigned char* sW = sA + BM * ROW_B;
-      unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
-      const int kt = live ? kt_ : k1 - 1;
-      const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
+  };
+  // k-steps past the end of the segment are clamped to its last one and land in a per-wave dump slot behind the ring:
+  // the loop body then has no branch around a DMA, every vmcnt is static, and nothing stale can land in the ring after the segment
+  auto issue_one = [&](int kt_, int stage, int i) {
+    const int k1 = cur.k1;
+    const bool live = kt_ < k1;
+    unsigned char* sA = smem + stage * STAGE_B;
+    unsigned char* sW = sA + BM * ROW_B;
+    unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
+    const int kt = live ? kt_ : k1 - 1;
+    const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
 #ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
-      if (kt >= 0) return;
+    if (kt >= 0) return;
 #endif
-      if (i < NAI) {
-        if constexpr (CONV) {
-          // piece i is issued once per k-step in increasing kt (clamped repeats of the last one included), so its base is
-          // recomputed exactly when a tap starts
-          const int chunk = kt & ((1 << P.kshift) - 1);
-          if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
-          const unsigned char* src = a_src[i] + chunk * (BK * 4);
-          if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
-            // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
-            if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
-          }
-          dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
-        } else {
-          dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
+    if (i < NAI) {
+      if constexpr (CONV) {
+        const DevProblem& P = a.pr[cur.pi];
+        // piece i is issued once per k-step in increasing kt (clamped repeats of the last one included), so its base is
+        // recomputed exactly when a tap starts
+        const int chunk = kt & ((1 << P.kshift) - 1);
+        if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
+        const unsigned char* src = a_src[i] + chunk * (BK * 4);
+        if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
+          // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
+          if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
         }
+        dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
       } else {
-        dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
+        dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
       }
-    };
+    } else {
+      dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
+    }
+  };
+  // the first two ring stages of `cur` (k-steps k0 and k0 + 1)
+  auto issue_prologue = [&]() {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) issue_one(cur.k0, 0, i);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) issue_one(cur.k0 + 1, 1, i);
+  };
+  set_sources();
+  issue_prologue();
+
+  long long u = u_begin;
+  bool first_seg = true;
+  while (true) {
+    const DevProblem& P = a.pr[cur.pi];
+    const int tile = cur.tile, k0 = cur.k0, k1 = cur.k1, b = cur.b, bm = cur.bm, bn = cur.bn;
+    const int M = P.d.M;
+    // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
+    // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
+    const bool wave_rows = bm * BM + 16 * RT * wave < M;
 
     f32x4 acc[NACC];
 #pragma unroll
@@ -567,15 +607,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     sb = sb1;                                                                                                \
   }
 
-    // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
-#pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
-#pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
-    if constexpr (ND == 6) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // prologue: k-steps k0 and k0+1 are in flight (issued at kernel entry / before the previous segment's epilogue); fragments of
+    // k0 (A, W column tiles 0-3) loading.  First segment: only the 2 ND prologue DMAs are outstanding -> stage 0 has landed at
+    // vmcnt(ND).  Later segments: the previous epilogue's loads and stores were issued AFTER the DMAs, so everything is drained
+    // (the first in-loop wait would force the same: the vector-memory counter retires in issue order).
+    if (first_seg) {
+      if constexpr (ND == 6) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     LDC_STAMP(1 + 4 * seg_)
@@ -613,8 +656,20 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     if (seg_ == 0) { LDC_STAMP_CLK(14) }
     LDC_STAMP(2 + 4 * seg_)
 
-    if (k0 == 0 && k1 == P.kt) {
-      tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
+    // ---- the ring is free (barrier above): put the next segment's first two stages in flight under this segment's epilogue ----
+    const long long u_next = u + (k1 - k0);
+    const bool has_next = u_next < u_end;
+    const int g_kt = P.kt;
+    const long long p_unit0 = P.unit0, p_tile0 = P.tile0;
+    const int old_pi = cur.pi;
+    if (has_next) {
+      cur = decode(u_next);
+      set_sources();
+      issue_prologue();
+    }
+    const DevProblem& PO = a.pr[old_pi];
+    if (k0 == 0 && k1 == g_kt) {
+      tile_epilogue<BM, !CONV>(PO, b, bm, bn, acc, wave, lane);
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
@@ -626,15 +681,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
           __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64 + lane, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;
-      const long long l = f + P.kt;
+      const long long f = p_unit0 + static_cast<long long>(tile) * g_kt;
+      const long long l = f + g_kt;
       long long g_first = g;
       while (g_first > 0 && range_start(g_first, a.U, a.G) > f) --g_first;
       long long g_last = g;
       while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
       const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
-      unsigned* cnt = a.counters + (P.tile0 + tile);
-      unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
+      unsigned* cnt = a.counters + (p_tile0 + tile);
+      // the hand-off flag: an LDS word of its own behind the ring and the dump slots (the ring is receiving the next segment)
+      unsigned* flag = reinterpret_cast<unsigned*>(smem + NSTAGE * STAGE_B + 8 * 1024);
       if (tid == 0) {
         const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
@@ -648,7 +704,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       __syncthreads();
       LDC_STAMP(3 + 4 * seg_)
       const unsigned is_last = *flag;
-      __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
+      __syncthreads();  // everyone has read the flag before a later hand-off of this workgroup rewrites it
       if (is_last) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -661,14 +717,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane];
           }
         }
-        tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
+        tile_epilogue<BM, !CONV>(PO, b, bm, bn, acc, wave, lane);
       }
     }
-    u += k1 - k0;
     LDC_STAMP(4 + 4 * seg_)
 #ifdef LDC_GEMM_STAMPS
     if (seg_ < 2) ++seg_;
 #endif
+    if (!has_next) break;
+    u = u_next;
+    first_seg = false;
   }
   LDC_STAMP(15)
 }
@@ -836,7 +894,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
-  const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
+  const size_t lds = NSTAGE * STAGE_B + 8 * 1024 + 16;  // ring + one 1 KiB dump slot per wave + the hand-off flag word
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM, TERMS, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -10,10 +10,12 @@
 // two waves per SIMD cover each other's staging stalls.
 //
 // A workgroup whose range covers a tile's full K applies the epilogue directly.  Otherwise it
-// stores its raw accumulators to a caller-provided workspace slot (<= 2 slots per workgroup) and
-// a second tiny kernel -- after a plain kernel boundary, so no in-launch inter-workgroup
-// hand-off is needed -- sums the slots of each split tile in fixed order and runs the same
-// epilogue.  Both kernels derive the schedule from (U, G) alone; results are deterministic.
+// publishes its raw accumulators as a write-through (sc1) slab in the caller-provided workspace
+// (<= 2 slabs per workgroup), drains, and draws ONE relaxed agent-scope ticket on the tile's
+// counter; the piece whose ticket is the last re-reads every slab of the tile in workgroup order
+// behind an agent-scope acquire and applies the epilogue (round 3: the protocol of
+// gemm_bf16x3_v3.hip / cdna_hip_programming.md G16 - nobody waits, the sum order is fixed, so the
+// result is bitwise reproducible and equal to what the former second "fix-up" launch produced).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,11 +50,12 @@ struct SKArgs {
   long long U;
   long long tiles;
   float* ws;
+  unsigned* counters;  // one per tile (head of the workspace, zeroed by ldc_gemm_grouped_workspace_init, re-armed by the last arriver)
 };
 
 __device__ __forceinline__ long long range_start(long long g, long long U, int G) { return (g * U) / G; }
 
-// epilogue shared by the main and the fix-up kernel; acc layout = MFMA C/D layout of the 2x2 wave grid
+// epilogue (whole tiles and the last-arriving piece of split tiles); acc layout = MFMA C/D layout of the 2x2 wave grid
 __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x16 (&acc)[2][2],
                                               int wm, int wn, int lane) {
   const int M = P.d.M, N = P.d.N;
@@ -88,6 +91,61 @@ __device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u
   for (int k = 1; k < MAXP; ++k)
     if (k < a.np && u >= a.pr[k].unit0) pi = k;
   return pi;
+}
+
+// A piece of a split tile: publish, take a ticket, and - if this piece arrived last - sum all pieces in workgroup order and
+// finish the tile.  `flag`: one LDS word that is idle here (the staging ring behind the k loop's last barrier).
+__device__ __forceinline__ void publish_or_reduce(const SKArgs& a, const DevProblem& P, int g, int tile, int k0, int b, int bm, int bn,
+                                                  f32x16 (&acc)[2][2], int wave, int wm, int wn, int lane, unsigned* flag) {
+  float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(slot + ((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;  // the tile's first unit
+  const long long l = f + P.kt;
+  long long g_first = g;
+  while (g_first > 0 && range_start(g_first, a.U, a.G) > f) --g_first;
+  long long g_last = g;
+  while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
+  const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
+  unsigned* cnt = a.counters + (P.tile0 + tile);
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  const unsigned is_last = *flag;
+  __syncthreads();  // the flag word is staging memory: everyone has read it before the next segment stages into it
+  if (!is_last) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (long long gp = g_first; gp <= g_last; ++gp) {
+    const long long s = range_start(gp, a.U, a.G);
+    const float* sl = a.ws + (2 * gp + (s > f ? 0 : 1)) * SLOT_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
+  }
+  tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(SKArgs a) {
@@ -191,13 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_kernel(SKArgs a) {
       tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
     } else {
       // raw accumulators, lane-contiguous: slot[(wave*4 + i*2 + j)*16 + r][lane]
-      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      publish_or_reduce(a, P, g, tile, k0, b, bm, bn, acc, wave, wm, wn, lane, reinterpret_cast<unsigned*>(smem));
     }
     u += k1 - k0;
   }
@@ -383,13 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_streamk_bf16x3_kernel(SKArgs a) {
     if (k0 == 0 && k1 == P.kt) {
       tile_epilogue(P, b, bm, bn, acc, wm, wn, lane);
     } else {
-      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      publish_or_reduce(a, P, g, tile, k0, b, bm, bn, acc, wave, wm, wn, lane, reinterpret_cast<unsigned*>(smem_b));
     }
     u += k1 - k0;
   }
@@ -407,51 +453,6 @@ __global__ __launch_bounds__(256) void pack_weight_bf16x2_kernel(const float* __
   split8(src[0], src[1], h, l);
   out[idx * 2] = h;
   out[idx * 2 + 1] = l;
-}
-
-// one workgroup per output tile; tiles that one range covered completely were finished above
-__global__ __launch_bounds__(256) void gemm_streamk_fixup_kernel(SKArgs a) {
-  const long long t = blockIdx.x;
-  int pi = 0;
-#pragma unroll
-  for (int k = 1; k < MAXP; ++k)
-    if (k < a.np && t >= a.pr[k].tile0) pi = k;
-  const DevProblem& P = a.pr[pi];
-  const int tile = static_cast<int>(t - P.tile0);
-  const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;  // tile's first unit
-  const long long l = f + P.kt;
-  long long g0 = (f * a.G) / a.U;
-  while (g0 + 1 < a.G && range_start(g0 + 1, a.U, a.G) <= f) ++g0;
-  while (g0 > 0 && range_start(g0, a.U, a.G) > f) --g0;
-  if (range_start(g0 + 1, a.U, a.G) >= l) return;  // a single range holds the whole tile
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (long long g = g0; g < a.G; ++g) {
-    const long long s = range_start(g, a.U, a.G), e = range_start(g + 1, a.U, a.G);
-    if (s >= l) break;
-    const long long ob = s > f ? s : f, oe = e < l ? e : l;
-    if (oe <= ob) continue;
-    const float* slot = a.ws + (2 * g + (ob > f ? 0 : 1)) * SLOT_FLOATS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane];
-  }
-  const int bn = tile % P.tn;
-  const int bmb = tile / P.tn;
-  tile_epilogue(P, bmb / P.tm, bmb % P.tm, bn, acc, wm, wn, lane);
 }
 
 }  // namespace
@@ -507,7 +508,7 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
     tiles += t;
     U += t * P.kt;
   }
-  if (tiles > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  if (tiles > LDC_GEMM_COUNTER_BYTES / 4 - 16) return LDC_ERR_UNSUPPORTED;  // one hand-off counter per tile (1 MiB block: 262 128 tiles)
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
   long long G = 512;
   {
@@ -530,6 +531,7 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
   a.U = U;
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
+  a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = split_bf16 ? 2 * STAGE_BYTES_B : 2 * STAGE_FLOATS * sizeof(float);
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_streamk_kernel),
@@ -542,10 +544,6 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (split_bf16) hipLaunchKernelGGL(gemm_streamk_bf16x3_kernel, dim3(a.G), dim3(256), lds, s, a);
   else hipLaunchKernelGGL(gemm_streamk_kernel, dim3(a.G), dim3(256), lds, s, a);
-  int st = ldc_launch_status();
-  if (st != LDC_OK) return st;
-  // some tile is split whenever the ranges are not tile-aligned; the fix-up exits at once for whole tiles
-  hipLaunchKernelGGL(gemm_streamk_fixup_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, a);
   return ldc_launch_status();
 }
 

@@ -96,7 +96,12 @@ def run_rollout(
     default process group when there is one.  ``save_as_latent``: rank 0 writes ``<output>/latent_YYYYMMDDHH.npy`` holding
     ``(ens, 84, 1 + steps, 15, 30)`` (:420-430).  Returns the per-initial-time tensors ``(ens, C, 1 + steps, h, w)`` (on every rank).
     ``device``: where the per-rank result block lives for the gather - pass this rank's GPU with the nccl (RCCL) backend.
-    ``batch_size``: initial times per sharded batch (default: the number of ranks, as pred_rollout.py:336-338)."""
+    ``batch_size``: initial times per sharded batch (default: the number of ranks, as pred_rollout.py:336-338).  Memory of the
+    gather: the collective itself moves the per-rank blocks in pieces of at most 256 MiB (``distributed.GATHER_CHUNK_BYTES``); the
+    assembled batch - ``batch_size x ens`` items - lives on ``device`` in latent mode (12 MB per member at 240 h) and on the HOST in
+    decoded mode (``save_as_latent=False``: 0.8 GB per member at 240 h; 8 initial times x 20 members = 130 GB, never on a GPU).
+    ``noise_level > 0`` perturbs each initial time's IC once, from a generator seeded by the initial time (``ic_noise_seed``, default
+    0), so the result does not depend on the number of ranks."""
     if total_lead_time_hour % step_size_hour:
         raise ValueError("total_lead_time_hour must be divisible by step_size_hour")  # pipelines/utils.py:305-306
     import torch.distributed as dist
@@ -110,7 +115,7 @@ def run_rollout(
     for b0 in range(0, len(init_times), batch_size):
         batch = init_times[b0 : b0 + batch_size]
         full = roll_out_sharded(
-            roll_out_serial, ensemble_size=ensemble_size, device=device, input_fields=input_fields, pred_timestamp=batch, pipeline=pipeline,
+            roll_out_serial, ensemble_size=ensemble_size, device=device, out_device=None if save_as_latent else "cpu", input_fields=input_fields, pred_timestamp=batch, pipeline=pipeline,
             normalization_param_dict=normalization_param_dict, num_inference_steps=num_inference_steps, return_seq_len=return_seq_len,
             encdec_model=encdec_model, encdec_model_type="ae", static_tensor4encdec=static_conditioning_tensor, latent_transform="normalize",
             latent_transform_args=latent_transform_args, total_lead_time_hour=total_lead_time_hour, step_size_hour=step_size_hour,

@@ -22,6 +22,7 @@ ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per row, the input row = its sinusoidal embedding
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
 ATTN_OUT_SPLIT, ATTN_BF16_1TERM, ATTN_OUT_BF16 = 1, 2, 4
+ABI_VERSION = 2  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
 FMT_F32, FMT_SPLIT, FMT_BF16 = 0, 1, 2  # activation formats of the producers' `out_split` arguments (True == FMT_SPLIT)
 
 
@@ -91,9 +92,6 @@ def _load():
         "ldc_relu_linear_attn_nhwc_fmt": (I, [P, P, I, I, I, I, I, F, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
         "ldc_ensemble_scores": (I, [P, L, L, P, L, P, L, P, I, I, I, I, I, P, P, P, P, L, P]),
-        "ldc_attn_packed_bytes": (L, [I, I, I]),
-        "ldc_attn_pack_bf16x3": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P, P]),
-        "ldc_attn_fwd_packed_bf16x3": (I, [P, P, I, I, I, I, L, I, P]),
         "ldc_layernorm_mod": (I, [P, P, I, I, I, I, L, I, L, P, P, I, I, F, I, P]),
         "ldc_layernorm_mod2": (I, [P, P, I, I, I, I, L, I, L, P, P, I, P, P, I, I, F, I, P]),
         "ldc_mean_rows": (I, [P, P, I, I, I, I, L, P]),
@@ -128,7 +126,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.ldc_abi_version() != 1:
+    if lib.ldc_abi_version() != ABI_VERSION:
         raise RuntimeError("libladcast_hip.so ABI version mismatch")
     if lib.ldc_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc) or lib.ldc_sizeof_gemm_problem() != ctypes.sizeof(GemmProblem):
         raise RuntimeError("ldc_gemm_desc / ldc_gemm_problem layout mismatch between header and binding")
@@ -193,7 +191,7 @@ def gemm_problem(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_b
 
 
 def gemm_grouped(problems, split_bf16=False):
-    """Up to MAX_GROUPED independent GEMMs in one persistent stream-K launch (+ fix-up launch).
+    """Up to MAX_GROUPED independent GEMMs in one persistent stream-K launch (split tiles are reduced inside the launch).
     split_bf16: every problem's W is a `pack_weight_bf16x2` buffer and the bf16x3 kernel is used."""
     n = len(problems)
     if not 1 <= n <= MAX_GROUPED:
@@ -294,20 +292,6 @@ def ensemble_scores(forecast, truth, clim, lat_weight, out, *, M, C, H, W, membe
                                    _p(ws), ws.numel() * 4, _stream()), "ldc_ensemble_scores")
 
 
-def attn_packed_bytes(B, S, H):
-    return int(lib.ldc_attn_packed_bytes(B, S, H))
-
-
-def attn_pack(Q, K, V, packed, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None, None, None, None), seg1=(None, None, None, None),
-              eps=1e-6):
-    """seg = (wq, wk, cos, sin) for token rows [0, split_row) / [split_row, S); None entries = no norm / no RoPE"""
-    _dev(Q, K, V, packed, *seg0, *seg1)
-    if packed.numel() * packed.element_size() < attn_packed_bytes(B, S, H):
-        raise ValueError("packed buffer smaller than ldc_attn_packed_bytes")
-    _check(lib.ldc_attn_pack_bf16x3(_p(Q), _p(K), _p(V), B, S, H, ld_qkv, qkv_bs, split_row, *[_p(t) for t in seg0],
-                                    *[_p(t) for t in seg1], eps, _p(packed), _stream()), "ldc_attn_pack_bf16x3")
-
-
 def compact_rope_table(cos, sin):
     """the reference's [rows][128] cos / sin tables (every value twice: get_1d_rotary_pos_embed's repeat_interleave(2)) -> the
     [rows][64][2] (cos_i, sin_i) table of `qkv_epilogue`; refuses tables that are not of that form"""
@@ -324,16 +308,44 @@ def qkv_epilogue(wq=None, wk=None, rope=None, *, eps=1e-7, heads, rope_row0=0, q
     return QkvEpilogue(pv(wq), pv(wk), pv(rope), None, eps, qscale, heads, rope_row0), (wq, wk, rope)
 
 
-def gemm_grouped_qkv(problems, epilogues):
+ERR_UNSUPPORTED = -3  # LDC_ERR_UNSUPPORTED
+
+
+def gemm_grouped_qkv(problems, epilogues, force_fallback=False):
     """`gemm_grouped(split_bf16=True)` where problem i with a non-None epilogue is a fused QKV projection whose C receives the
-    attention operand rows of `attn_fwd_split` (bias -> per-head RMSNorm -> rotary embedding -> q scale -> hi / lo split)"""
+    attention operand rows of `attn_fwd_split` (bias -> per-head RMSNorm -> rotary embedding -> q scale -> hi / lo split).
+    When the fused kernel does not serve the launch (LDC_ERR_UNSUPPORTED: K not a whole k-step, more tiles than hand-off counters)
+    this runs what include/ladcast_hip.h documents for that status - the plain grouped GEMM, then `ldc_attn_qkv_prepare_split` in
+    place on every QKV problem's output (split-bf16 mode only; `force_fallback` takes that route unconditionally, for tests)."""
     n = len(problems)
     if not 1 <= n <= MAX_GROUPED or len(epilogues) != n:
         raise ValueError(f"gemm_grouped_qkv takes 1..{MAX_GROUPED} problems and one epilogue (or None) per problem")
     arr = (GemmProblem * n)(*[p[0] for p in problems])
     epi = (QkvEpilogue * n)(*[(e[0] if e is not None else QkvEpilogue()) for e in epilogues])
     ws = _grouped_workspace(problems[0][1][2].device)
-    _check(lib.ldc_gemm_grouped_bf16x3_qkv(arr, epi, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped_bf16x3_qkv")
+    st = ERR_UNSUPPORTED if force_fallback else lib.ldc_gemm_grouped_bf16x3_qkv(arr, epi, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream())
+    if st != ERR_UNSUPPORTED:
+        _check(st, "ldc_gemm_grouped_bf16x3_qkv")
+        return
+    if any(p[0].d.flags & GEMM_BF16_1TERM for p in problems):
+        raise RuntimeError("ldc_gemm_grouped_bf16x3_qkv: shape not served by the fused kernel, and the plain-GEMM + ldc_attn_qkv_prepare_split "
+                           "route only writes split-bf16 operand rows (status -3 in the single-term bf16 mode)")
+    _check(lib.ldc_gemm_grouped_bf16x3(arr, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "ldc_gemm_grouped_bf16x3 (QKV fallback)")
+    for (p, keep), e in zip(problems, epilogues):
+        if e is None:
+            continue
+        q, (wq, wk, rope) = e
+        d, C = p.d, keep[2]
+        D, S = q.heads * 128, d.M
+        if d.N != 3 * D:
+            raise RuntimeError("ldc_gemm_grouped_bf16x3_qkv failed with status -1")  # what the fused launch reports for a wrong width
+        cos = sin = None
+        if rope is not None:  # the compact (cos_i, sin_i) table back in the [rows][128] form of ldc_attn_qkv_prepare_split
+            t = rope.reshape(-1, 64, 2)[q.rope_row0 : q.rope_row0 + S]
+            cos, sin = t[..., 0].repeat_interleave(2, dim=1).contiguous(), t[..., 1].repeat_interleave(2, dim=1).contiguous()
+        base = C.data_ptr()
+        _check(lib.ldc_attn_qkv_prepare_split(c_void_p(base), c_void_p(base + 4 * D), c_void_p(base + 8 * D), d.batch, S, q.heads, d.ldc, d.c_bs, S,
+                                              _p(wq), _p(wk), _p(cos), _p(sin), None, None, None, None, q.eps, _stream()), "ldc_attn_qkv_prepare_split")
 
 
 def attn_qkv_prepare_split(Q, K, V, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=(None, None, None, None), seg1=(None, None, None, None), eps=1e-7):
@@ -359,14 +371,6 @@ def pad_key_bias(bias):
     out = torch.zeros(32 * ((S + 31) // 32), device=bias.device, dtype=torch.float32)
     out[:S] = bias.reshape(-1)
     return out
-
-
-def attn_fwd_packed(packed, O, *, B, S, H, ldo, o_bs, out_split=False, one_term=False):
-    """one_term: single-term bf16 products (the "bf16" mixed-precision mode) instead of the split-bf16 three"""
-    _dev(packed, O)
-    flags = (ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
-    _check(lib.ldc_attn_fwd_packed_bf16x3(_p(packed), _p(O), B, S, H, ldo, o_bs, flags, _stream()),
-           "ldc_attn_fwd_packed_bf16x3")
 
 
 def qk_rmsnorm_rope(q, k, *, B, row0, rows, H, ld, bs, wq, wk, eps, cos=None, sin=None):

@@ -28,16 +28,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-import os
-
 from .. import hip
 from .embeddings import get_year_sincos_embedding, rope_tables_from_grid
 from .modeling_utils import ModelMixin
 
-
-# measurement aid, read once: LDC_ATTN_PATH=packed runs the second-generation attention (plain QKV GEMM -> pack pass -> packed attention)
-# instead of the fused QKV epilogue + row-major split attention, for same-box A/B runs (profiles/README.md); never set in production
-_PACKED_ATTENTION = os.environ.get("LDC_ATTN_PATH", "") == "packed"
 
 # ---------------------------------------------------------------------------
 # parameter containers (names = reference / diffusers attribute names)
@@ -569,20 +563,11 @@ class LaDCastTransformer3DModel(ModelMixin):
         q = qkv[:, row0:, 0:D]
         k = qkv[:, row0:, D : 2 * D]
         v = qkv[:, row0:, 2 * D : 3 * D]
-        if self.gemm_precision in ("bf16x3", "bf16") and not _PACKED_ATTENTION:
+        if self.gemm_precision in ("bf16x3", "bf16"):
             hip.attn_fwd_split(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, out_split=out_split,
                                one_term=self.gemm_precision == "bf16", key_bias=key_bias)
             return
         segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
-        if self.gemm_precision in ("bf16x3", "bf16"):  # measurement aid (LDC_ATTN_PATH=packed): the second-generation pack pass + attention
-            if key_bias is not None:
-                raise NotImplementedError("the packed attention path has no key bias")
-            if getattr(ws, "apack", None) is None:
-                ws.apack = torch.empty(hip.attn_packed_bytes(B, full, H) // 4, device=qkv.device, dtype=torch.float32)
-            sg = [(n.weight, m.weight, c, s_) for (_, (n, m, c, s_)) in segs] + [(None, None, None, None)]
-            hip.attn_pack(q, k, v, ws.apack, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, split_row=segs[0][0], seg0=sg[0], seg1=sg[1], eps=segs[0][1][0].eps)
-            hip.attn_fwd_packed(ws.apack, out, B=B, S=S, H=H, ldo=ldo, o_bs=o_bs, out_split=out_split, one_term=self.gemm_precision == "bf16")
-            return
         r0 = row0
         for rows, (nq, nk, c, s_) in segs:
             hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
@@ -745,7 +730,7 @@ class LaDCastTransformer3DModel(ModelMixin):
 
         def run_qkv(problems, epis):
             # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
-            if split and not _PACKED_ATTENTION:
+            if split:
                 hip.gemm_grouped_qkv(problems, epis)
             else:
                 hip.gemm_grouped(problems, split_bf16=split)

@@ -15,7 +15,9 @@ times than ranks GPUs idle, and a 20-member forecast never uses more than one GP
 ``world`` contiguous blocks whose sizes differ by at most one (``shard_work``): 1 initial time x 20
 members on 8 ranks is 2/3/2/3/2/3/2/3 (nothing better exists), 2 initial times x 20 members is 5 items
 everywhere, and ``ensemble_size < world`` leaves ``world - n_items`` ranks without work - they launch
-nothing and only join the gather.  Results do not depend on the partition.
+nothing and only join the gather.  Results do not depend on the partition: member k is seeded with k, and the optional IC
+perturbation (``noise_level > 0``: ONE draw per initial time shared by its members, pipelines/utils.py:518-528) is drawn from a
+generator seeded by the initial time (``ic_noise_seed``, set here when the caller did not), not from a per-process RNG stream.
 
 The helpers are device-agnostic (they only move tensors), so the N>1 logic is exercised on CPU
 with the gloo backend in ``tests/test_distributed_cpu.py``.
@@ -91,13 +93,21 @@ def shard_work(n_init: int, ensemble_size: int, rank: int, world_size: int) -> L
     return groups
 
 
-def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, group=None, device=None) -> torch.Tensor:
+GATHER_CHUNK_BYTES = 256 << 20  # per-rank bytes of one all_gather: bounds the device memory the collective itself needs
+
+
+def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, group=None, device=None, out_device=None,
+                max_bytes: int = GATHER_CHUNK_BYTES) -> torch.Tensor:
     """``local``: this rank's items ``(n_local, *item_shape)`` in ``shard_work`` order (``None`` / 0 rows for a rank without
-    work) -> ``(n_init, ensemble_size, *item_shape)`` on every rank.  One small all_reduce tells empty ranks the item shape,
-    one all_gather moves the (padded) blocks."""
+    work) -> ``(n_init, ensemble_size, *item_shape)`` on every rank.  One small all_reduce tells empty ranks the item shape; the
+    (padded) blocks move in all_gathers of at most ``max_bytes`` per rank each (latent items: one collective; decoded fields of a
+    long rollout - 0.8 GB per member at 240 h - several), so the collective needs ``(world + 1) x max_bytes`` of scratch on
+    ``device`` however large the batch is.  ``out_device``: where the assembled result lives (default: ``device``); pass "cpu"
+    for decoded-field batches that should not be resident on every GPU."""
     if not _active(group):
         assert local is not None and local.shape[0] == n_init * ensemble_size
-        return local.reshape(n_init, ensemble_size, *local.shape[1:])
+        out = local.reshape(n_init, ensemble_size, *local.shape[1:])
+        return out if out_device is None else out.to(out_device)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     b = work_bounds(n_init * ensemble_size, world)
     mine = b[rank + 1] - b[rank]
@@ -114,17 +124,30 @@ def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, 
     meta = meta.tolist()
     item = tuple(int(v) for v in meta[1 : 1 + int(meta[0])])
     cmax = max(b[r + 1] - b[r] for r in range(world))
-    x = torch.zeros((cmax,) + item, dtype=torch.float32, device=device)
-    if mine:
-        x[:mine] = local.to(device)
-    bufs = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(bufs, x, group=group)
-    out = torch.cat([bufs[r][: b[r + 1] - b[r]] for r in range(world)], dim=0)
+    if out_device is None:
+        out_device = device
+    n_el = 1
+    for v in item:
+        n_el *= v
+    rows = max(1, int(max_bytes // max(4 * n_el, 1)))  # rows of the padded block per collective
+    out = torch.empty((n_init * ensemble_size,) + item, dtype=torch.float32, device=out_device)
+    for r0 in range(0, cmax, rows):
+        n = min(rows, cmax - r0)
+        x = torch.zeros((n,) + item, dtype=torch.float32, device=device)
+        have = min(max(mine - r0, 0), n)
+        if have:
+            x[:have] = local[r0 : r0 + have].to(device)
+        bufs = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(bufs, x, group=group)
+        for r in range(world):
+            cnt = min(max(b[r + 1] - b[r] - r0, 0), n)
+            if cnt:
+                out[b[r] + r0 : b[r] + r0 + cnt] = bufs[r][:cnt].to(out_device)
     return out.reshape(n_init, ensemble_size, *item)
 
 
 def roll_out_sharded(roll_out_fn, ensemble_size: int, pred_timestamp: Sequence, group=None, device: Optional[torch.device] = None,
-                     **kwargs) -> torch.Tensor:
+                     out_device=None, **kwargs) -> torch.Tensor:
     """Run ``roll_out_fn`` (``roll_out_serial``-compatible) on this rank's (initial time, member) items and gather.
 
     One call per initial time this rank touches, with ``ensemble_size = len(ids)`` and ``member_ids = ids``; its output is
@@ -133,6 +156,8 @@ def roll_out_sharded(roll_out_fn, ensemble_size: int, pred_timestamp: Sequence, 
     (this rank's GPU with the nccl = RCCL backend; the host with gloo)."""
     if kwargs.get("return_ensemble_mean"):
         raise ValueError("return_ensemble_mean needs every member on one rank; gather the members and average instead")
+    if kwargs.get("noise_level") and kwargs.get("ic_noise_seed") is None:
+        kwargs["ic_noise_seed"] = 0  # the IC perturbation of an initial time must not depend on which rank / piece draws it
     rank = dist.get_rank(group) if _active(group) else 0
     world = dist.get_world_size(group) if _active(group) else 1
     n_init = len(pred_timestamp)
@@ -141,6 +166,6 @@ def roll_out_sharded(roll_out_fn, ensemble_size: int, pred_timestamp: Sequence, 
         o = roll_out_fn(ensemble_size=len(ids), member_ids=ids, pred_timestamp=[pred_timestamp[t]], **kwargs)
         blocks.append(o[0])
     local = torch.cat(blocks, dim=0) if blocks else None
-    if local is not None and device is not None:
-        local = local.to(device)
-    return gather_work(local, n_init, ensemble_size, group=group, device=device)
+    if local is not None and device is not None and out_device is None:
+        local = local.to(device)  # (with a separate out_device the block is moved piece by piece inside gather_work)
+    return gather_work(local, n_init, ensemble_size, group=group, device=device, out_device=out_device)

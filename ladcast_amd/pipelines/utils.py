@@ -201,6 +201,7 @@ def roll_out_serial(
     member_ids: Optional[Sequence[int]] = None,
     known_latents_override: Optional[torch.Tensor] = None,
     raw_input_fields: Optional[Callable[[datetime], torch.Tensor]] = None,
+    ic_noise_seed: Optional[int] = None,
     **_ignored,  # e.g. log_pred_interval_hour, which the reference CLI passes (evaluate/pred_rollout.py:384, Q2)
 ) -> torch.Tensor:
     """Tensor mode of pipelines/utils.py:249-661.
@@ -217,7 +218,10 @@ def roll_out_serial(
     ``(C, T_in, h, w)`` un-normalised IC latent used instead of encoding.  ``ensemble_size == 0`` (a rank
     without members) returns the ``(n_init, 0, ...)``-shaped tensor without launching kernels when the
     shape is known without encoding (``known_latents_override``), and is otherwise handled by the caller
-    (``pipelines/distributed.py``).
+    (``pipelines/distributed.py``).  ``noise_level > 0`` perturbs the IC latent ONCE per initial time, shared by all members
+    (:518-528).  ``ic_noise_seed=None`` draws that perturbation from torch's global RNG as the reference does; an integer draws it
+    from a CPU generator seeded with ``ic_noise_seed + YYYYMMDDHH`` of the initial time, so that every call that touches this initial
+    time - e.g. the pieces of one forecast cut over several ranks (``pipelines/distributed.py``) - perturbs it identically.
     """
     if not return_tensor:
         raise NotImplementedError("xarray output is out of scope; use return_tensor=True")
@@ -278,7 +282,12 @@ def roll_out_serial(
         known = fwd(known.contiguous())
         if noise_level and noise_level > 0:
             lstd = torch.tensor(latent_transform_args["std"], dtype=torch.float32, device=known.device)[:, None, None, None]
-            known = known + torch.randn_like(known) * noise_level * lstd
+            if ic_noise_seed is None:
+                eps = torch.randn_like(known)
+            else:
+                gen = torch.Generator("cpu").manual_seed((int(ic_noise_seed) + convert_datetime_to_int(t0)) % (1 << 62))
+                eps = torch.randn(tuple(known.shape), generator=gen, dtype=torch.float32).to(known.device)
+            known = known + eps * noise_level * lstd
         known = known.unsqueeze(0)
         for step in range(reps):
             cur = min(1 + (step + 1) * return_seq_len, total + 1)

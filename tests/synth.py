@@ -86,3 +86,18 @@ class DuckDDIMScheduler:
         x0 = (sample - (1.0 - a_t) ** 0.5 * model_output) / a_t**0.5
         prev = a_prev**0.5 * x0 + (1.0 - a_prev) ** 0.5 * model_output
         return (prev,) if not return_dict else {"prev_sample": prev}
+
+
+class oracle_threads:
+    """tiny-width oracle runs on a 128-core host are slower with all cores than with a few (the ops are small): limit torch's
+    intra-op pool for the block (results do not depend on it beyond BLAS blocking, ~1e-7)"""
+
+    def __init__(self, n=16):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(min(self.n, self.old))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.old)

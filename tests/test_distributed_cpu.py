@@ -147,3 +147,71 @@ def test_run_rollout_batches_and_files(tmp_path):
     for t, r in zip(times, res):
         f = np.load(os.path.join(str(tmp_path), t.strftime("latent_%Y%m%d%H.npy")))
         assert np.array_equal(f, r.numpy())
+
+
+# -- IC perturbation (noise_level > 0) must not depend on the partition; chunked gather ---------------------------------------------
+def _real_rollout_kwargs():
+    """the PRODUCT's roll_out_serial on the CPU: host loop of the pipeline sampler with an elementwise toy network and a duck-typed
+    scheduler (no HIP kernel on this path: latent_transform=None, sampler_type="pipeline", a given IC latent)"""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline
+    from tests.golden.make_golden import ToyNet
+    from tests.synth import DuckDDIMScheduler, synth_known
+
+    g = torch.Generator().manual_seed(5)
+    return dict(input_fields=None, pipeline=AutoRegressive2DPipeline(ToyNet(84), DuckDDIMScheduler()), num_inference_steps=3, return_seq_len=2,
+                latent_transform=None, latent_transform_args={"std": (torch.rand(84, generator=g) + 0.5).tolist()}, total_lead_time_hour=18,
+                sampler_type="pipeline", return_latent=True, known_latents_override=synth_known(1)[0], noise_level=0.3)
+
+
+def _worker_noise(rank, world, port, result_path):
+    from datetime import datetime
+
+    from ladcast_amd.pipelines import roll_out_serial
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different global RNG streams per process: the result must not see them
+    times = [datetime(2018, 1, 1, 0), datetime(2018, 1, 2, 12)]
+    full = roll_out_sharded(roll_out_serial, ensemble_size=3, pred_timestamp=times, **_real_rollout_kwargs())
+    x = torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3) + 1000 * rank
+    mine = work_bounds(14, world)
+    chunked = gather_work(x[: mine[rank + 1] - mine[rank]], 2, 7, max_bytes=2 * 15 * 4, out_device="cpu")  # two rows per collective
+    torch.save((full, chunked), f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ic_noise_is_partition_invariant_and_gather_is_chunked(tmp_path):
+    """2 initial times x 3 members on 2 ranks cut initial time 1 between the ranks (items 0-2 | 3-5 are whole
+    times here, so also 1 x 3 on 2 ranks below); with noise_level > 0 every piece of an initial time must start from the SAME perturbed
+    IC.  The 2-rank result equals the single-process result bit for bit, members of one initial time share slot 0, and initial times
+    differ."""
+    from datetime import datetime
+
+    from ladcast_amd.pipelines import roll_out_serial
+
+    path = str(tmp_path / "res")
+    mp.spawn(_worker_noise, args=(2, _free_port(), path), nprocs=2, join=True)
+    (f0, c0), (f1, c1) = torch.load(path + ".0"), torch.load(path + ".1")
+    times = [datetime(2018, 1, 1, 0), datetime(2018, 1, 2, 12)]
+    torch.manual_seed(7)
+    single = roll_out_sharded(roll_out_serial, ensemble_size=3, pred_timestamp=times, **_real_rollout_kwargs())
+    assert single.shape == (2, 3, 84, 4, 15, 30) and torch.isfinite(single).all()
+    assert torch.equal(f0, single) and torch.equal(f1, single)
+    # the perturbation is real, shared by the members of an initial time, different between initial times
+    clean = roll_out_sharded(roll_out_serial, ensemble_size=3, pred_timestamp=times, **dict(_real_rollout_kwargs(), noise_level=0))
+    assert not torch.equal(single[:, :, :, 1:], clean[:, :, :, 1:])
+    kw = dict(_real_rollout_kwargs(), ic_noise_seed=0)
+    a = roll_out_serial(pred_timestamp=times[:1], ensemble_size=1, member_ids=[2], **kw)
+    assert torch.equal(a[0, 0], single[0, 2])  # a piece holding only member 2 of the first initial time
+    assert not torch.equal(single[0, 0, :, 1:], single[1, 0, :, 1:])
+    # the reference's own behaviour (global RNG) is still there when no seed is given
+    torch.manual_seed(1)
+    r1 = roll_out_serial(pred_timestamp=times[:1], ensemble_size=1, **_real_rollout_kwargs())
+    torch.manual_seed(2)
+    r2 = roll_out_serial(pred_timestamp=times[:1], ensemble_size=1, **_real_rollout_kwargs())
+    assert not torch.equal(r1[:, :, :, 1:], r2[:, :, :, 1:])
+    # chunked gather: 14 items of (5, 3) over 2 ranks in collectives of two rows
+    want = torch.cat([torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3) + 1000 * r for r in range(2)]).reshape(2, 7, 5, 3)
+    assert torch.equal(c0, want) and torch.equal(c1, want)

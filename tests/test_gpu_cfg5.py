@@ -20,7 +20,7 @@ from oracle import autocast as OA  # noqa: E402
 from oracle import pipelines as OP  # noqa: E402
 from oracle.dcae import CONFIG_DCAE_84  # noqa: E402
 from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler  # noqa: E402
-from tests.synth import make_ar, make_dcae, rel_l2, synth_field, tiny_ar_config  # noqa: E402
+from tests.synth import make_ar, make_dcae, oracle_threads, rel_l2, synth_field, tiny_ar_config  # noqa: E402
 
 
 def _hip_ar(o, cfg):
@@ -74,16 +74,15 @@ def test_cfg5_end_to_end_three_chunks_bf16_mixed_vs_oracle_and_autocast():
     def per_chunk(got, want):
         return [rel_l2(got[:, :, :, 1 + R * c : 1 + R * (c + 1)].float(), want[:, :, :, 1 + R * c : 1 + R * (c + 1)]) for c in range(chunks)]
 
-    want = oracle_run(False)
-    want_lat = oracle_run(True)
-    assert want.shape == (1, 2, 84, 1 + R * chunks, 120, 240) and not torch.isnan(want[:, :, :, 1:]).any()
-    auto = {}
-    for policy in ("cuda", "cpu"):
-        with OA.reference_autocast(policy):
-            auto[policy] = (per_chunk(oracle_run(False), want), per_chunk(oracle_run(True), want_lat))
-        print(f"\ncfg5 tiny, oracle under autocast[{policy}] vs fp32 oracle, per chunk: decoded {_fmt(auto[policy][0])} | latent {_fmt(auto[policy][1])}")
-    best_dec = [min(a, b) for a, b in zip(auto["cuda"][0], auto["cpu"][0])]
-    best_lat = [min(a, b) for a, b in zip(auto["cuda"][1], auto["cpu"][1])]
+    with oracle_threads(16):
+        want = oracle_run(False)
+        want_lat = oracle_run(True)
+        assert want.shape == (1, 2, 84, 1 + R * chunks, 120, 240) and not torch.isnan(want[:, :, :, 1:]).any()
+        # policy "cuda": the cast lists of the reference's device; the literal CPU lists ("cpu") give the same figures to 3 digits
+        # (profiles/r03_a_gpu_tests.log)
+        with OA.reference_autocast("cuda"):
+            best_dec, best_lat = per_chunk(oracle_run(False), want), per_chunk(oracle_run(True), want_lat)
+    print(f"\ncfg5 tiny, oracle under autocast vs fp32 oracle, per chunk: decoded {_fmt(best_dec)} | latent {_fmt(best_lat)}")
 
     gae.set_gemm_precision("bf16")
     gar.set_gemm_precision("bf16")

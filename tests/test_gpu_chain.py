@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 from oracle import pipelines as OP  # noqa: E402
 from oracle.ar_model import CONFIG_375M  # noqa: E402
 from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler  # noqa: E402
-from tests.synth import make_ar, rel_l2, synth_known, tiny_ar_config  # noqa: E402
+from tests.synth import make_ar, oracle_threads, rel_l2, synth_known, tiny_ar_config  # noqa: E402
 
 TOL = 1e-4
 
@@ -141,8 +141,9 @@ def test_ten_chunk_chain_bf16x3_error_growth():
     kw = dict(ensemble_size=2, num_inference_steps=20, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=240, sampler_type="edm",
               return_latent=True)
     tc = time.perf_counter()
-    want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
-                              static_tensor4encdec=torch.zeros(5, 120, 240), **kw)
+    with oracle_threads(16):
+        want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
+                                  static_tensor4encdec=torch.zeros(5, 120, 240), **kw)
     tc = time.perf_counter() - tc
     assert want.shape == (1, 2, 84, 41, 15, 30)
     for mode in ("bf16x3", "fp32"):

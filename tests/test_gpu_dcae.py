@@ -586,3 +586,28 @@ def test_dcae_hip_graph_is_bitwise_equal_to_eager(prec):
         for x, y, z in zip(a, b, c):
             assert torch.equal(x, y) and torch.equal(x, z)
     assert runs[False][0][0][2].shape[1] == runs[False][0][0][1].shape[1] + 5
+
+
+def test_dc_ae_ray_1024_shape_one_frame():
+    """The reference's OTHER shipped autoencoder config, configs/DC_AE_ray_1024.yaml:1-50 - 90 in / out channels (84 + 6 static fields),
+    1024 latent channels, widths 512 / 1024 / 1024 / 2048 (64 linear-attention heads at the deepest stage), 1.09 G parameters - is
+    inside the supported set: instantiated at full width, one frame encoded and decoded against the oracle in the exact-fp32 and the
+    split-bf16 mode.  The frame is 48 x 96 (latent 6 x 12: still the linear-attention branch) so that the CPU oracle needs seconds."""
+    cfg = dict(OD.CONFIG_DCAE_84, in_channels=90, out_channels=90, latent_channels=1024, encoder_block_out_channels=(512, 1024, 1024, 2048),
+               decoder_block_out_channels=(512, 1024, 1024, 2048), static_channels=6)
+    o = make_dcae(cfg)
+    g = _hip_of(o, cfg)
+    f, st = synth_field(1, 84, 48, 96), synth_field(1, 6, 48, 96, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st).latent
+        yo = o.decode(zo).sample
+    assert zo.shape == (1, 1024, 6, 12) and yo.shape == (1, 84, 48, 96)
+    for mode in ("fp32", "bf16x3"):
+        g.set_gemm_precision(mode)
+        zg = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+        yg = g.decode(zo.cuda()).sample
+        ez, ey = rel_l2(zg.cpu(), zo), rel_l2(yg.cpu(), yo)
+        print(f"\nDC_AE_ray_1024 shape, one 48 x 96 frame [{mode}]: encode rel-L2 {ez:.2e}, decode rel-L2 {ey:.2e}")
+        assert zg.shape == zo.shape and yg.shape == yo.shape
+        assert ez < 1e-4 and ey < 1e-4, (mode, ez, ey)
+

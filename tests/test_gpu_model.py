@@ -184,9 +184,10 @@ def test_full_375m_forward_all_modes_one_and_two_members(oracle_375m):
             got = g(x.cuda(), torch.tensor([t]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
             errs[mode] = rel_l2(got.cpu(), want)
             assert errs[mode] < tolerance(mode, "forward"), (B, t, mode, errs)
-            if B == 2:  # members of one batch are independent: member 1 alone gives the same bits as inside the batch
+            if B == 2:  # members of one batch are independent: member 1 alone gives the same values as inside the batch (not the same
+                # bits: the stream-K unit ranges of a two-member launch cut the k loops of its tiles elsewhere)
                 alone = g(x[1:].cuda(), torch.tensor([t]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
-                assert torch.equal(alone[0], got[1]), mode
+                assert rel_l2(alone[0], got[1]) < (1e-6 if mode == "fp32" else 2e-5 if mode == "bf16x3" else 2e-3), mode
         print(f"\n375M forward B = {B}, c_noise = {t}: rel-L2 vs fp32 oracle " + ", ".join(f"{m} {e:.2e}" for m, e in errs.items())
               + (f"; oracle under autocast {e_auto:.2e}" if e_auto is not None else ""))
         assert errs["bf16"] > 1e-5  # the single-term mode is really on

@@ -253,6 +253,29 @@ def test_gemm_bf16x3_inlaunch_reduction_is_deterministic_and_rearmed(hip):
     assert int(ws.view(torch.int32)[: (1 << 20) // 4].abs().sum().item()) == 0
 
 
+def test_gemm_fp32_streamk_inlaunch_reduction_is_deterministic_and_rearmed(hip):
+    """round 3: the exact-fp32 stream-K kernel reduces its split tiles INSIDE the launch (last arriver, fixed order; the second
+    "fix-up" launch is gone): repeated launches are bitwise identical - with other launches in between that leave different data in
+    the slabs -, the arrival counters are back to zero after every call, ragged shapes whose tiles are cut into 3+ pieces included,
+    and a grouped launch of different k-depths."""
+    for (M, N, K) in ((2250, 1536, 7680), (450, 1536, 6144), (129, 130, 36), (2250, 4608, 1536)):
+        A, W, b = dev(rnd(M, K, seed=1)), dev(rnd(N, K, seed=2) / math.sqrt(K)), dev(rnd(N, seed=3))
+        other = dev(rnd(M, K, seed=9) * 3)
+        outs = []
+        for it in range(5):
+            C = torch.full((M, N), float("nan"), device="cuda")
+            hip.gemm_sk(A, W, C, M=M, N=N, K=K, bias=b, act=hip.ACT_GELU_TANH)
+            outs.append(C)
+            if it % 2 == 0:
+                hip.gemm_sk(other, W, torch.empty(M, N, device="cuda"), M=M, N=N, K=K)
+        for c in outs[1:]:
+            assert torch.equal(outs[0], c), (M, N, K)
+        want = F.gelu(A.cpu().double() @ W.cpu().double().T + b.cpu().double(), approximate="tanh")
+        assert rel(outs[0], want) < 2e-6
+        ws = hip._grouped_workspace(A.device)
+        assert int(ws.view(torch.int32)[: (1 << 20) // 4].abs().sum().item()) == 0
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a = torch.zeros(8, 6, device="cuda")
     with pytest.raises(RuntimeError):
@@ -276,68 +299,8 @@ def test_attention(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
 
 
-def _packed(hip, B, S, H):
-    return torch.empty(hip.attn_packed_bytes(B, S, H) // 4, device="cuda", dtype=torch.float32)
-
-
-@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (1, 128, 3), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 2250, 16), (1, 97, 2)])
-def test_attention_packed_bf16x3(hip, B, S, H):
-    """pack (no norm / RoPE) + LDS-DMA attention == sdpa on the raw operands; Q, K, V are left untouched"""
-    D = H * 128
-    qkv = rnd(B, S, 3 * D, seed=11)
-    qkv[..., :D] *= 4.0
-    d_qkv = dev(qkv)
-    pk = _packed(hip, B, S, H)
-    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
-    hip.attn_pack(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, split_row=S)
-    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64))
-    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
-    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, S, D)
-    assert torch.isfinite(out[:, :, :D]).all()
-    assert rel(out[:, :, :D], want) < 2e-5
-    assert torch.isnan(out[:, :, D:]).all()
-    assert torch.equal(d_qkv.cpu(), qkv)
-
-
-@pytest.mark.parametrize("Nx,Nc,rope1", [(37, 11, False), (1800, 450, True), (64, 0, False), (40, 57, True)])
-def test_attention_packed_norm_rope_two_segments(hip, Nx, Nc, rope1):
-    """the pack kernel's q/k RMSNorm + RoPE per row segment, against the oracle layers + sdpa (same maths as
-    ldc_qk_rmsnorm_rope + ldc_attn_fwd; reference models/LaDCast_3D_model.py:103-203)"""
-    B, H = 2 if Nx < 100 else 1, 3
-    D, S = H * 128, Nx + Nc
-    qkv = rnd(B, S + 5, 3 * D, seed=1)  # 5 extra token rows in the buffer: batch stride != S * ld
-    wq0, wk0, wq1, wk1 = [1 + 0.1 * rnd(128, seed=s_) for s_ in (2, 3, 4, 5)]
-    cos0, sin0 = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
-    cos1, sin1 = L.get_1d_rotary_pos_embed(128, torch.arange(max(Nc, 1)).float() * 0.11 - 3.0, 256.0)
-    d = dev(qkv)
-    pk = _packed(hip, B, S, H)
-    out = torch.empty(B, S, D, device="cuda")
-    seg1 = (dev(wq1), dev(wk1), dev(cos1) if rope1 else None, dev(sin1) if rope1 else None)
-    hip.attn_pack(d[:, :, :D], d[:, :, D : 2 * D], d[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=(S + 5) * 3 * D, split_row=Nx,
-                  seg0=(dev(wq0), dev(wk0), dev(cos0), dev(sin0)), seg1=seg1, eps=1e-7)
-    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D, o_bs=S * D)
-    norms = []
-    for w in (wq0, wk0, wq1, wk1):
-        n = L.RMSNorm(128, 1e-7)
-        n.weight.data = w
-        norms.append(n)
-    with torch.no_grad():
-        x = qkv[:, :S].double()
-        qk = []
-        for j in range(2):
-            t = x[:, :, j * D : (j + 1) * D].reshape(B, S, H, 128).transpose(1, 2).float()
-            a = L.apply_rotary_emb(norms[j](t[:, :, :Nx]), (cos0, sin0))
-            b = norms[2 + j](t[:, :, Nx:])
-            if rope1 and Nc:
-                b = L.apply_rotary_emb(b, (cos1, sin1))
-            qk.append(torch.cat([a, b], dim=2).double())
-        v = x[:, :, 2 * D :].reshape(B, S, H, 128).transpose(1, 2)
-        want = F.scaled_dot_product_attention(qk[0], qk[1], v).transpose(1, 2).reshape(B, S, D)
-    assert rel(out, want) < 2e-5
-
-
 def test_split_activation_producers(hip):
-    """LayerNorm and the packed attention can write their output in the split activation format: it must be the
+    """LayerNorm and the split attention can write their output in the split activation format: it must be the
     hi / lo split of exactly the fp32 values they write otherwise"""
     B, rows, D = 2, 53, 1536
     x = rnd(B, rows, D, seed=1) * 3 + 0.5
@@ -353,11 +316,11 @@ def test_split_activation_producers(hip):
     Bq, S, H = 1, 300, 3
     Dh = H * 128
     qkv = dev(rnd(Bq, S, 3 * Dh, seed=11))
-    pk = _packed(hip, Bq, S, H)
-    hip.attn_pack(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], pk, B=Bq, S=S, H=H, ld_qkv=3 * Dh, qkv_bs=S * 3 * Dh, split_row=S)
+    kwa = dict(B=Bq, S=S, H=H, ld_qkv=3 * Dh, qkv_bs=S * 3 * Dh)
+    hip.attn_qkv_prepare_split(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], split_row=S, **kwa)
     o0, o1 = torch.empty(Bq, S, Dh + 64, device="cuda"), torch.zeros(Bq, S, Dh + 64, device="cuda")
-    hip.attn_fwd_packed(pk, o0, B=Bq, S=S, H=H, ldo=Dh + 64, o_bs=S * (Dh + 64))
-    hip.attn_fwd_packed(pk, o1, B=Bq, S=S, H=H, ldo=Dh + 64, o_bs=S * (Dh + 64), out_split=True)
+    hip.attn_fwd_split(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], o0, ldo=Dh + 64, o_bs=S * (Dh + 64), **kwa)
+    hip.attn_fwd_split(qkv[:, :, :Dh], qkv[:, :, Dh : 2 * Dh], qkv[:, :, 2 * Dh :], o1, ldo=Dh + 64, o_bs=S * (Dh + 64), out_split=True, **kwa)
     hi, lo = _unsplit(o1, S, Dh + 64)
     w = o0.cpu().reshape(S, Dh + 64)[:, :Dh]
     assert torch.equal(hi[:, :Dh], w.bfloat16().float()) and torch.equal(lo[:, :Dh], (w - w.bfloat16().float()).bfloat16().float())
@@ -388,20 +351,6 @@ def test_split_format_from_the_transpose_and_the_pooling_pass(hip):
     hi, lo = _unsplit(big[:, S - rows :].contiguous(), B * rows, D)
     w = h.cpu().reshape(B * rows, D)
     assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - w.bfloat16().float()).bfloat16().float())
-
-
-def test_attention_packed_rescale_branch(hip):
-    S = 200
-    qkv = rnd(1, S, 3 * 128, seed=5) * 0.1
-    qkv[0, 150, 128:256] = qkv[0, 7, 0:128] * 400.0
-    d_qkv = dev(qkv)
-    pk = _packed(hip, 1, S, 1)
-    out = torch.empty(1, S, 128, device="cuda")
-    hip.attn_pack(d_qkv[:, :, :128], d_qkv[:, :, 128:256], d_qkv[:, :, 256:], pk, B=1, S=S, H=1, ld_qkv=384, qkv_bs=S * 384, split_row=S)
-    hip.attn_fwd_packed(pk, out, B=1, S=S, H=1, ldo=128, o_bs=S * 128)
-    q, k, v = [t.reshape(1, S, 1, 128).transpose(1, 2).double() for t in qkv.split(128, dim=-1)]
-    want = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, S, 128)
-    assert rel(out, want) < 2e-5 and rel(out[0, 7], want[0, 7]) < 2e-5
 
 
 def test_attention_online_softmax_rescale_branch(hip):
@@ -663,31 +612,6 @@ def test_bf16_row_producers(hip):
     assert torch.equal(_from_bf16_rows(o2, Dh + 128)[..., :Dh], o0.cpu()[..., :Dh].bfloat16().float())
 
 
-@pytest.mark.parametrize("B,S,H", [(1, 2250, 12), (2, 450, 2), (1, 33, 1), (3, 70, 2), (1, 1, 1), (2, 2250, 12), (1, 97, 2)])
-def test_attention_packed_bf16_single_term(hip, B, S, H):
-    """Qh.Kh^T scores (fp32), fp32 softmax, bf16(P).Vh: vs fp64 SDPA on the bf16-ROUNDED q, k, v the remaining difference is the
-    rounding of P (2^-9 relative per probability, averaged by the sum: stated 3e-3); vs SDPA on the raw operands 1e-2."""
-    D = H * 128
-    qkv = rnd(B, S, 3 * D, seed=11)
-    qkv[..., :D] *= 4.0
-    d_qkv = dev(qkv)
-    pk = _packed(hip, B, S, H)
-    out = torch.full((B, S, D + 64), float("nan"), device="cuda")
-    hip.attn_pack(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], pk, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, split_row=S)
-    hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64), one_term=True)
-    scale = 0.08838834764831845 * 1.4426950408889634  # the pack pass folds log2(e)/sqrt(128) into q BEFORE the rounding
-    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2) for t in qkv.split(D, dim=-1)]
-    qr = ((q * scale).bfloat16().double() / scale)
-    want_r = F.scaled_dot_product_attention(qr, k.bfloat16().double(), v.bfloat16().double()).transpose(1, 2).reshape(B, S, D)
-    want = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).transpose(1, 2).reshape(B, S, D)
-    assert torch.isfinite(out[:, :, :D]).all() and torch.isnan(out[:, :, D:]).all()
-    assert rel(out[:, :, :D], want_r) < 3e-3
-    assert rel(out[:, :, :D], want) < 1e-2
-    out3 = torch.empty_like(out)
-    hip.attn_fwd_packed(pk, out3, B=B, S=S, H=H, ldo=D + 64, o_bs=S * (D + 64))
-    assert rel(out3[:, :, :D], want) < 2e-5  # the same images still serve the split mode
-
-
 # -- third-generation attention: row-major split-bf16 operand rows (attn_split.hip) + the fused QKV-projection epilogue ----------------
 def _prep(hip, d_qkv, B, S, H, D, **kw):
     hip.attn_qkv_prepare_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=d_qkv.shape[1] * 3 * D, **kw)
@@ -827,6 +751,14 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     assert rel(h1 + l1, h2 + l2) < 1e-5
     with pytest.raises(RuntimeError):  # N must be 3 * heads * 128
         hip.gemm_grouped_qkv(probs[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, heads=H + 1)])
+    # the route ladcast_hip.h documents for LDC_ERR_UNSUPPORTED (plain GEMM, then ldc_attn_qkv_prepare_split in place): same attention
+    qkv.fill_(float("nan"))
+    mlp.zero_()
+    hip.gemm_grouped_qkv(probs, epis, force_fallback=True)
+    out_fb = torch.empty(batch, S, D, device="cuda")
+    hip.attn_fwd_split(qkv[:, :, :D], qkv[:, :, D : 2 * D], qkv[:, :, 2 * D :], out_fb, B=batch, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D)
+    assert rel(out_fb, want) < 2e-5 and rel(out_fb, out.double().cpu()) < 1e-5
+    assert rel(mlp, F.gelu(A.double() @ Wm.double().T + bm.double(), approximate="tanh")) < 1e-5
 
 
 # -- launch merges: each fused launch is bit-identical to the two launches it replaces ---------------------------------------------------

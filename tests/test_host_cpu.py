@@ -20,7 +20,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(hip.lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.SIGNATURES), "binding and header disagree"
-    assert hip.lib.ldc_abi_version() == 1 and hip.lib.ldc_build_arch() == b"gfx950"
+    abi = int(re.search(r"#define LDC_ABI_VERSION (\d+)", header).group(1))
+    assert hip.lib.ldc_abi_version() == abi == hip.ABI_VERSION == 2 and hip.lib.ldc_build_arch() == b"gfx950"
 
 
 def test_kernels_refuse_host_tensors():

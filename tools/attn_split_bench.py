@@ -1,5 +1,5 @@
-"""attention kernels at the model's shapes under sustained load: packed (2nd generation: pack pass + attention) vs split (3rd generation:
-operand rows from the QKV epilogue, no pack pass), both arithmetic modes.  usage: python tools/attn_split_bench.py [B]"""
+"""the split attention kernel (operand rows from the QKV epilogue) at the model's shapes under sustained load, both arithmetic modes.
+usage: python tools/attn_split_bench.py [B]   (the packed second-generation arm of the round-2 A/B was removed with its kernel)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,18 +11,13 @@ for (S, H) in ((2250, 12), (450, 12), (2250, 16)):
     qkv = torch.randn(B, S, 3 * D, device="cuda")
     qkv[..., :D] *= 2.0
     out = torch.empty(B, S, D, device="cuda")
-    pk = torch.empty(hip.attn_packed_bytes(B, S, H) // 4, device="cuda", dtype=torch.float32)
     q, k, v = qkv[:, :, :D], qkv[:, :, D : 2 * D], qkv[:, :, 2 * D :]
     kw = dict(B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D)
-    hip.attn_pack(q, k, v, pk, split_row=S, **kw)
     sp = qkv.clone()
     hip.attn_qkv_prepare_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], split_row=S, **kw)
     fl = 4.0 * B * H * S * S * 128
     variants = {
-        "pack pass": lambda: hip.attn_pack(q, k, v, pk, split_row=S, **kw),
-        "packed x3": lambda: hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D, o_bs=S * D, out_split=True),
         "split  x3": lambda: hip.attn_fwd_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], out, ldo=D, o_bs=S * D, out_split=True, **kw),
-        "packed x1": lambda: hip.attn_fwd_packed(pk, out, B=B, S=S, H=H, ldo=D, o_bs=S * D, out_split=True, one_term=True),
         "split  x1": lambda: hip.attn_fwd_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], out, ldo=D, o_bs=S * D, out_split=True, one_term=True, **kw),
     }
     res = {n: [] for n in variants}
@@ -39,4 +34,4 @@ for (S, H) in ((2250, 12), (450, 12), (2250, 16)):
             for _ in range(50): fn()
             b.record(); torch.cuda.synchronize()
             res[n].append(a.elapsed_time(b) * 20)
-    print(f"B={B} S={S} H={H}: " + "  ".join(f"{n}: {sorted(v)[len(v)//2]:6.1f} us" + (f" ({fl / sorted(v)[len(v)//2] / 1e6:5.0f} TF/s)" if n != 'pack pass' else "") for n, v in res.items()))
+    print(f"B={B} S={S} H={H}: " + "  ".join(f"{n}: {sorted(v)[len(v)//2]:6.1f} us" + f" ({fl / sorted(v)[len(v)//2] / 1e6:5.0f} TF/s)" for n, v in res.items()))

@@ -2,8 +2,11 @@
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and, on gfx950,
 FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md section HBM), hence the factor 2."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, subprocess, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ladcast_amd.build_id import csrc_sha16  # noqa: E402
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 out = {}
@@ -22,6 +25,13 @@ for name in sorted(set(vals["FETCH_SIZE"]) | set(vals["WRITE_SIZE"])):
     f_kib, w_kib = sum(fs) / len(fs), sum(wsz) / len(wsz)
     out[name] = dict(launches=len(fs), fetch_size_kib_raw=round(f_kib, 1), write_size_kib=round(w_kib, 1),
                      hbm_bytes_per_launch=round((2 * f_kib + w_kib) * 1024))
+# build identity of the tree the passes were run on (run this script in that tree): bench.py flags the copied figures as stale when
+# the kernel sources differ.  `git_head` only where a work tree exists (not on the GPU box).
+try:
+    head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+except OSError:
+    head = None
+out["_build"] = dict(csrc_sha16=csrc_sha16(), git_head=head)
 json.dump(out, open(os.path.join("profiles", "pmc_summary.json"), "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]:
+for k, v in sorted(((k, v) for k, v in out.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]:
     print(f"{k[:44]:44s} launches={v['launches']:5d} fetch_raw={v['fetch_size_kib_raw']/1024:9.2f} MiB write={v['write_size_kib']/1024:9.2f} MiB -> HBM/launch={v['hbm_bytes_per_launch']/1e6:9.2f} MB")
