@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="token-stream GEMM / attention arithmetic: exact fp32 MFMA; split-bf16 (hi*hi+hi*lo+lo*hi, fp32 accumulate; the headline, "
                          "inside the 1e-4 budget); bf16 = ONE bf16 MFMA per product, the mixed-precision mode of BASELINE configs[4] (own tolerance)")
+    ap.add_argument("--no-batched-conditioning", action="store_true", help="A/B aid: evaluate the sample-independent part of the network (context refiner, conditioning "
+                    "embedding, AdaLN modulation vectors) inside every network evaluation as the reference does, instead of once per chunk as one batch over the "
+                    "chunk's noise levels (LaDCastTransformer3DModel.prepare_conditioning)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="after the K timed steps keep stepping until this many seconds of "
                     "back-to-back chunks have run and report that window as `sustained` (clock under sustained load); 0 = skip")
     args = ap.parse_args()
@@ -300,6 +303,7 @@ def main():
     torch.manual_seed(1234)
     model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval().set_gemm_precision(args.precision)
     model.enable_hip_graph(not args.no_graph)
+    model.batch_conditioning = not args.no_batched_conditioning
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     from ladcast_amd.pipelines.distributed import shard_members
     from ladcast_amd.precision import tolerance
@@ -514,6 +518,10 @@ def main():
                 "sampler": args.sampler, "members_per_gpu": m if not strong else None, "ensemble_size": total_members,
                 "members_on_rank": [len(shard_members(total_members, r, world)) for r in range(world)], "lead_steps": lead, "return_seq_len": R, "forwards_per_step": chunks * fwd_per_chunk,
                 "tflop_per_forward_per_member": round((gflops + aflops) / 1e12, 4),
+                "conditioning_path": ("per chunk: the sample-independent part of every forward (context refiner, conditioning embedding, AdaLN modulation GEMV: "
+                                      "0.026 of the 0.979 TFLOP and 17 of the 52 launches of a 375M forward) runs once per chunk as ONE batch over the chunk's "
+                                      f"{args.solver_steps} noise levels, inside the timed region, every chunk; --no-batched-conditioning runs it per evaluation")
+                if model.batch_conditioning else "per network evaluation (as the reference)",
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
             "other_sampler": other_sampler,

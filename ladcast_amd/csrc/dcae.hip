@@ -301,6 +301,8 @@ __global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const 
 
 // RMSNorm over channels of an NHWC row with weight + bias, then optional residual add and activation:
 //   y = act(x * rsqrt(mean(x^2) + eps) * w + b (+ resid))          (models/DCAE.py:259-260,317-322,371-377,729-730)
+// NV4 float4 per lane hold the row: 4 (C <= 1024: the 84-variable autoencoder's widths) or 8 (C <= 2048: configs/DC_AE_ray_1024.yaml)
+template <int NV4>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, const float* __restrict__ resid,
                                                            float* __restrict__ y, float* __restrict__ ys, long long rows, int C,
@@ -310,10 +312,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
   if (row >= rows) return;
   const float* xr = x + row * ldx;
   const int nv4 = C >> 2;
-  float4 v[4];
+  float4 v[NV4];
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV4; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       v[i] = reinterpret_cast<const float4*>(xr)[c];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
   float* yr = y ? y + row * ldy : nullptr;  // fp32 copy: residual stream / input of a depthwise conv
   unsigned char* sr = ys ? reinterpret_cast<unsigned char*>(ys + row * lds) : nullptr;  // split copy: operand rows of the next conv
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV4; ++i) {
     const int c = lane + 64 * i;
     if (c < nv4) {
       const float4 wv = reinterpret_cast<const float4*>(w)[c];
@@ -556,13 +558,17 @@ extern "C" int ldc_rmsnorm_rows_split(const float* x, const float* w, const floa
   if (y == nullptr && ys == nullptr) return LDC_ERR_ARG;
   if (ys && fmt != LDC_FMT_SPLIT && fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
   if (rows <= 0 || C <= 0) return LDC_ERR_ARG;
-  if ((C & 3) || C > 1024 || (ldx & 3) || (y && (ldy & 3)) || (resid && (ldr & 3))) return LDC_ERR_UNSUPPORTED;
+  if ((C & 3) || C > 2048 || (ldx & 3) || (y && (ldy & 3)) || (resid && (ldr & 3))) return LDC_ERR_UNSUPPORTED;
   if (ys && ((lds & 7) || lds < ((C + 7) & ~7) || (reinterpret_cast<uintptr_t>(ys) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(x);
   LDC_CHECK_ALIGN16(w);
   if (y) LDC_CHECK_ALIGN16(y);
-  hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(ldc_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b,
-                     resid, y, ys, rows, C, ldx, ldr, ldy, lds, fmt, eps, act);
+  if (C <= 1024)
+    hipLaunchKernelGGL(rmsnorm_rows_kernel<4>, dim3(ldc_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b,
+                       resid, y, ys, rows, C, ldx, ldr, ldy, lds, fmt, eps, act);
+  else
+    hipLaunchKernelGGL(rmsnorm_rows_kernel<8>, dim3(ldc_cdiv(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b,
+                       resid, y, ys, rows, C, ldx, ldr, ldy, lds, fmt, eps, act);
   return ldc_launch_status();
 }
 

@@ -126,71 +126,173 @@ __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm,
   constexpr int RT = BM / 128;
   const int M = P.d.M;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
-  const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v
+  const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v (wave-uniform)
   const int nl = 4 * (lane >> 4);
-  const float* __restrict__ bias = P.bias ? P.bias + bn * BN + nl : nullptr;
   const float* __restrict__ w = which < 2 ? P.qk_w[which] : nullptr;
   const float* __restrict__ rope = which < 2 ? P.rope_cs : nullptr;
+  // round 3: every load of the tile's epilogue is issued before the arithmetic that needs it (bias and norm weights of the column
+  // panel here, a row tile's eight rotary vectors at its start) instead of one exposed L2 round trip per column tile and pass
+  float4 bv[8], wv[8];
+  if (P.bias) {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = *reinterpret_cast<const float4*>(P.bias + bn * BN + nl + 16 * ct);
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (w) {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) wv[ct] = *reinterpret_cast<const float4*>(w + 16 * ct + nl);
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) wv[ct] = make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  const float qs = which == 0 ? P.qscale : 1.f;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
+    asm volatile("" ::: "memory");  // one row tile's loads at a time
     if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
-    float r = 1.f;
-    if (w) {  // pass 1: sum of squares of the head row (acc + bias, recomputed below: registers, not time, are what is scarce here)
-      float ss = 0.f;
+    float4 tv[8];  // (cos, sin) of this lane's two rotary pairs per column tile: one 16-byte load each
+    if (rope) {
+      const float* __restrict__ cs = rope + static_cast<long long>(P.rope_row0 + m) * 128 + nl;
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
-        f32x4 x = acc[rt * 8 + ct];
-        if (bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ct);
-          x[0] += bv.x; x[1] += bv.y; x[2] += bv.z; x[3] += bv.w;
-        }
-        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-      }
+      for (int ct = 0; ct < 8; ++ct) tv[ct] = *reinterpret_cast<const float4*>(cs + 16 * ct);
+    }
+    float x[8][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const f32x4 av = acc[rt * 8 + ct];
+      x[ct][0] = av[0] + bv[ct].x; x[ct][1] = av[1] + bv[ct].y; x[ct][2] = av[2] + bv[ct].z; x[ct][3] = av[3] + bv[ct].w;
+      ss += x[ct][0] * x[ct][0] + x[ct][1] * x[ct][1] + x[ct][2] * x[ct][2] + x[ct][3] * x[ct][3];
+    }
+    float r = 1.f;
+    if (w) {  // RMSNorm(128, eps) of the head row: the 4 lanes 16 / 32 / 48 further hold the rest of it
       ss = xor32_add(xor16_add(ss));
       r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
     }
     unsigned char* row = reinterpret_cast<unsigned char*>(C + static_cast<long long>(m) * P.d.ldc + bn * BN);
-    const float* __restrict__ cs = rope ? rope + static_cast<long long>(P.rope_row0 + m) * 128 + nl : nullptr;
-    // pass 2, four column tiles at a time (the accumulators of a 256-row tile leave room for little else)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float x[4][4];
+    for (int ct = 0; ct < 8; ++ct) {
+      float x0 = x[ct][0], x1 = x[ct][1], x2 = x[ct][2], x3 = x[ct][3];
+      if (w) {
+        x0 = x0 * r * wv[ct].x; x1 = x1 * r * wv[ct].y; x2 = x2 * r * wv[ct].z; x3 = x3 * r * wv[ct].w;
+      }
+      if (rope) {
+        const float4 t = tv[ct];
+        const float o0 = x0 * t.x + (-x1) * t.y, o1 = x1 * t.x + x0 * t.y;
+        const float o2 = x2 * t.z + (-x3) * t.w, o3 = x3 * t.z + x2 * t.w;
+        x0 = o0; x1 = o1; x2 = o2; x3 = o3;
+      }
+      if (which == 0) { x0 *= qs; x1 *= qs; x2 *= qs; x3 *= qs; }
+      const int n = 16 * ct + nl;
+      float r0, r1, r2, r3;
+      const unsigned hx = ldc_split_pair(x0, x1, r0, r1), hy = ldc_split_pair(x2, x3, r2, r3);
+      const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
+      // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
+      const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+      unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
+                                     : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
+      *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    }
+  }
+}
+
+// Round 3: the ordinary epilogue in a form whose loads do not wait on each other.  The generic routine below decides everything per
+// column tile at run time (bias / gate / residual present, activation, output format, edge columns): 16 (8) times "load -> wait ->
+// compute -> store" behind wave-uniform branches, i.e. 16 exposed L2 round trips per tile - measured 11-14 us per 256-row GELU tile of
+// which the stores are 2.5 us and the activation 4 us (profiles/r03_b_gemm_epilogue_diagnostics.log).  Here the run-time decisions sit
+// OUTSIDE the unrolled loops: the eight bias and gate vectors of the column panel are fetched first, then a row tile's eight residual
+// vectors together, then arithmetic and stores run without a memory wait in between.  ACT and FMT are compile-time; an absent bias /
+// gate / residual is a register of zeros / ones (x * 1 + 0 is exact).  Same value as the generic routine for every element (the
+// gate / residual step is the same fused multiply-add); used for whole 128-column panels with 16-byte-aligned rows (`vec4`).
+template <int BM, int ACT, int FMT>
+__device__ __forceinline__ void tile_epilogue_fast(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
+                                                   int lane) {
+  constexpr int RT = BM / 128;
+  const int M = P.d.M;
+  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
+  const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
+  const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
+  const int n0 = bn * BN + 4 * (lane >> 4);
+  float4 bv[8], gv[8];
+  if (P.bias) {
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int ct = 4 * half + c4;
-        const f32x4 av = acc[rt * 8 + ct];
-        x[c4][0] = av[0]; x[c4][1] = av[1]; x[c4][2] = av[2]; x[c4][3] = av[3];
-        if (bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * ct);
-          x[c4][0] += bv.x; x[c4][1] += bv.y; x[c4][2] += bv.z; x[c4][3] += bv.w;
-        }
-        if (w) {
-          const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + nl);
-          x[c4][0] = x[c4][0] * r * wv.x; x[c4][1] = x[c4][1] * r * wv.y; x[c4][2] = x[c4][2] * r * wv.z; x[c4][3] = x[c4][3] * r * wv.w;
-        }
-        if (cs) {  // (cos, sin) of this lane's two rotary pairs: one 16-byte load
-          const float4 t = *reinterpret_cast<const float4*>(cs + 16 * ct);
-          const float o0 = x[c4][0] * t.x + (-x[c4][1]) * t.y, o1 = x[c4][1] * t.x + x[c4][0] * t.y;
-          const float o2 = x[c4][2] * t.z + (-x[c4][3]) * t.w, o3 = x[c4][3] * t.z + x[c4][2] * t.w;
-          x[c4][0] = o0; x[c4][1] = o1; x[c4][2] = o2; x[c4][3] = o3;
-        }
-        if (which == 0) { x[c4][0] *= P.qscale; x[c4][1] *= P.qscale; x[c4][2] *= P.qscale; x[c4][3] *= P.qscale; }
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = *reinterpret_cast<const float4*>(P.bias + n0 + 16 * ct);
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool mod = gate != nullptr || R != nullptr;  // wave-uniform
+  if (gate) {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) gv[ct] = *reinterpret_cast<const float4*>(gate + n0 + 16 * ct);
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) gv[ct] = make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
+    asm volatile("" ::: "memory");  // one row tile's loads at a time (the second tile's would otherwise be hoisted and spill)
+    if (m >= M) continue;  // the 4 lanes of a row share m: the lane-group swaps below stay among active lanes
+    float* crow = C + static_cast<long long>(m) * P.d.ldc;
+    float4 v[8];
+    if (mod) {
+      float4 rv[8];
+      if (R) {
+        const float* rrow = R + static_cast<long long>(m) * P.d.ldr + n0;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) rv[ct] = *reinterpret_cast<const float4*>(rrow + 16 * ct);
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) rv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int n = 16 * (4 * half + c4) + nl;
-        float r0, r1, r2, r3;
-        const unsigned hx = ldc_split_pair(x[c4][0], x[c4][1], r0, r1), hy = ldc_split_pair(x[c4][2], x[c4][3], r2, r3);
-        const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
-        // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
-        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
-        unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
-                                       : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
-        *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      for (int ct = 0; ct < 8; ++ct) {
+        const f32x4 av = acc[rt * 8 + ct];
+        float4 x = make_float4(ldc_apply_act(av[0] + bv[ct].x, ACT), ldc_apply_act(av[1] + bv[ct].y, ACT), ldc_apply_act(av[2] + bv[ct].z, ACT),
+                               ldc_apply_act(av[3] + bv[ct].w, ACT));
+        v[ct] = make_float4(fmaf(x.x, gv[ct].x, rv[ct].x), fmaf(x.y, gv[ct].y, rv[ct].y), fmaf(x.z, gv[ct].z, rv[ct].z), fmaf(x.w, gv[ct].w, rv[ct].w));
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const f32x4 av = acc[rt * 8 + ct];
+        v[ct] = make_float4(ldc_apply_act(av[0] + bv[ct].x, ACT), ldc_apply_act(av[1] + bv[ct].y, ACT), ldc_apply_act(av[2] + bv[ct].z, ACT),
+                            ldc_apply_act(av[3] + bv[ct].w, ACT));
       }
     }
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const int n = n0 + 16 * ct;
+      if constexpr (FMT == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(crow) + 2 * n) = make_uint2(ldc_pack_pair(v[ct].x, v[ct].y), ldc_pack_pair(v[ct].z, v[ct].w));
+      } else if constexpr (FMT == LDC_FMT_SPLIT) {  // [hi x8 | lo x8] groups: see the generic routine
+        float r0, r1, r2, r3;
+        const unsigned hx = ldc_split_pair(v[ct].x, v[ct].y, r0, r1), hy = ldc_split_pair(v[ct].z, v[ct].w, r2, r3);
+        const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
+        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+        unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
+        *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      } else {
+        *reinterpret_cast<float4*>(crow + n) = v[ct];
+      }
+    }
+  }
+}
+
+template <int BM, int FMT>
+__device__ __forceinline__ void tile_epilogue_fast_act(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
+                                                       int lane) {
+  switch (P.d.act) {  // wave-uniform; one straight-line body per activation
+    case LDC_ACT_SILU: tile_epilogue_fast<BM, LDC_ACT_SILU, FMT>(P, b, bm, bn, acc, wave, lane); break;
+    case LDC_ACT_GELU_TANH: tile_epilogue_fast<BM, LDC_ACT_GELU_TANH, FMT>(P, b, bm, bn, acc, wave, lane); break;
+    case LDC_ACT_RELU: tile_epilogue_fast<BM, LDC_ACT_RELU, FMT>(P, b, bm, bn, acc, wave, lane); break;
+    default: tile_epilogue_fast<BM, LDC_ACT_NONE, FMT>(P, b, bm, bn, acc, wave, lane); break;
   }
 }
 
@@ -205,6 +307,14 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
       return;
     }
   }
+#ifndef LDC_EPI_GENERIC_ONLY  // measurement aid (make ... DIAG=-DLDC_EPI_GENERIC_ONLY): the round-2 epilogue everywhere
+  if (P.vec4 && bn * BN + BN <= P.d.N) {  // a whole column panel, 16-byte accesses
+    if (P.c_split == LDC_FMT_BF16) tile_epilogue_fast_act<BM, LDC_FMT_BF16>(P, b, bm, bn, acc, wave, lane);
+    else if (P.c_split) tile_epilogue_fast_act<BM, LDC_FMT_SPLIT>(P, b, bm, bn, acc, wave, lane);
+    else tile_epilogue_fast_act<BM, LDC_FMT_F32>(P, b, bm, bn, acc, wave, lane);
+    return;
+  }
+#endif
   const int M = P.d.M, N = P.d.N;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -230,9 +340,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         }
-#ifndef LDC_EPI_DIAG_NOACT  // diagnostic builds only (make stamps DIAG=...): what the activation costs
         v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
-#endif
         if (gate && !pad) {
           const float4 gv = *reinterpret_cast<const float4*>(gate + n);
           v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
@@ -255,17 +363,9 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
           const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);  // [0]: even rows keep hi, odd rows get lo(even)
           const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);  // [1]: even rows get hi(odd), odd rows keep lo
           unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
-#ifdef LDC_EPI_DIAG_NOSTORE  // diagnostic builds only: the epilogue without its stores (values kept live)
-          asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]), "v"(grp));
-#else
           *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-#endif
         } else {
-#ifdef LDC_EPI_DIAG_NOSTORE
-          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(crow));
-#else
           *reinterpret_cast<float4*>(crow + n) = v;
-#endif
         }
       } else {
 #pragma unroll
@@ -352,60 +452,51 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
   const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
 
-  // One SEGMENT = the k-steps [k0, k1) of one output tile (a whole tile when the unit ranges are tile-aligned).  Its decoded
-  // coordinates are wave-uniform scalars; `cur` is the segment whose main loop runs, and - round 3 - the NEXT segment is decoded and
-  // its first two ring stages are put in flight BEFORE the current segment's epilogue / hand-off, so that the DMA latency (a cold
-  // weight panel: ~2 us) runs under the epilogue's own loads, arithmetic and stores instead of after them.
-  struct Seg {
-    int pi, tile, k0, k1, b, bm, bn;
-  };
-  auto decode = [&](long long u_) {
-    Seg sg;
-    sg.pi = find_problem_by_unit(a, u_);
-    const DevProblem& P = a.pr[sg.pi];
-    const long long local = u_ - P.unit0;
-    sg.tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
-    sg.k0 = static_cast<int>(local - static_cast<long long>(sg.tile) * P.kt);
-    const long long left = u_end - u_;
-    sg.k1 = (P.kt - sg.k0 <= left) ? P.kt : sg.k0 + static_cast<int>(left);
+  long long u = u_begin;
+  while (u < u_end) {
+    const int pi = find_problem_by_unit(a, u);
+    const DevProblem& P = a.pr[pi];
+    const long long local = u - P.unit0;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
+    const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
+    const long long left = u_end - u;
+    const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
     // tile order (speed only): batch, then super-rows of rm row tiles, then column panels, row tile fastest.  An XCD owns a
     // contiguous run of units, i.e. about rm row panels x (tiles per XCD / rm) column panels: with rm = tm (one super-row)
     // every XCD streams ALL of A and 1/8 of W; a squarer block fetches fewer bytes through the fabric (launch_v3 picks rm)
     const int per_b = P.tm * P.tn;
-    sg.b = sg.tile / per_b;
-    const int t_in = sg.tile - sg.b * per_b;
+    const int b = tile / per_b;
+    const int t_in = tile - b * per_b;
     const int strip = P.rm * P.tn;
     const int sr = t_in / strip;
     const int r_in = t_in - sr * strip;
     const int h_sr = (P.tm - sr * P.rm) < P.rm ? (P.tm - sr * P.rm) : P.rm;
-    sg.bn = r_in / h_sr;
-    sg.bm = sr * P.rm + (r_in - sg.bn * h_sr);
-    return sg;
-  };
-  Seg cur = decode(u_begin);
+    const int bn = r_in / h_sr;
+    const int bm = sr * P.rm + (r_in - bn * h_sr);
+    const int M = P.d.M, N = P.d.N, K = P.d.K;
+    // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
+    // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
+    const bool wave_rows = bm * BM + 16 * RT * wave < M;
+    const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
+    const int lda = P.d.lda;
+    const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
 
-  // per-lane DMA sources of `cur` (k-step 0); rows past the edge are clamped (their outputs are never stored).
-  // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
-  const unsigned char* a_src[NAI];
-  const unsigned char* w_src[2];
-  int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
-  // the 16-byte slot this lane fills is the same for all its A instructions: swz(r) only looks at r & 15 = 8 (wave & 1) + lr
-  const int cslot = lp ^ swz(8 * (wave & 1) + lr);
-  auto conv_tap_base = [&](int i, int tap) {  // CONV: this lane's chunk of the source pixel of tap `tap` (channel chunk 0)
-    const DevProblem& P = a.pr[cur.pi];
-    const int ky = tap / P.ks, kx = tap - ky * P.ks;
-    const int src = pix_b[i] + ldc_sphere_src_pixel(pix_hw[i] >> 16, pix_hw[i] & 0xffff, ky, kx, P.cH, P.cW, P.ks);
-    return reinterpret_cast<const unsigned char*>(P.A + static_cast<long long>(cur.b) * P.d.a_bs + static_cast<long long>(src) * P.d.lda) + (cslot << 4);
-  };
-  auto set_sources = [&]() {
-    const DevProblem& P = a.pr[cur.pi];
-    const int M = P.d.M, N = P.d.N;
-    const float* __restrict__ A = P.A + static_cast<long long>(cur.b) * P.d.a_bs;
-    const long long w_row_bytes = static_cast<long long>(P.d.K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
+    // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
+    // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
+    const unsigned char* a_src[NAI];
+    const unsigned char* w_src[2];
+    int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
+    // the 16-byte slot this lane fills is the same for all its A instructions: swz(r) only looks at r & 15 = 8 (wave & 1) + lr
+    const int cslot = lp ^ swz(8 * (wave & 1) + lr);
+    auto conv_tap_base = [&](int i, int tap) {  // CONV: this lane's chunk of the source pixel of tap `tap` (channel chunk 0)
+      const int ky = tap / P.ks, kx = tap - ky * P.ks;
+      const int src = pix_b[i] + ldc_sphere_src_pixel(pix_hw[i] >> 16, pix_hw[i] & 0xffff, ky, kx, P.cH, P.cW, P.ks);
+      return reinterpret_cast<const unsigned char*>(A + static_cast<long long>(src) * lda) + (cslot << 4);
+    };
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
       const int r = 8 * (wave + 8 * i) + lr;
-      int gm = cur.bm * BM + r;
+      int gm = bm * BM + r;
       gm = gm < M ? gm : M - 1;
       if constexpr (CONV) {
         const int hw = P.cH * P.cW;
@@ -414,71 +505,50 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
         const int h = rem / P.cW;
         pix_b[i] = bimg * hw;
         pix_hw[i] = (h << 16) | (rem - h * P.cW);
-        a_src[i] = conv_tap_base(i, cur.k0 >> P.kshift);
+        a_src[i] = conv_tap_base(i, k0 >> P.kshift);
       } else {
-        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * P.d.lda) + ((lp ^ swz(r)) << 4);
+        a_src[i] = reinterpret_cast<const unsigned char*>(A + static_cast<long long>(gm) * lda) + ((lp ^ swz(r)) << 4);
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 8 * (wave + 8 * i) + lr;
-      int gn = cur.bn * BN + r;
+      int gn = bn * BN + r;
       gn = gn < N ? gn : N - 1;
       w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
     }
-  };
-  // k-steps past the end of the segment are clamped to its last one and land in a per-wave dump slot behind the ring:
-  // the loop body then has no branch around a DMA, every vmcnt is static, and nothing stale can land in the ring after the segment
-  auto issue_one = [&](int kt_, int stage, int i) {
-    const int k1 = cur.k1;
-    const bool live = kt_ < k1;
-    unsigned char* sA = smem + stage * STAGE_B;
-    unsigned char* sW = sA + BM * ROW_B;
-    unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
-    const int kt = live ? kt_ : k1 - 1;
-    const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
+    // k-steps past the end of the segment are clamped to its last one and land in a per-wave dump slot behind the ring:
+    // the loop body then has no branch around a DMA, every vmcnt is static, and nothing stale can land in the ring (or
+    // on the hand-off flag word in it) after the segment
+    auto issue_one = [&](int kt_, int stage, int i) {
+      const bool live = kt_ < k1;
+      unsigned char* sA = smem + stage * STAGE_B;
+      unsigned char* sW = sA + BM * ROW_B;
+      unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
+      const int kt = live ? kt_ : k1 - 1;
+      const long long koff = static_cast<long long>(kt) * (BK * 4);  // 128 B per k-step in both operands
 #ifdef LDC_GEMM_DIAG_NODMA  // diagnostic build: no operand traffic at all (results are garbage)
-    if (kt >= 0) return;
+      if (kt >= 0) return;
 #endif
-    if (i < NAI) {
-      if constexpr (CONV) {
-        const DevProblem& P = a.pr[cur.pi];
-        // piece i is issued once per k-step in increasing kt (clamped repeats of the last one included), so its base is
-        // recomputed exactly when a tap starts
-        const int chunk = kt & ((1 << P.kshift) - 1);
-        if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
-        const unsigned char* src = a_src[i] + chunk * (BK * 4);
-        if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
-          // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
-          if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
+      if (i < NAI) {
+        if constexpr (CONV) {
+          // piece i is issued once per k-step in increasing kt (clamped repeats of the last one included), so its base is
+          // recomputed exactly when a tap starts
+          const int chunk = kt & ((1 << P.kshift) - 1);
+          if (chunk == 0) a_src[i] = conv_tap_base(i, kt >> P.kshift);
+          const unsigned char* src = a_src[i] + chunk * (BK * 4);
+          if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
+            // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
+            if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
+          }
+          dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
+        } else {
+          dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
         }
-        dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
       } else {
-        dma16(a_src[i] + koff, live ? sA + (wave + 8 * i) * 1024 : dump);
+        dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
       }
-    } else {
-      dma16(w_src[i - NAI] + koff, live ? sW + (wave + 8 * (i - NAI)) * 1024 : dump);
-    }
-  };
-  // the first two ring stages of `cur` (k-steps k0 and k0 + 1)
-  auto issue_prologue = [&]() {
-#pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(cur.k0, 0, i);
-#pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(cur.k0 + 1, 1, i);
-  };
-  set_sources();
-  issue_prologue();
-
-  long long u = u_begin;
-  bool first_seg = true;
-  while (true) {
-    const DevProblem& P = a.pr[cur.pi];
-    const int tile = cur.tile, k0 = cur.k0, k1 = cur.k1, b = cur.b, bm = cur.bm, bn = cur.bn;
-    const int M = P.d.M;
-    // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
-    // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
-    const bool wave_rows = bm * BM + 16 * RT * wave < M;
+    };
 
     f32x4 acc[NACC];
 #pragma unroll
@@ -607,18 +677,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     sb = sb1;                                                                                                \
   }
 
-    // prologue: k-steps k0 and k0+1 are in flight (issued at kernel entry / before the previous segment's epilogue); fragments of
-    // k0 (A, W column tiles 0-3) loading.  First segment: only the 2 ND prologue DMAs are outstanding -> stage 0 has landed at
-    // vmcnt(ND).  Later segments: the previous epilogue's loads and stores were issued AFTER the DMAs, so everything is drained
-    // (the first in-loop wait would force the same: the vector-memory counter retires in issue order).
-    if (first_seg) {
-      if constexpr (ND == 6) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      }
+    // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
+#pragma unroll
+    for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+    if constexpr (ND == 6) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     LDC_STAMP(1 + 4 * seg_)
@@ -656,20 +723,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     if (seg_ == 0) { LDC_STAMP_CLK(14) }
     LDC_STAMP(2 + 4 * seg_)
 
-    // ---- the ring is free (barrier above): put the next segment's first two stages in flight under this segment's epilogue ----
-    const long long u_next = u + (k1 - k0);
-    const bool has_next = u_next < u_end;
-    const int g_kt = P.kt;
-    const long long p_unit0 = P.unit0, p_tile0 = P.tile0;
-    const int old_pi = cur.pi;
-    if (has_next) {
-      cur = decode(u_next);
-      set_sources();
-      issue_prologue();
-    }
-    const DevProblem& PO = a.pr[old_pi];
-    if (k0 == 0 && k1 == g_kt) {
-      tile_epilogue<BM, !CONV>(PO, b, bm, bn, acc, wave, lane);
+    if (k0 == 0 && k1 == P.kt) {
+      tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
@@ -681,16 +736,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
           __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64 + lane, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const long long f = p_unit0 + static_cast<long long>(tile) * g_kt;
-      const long long l = f + g_kt;
+      const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;
+      const long long l = f + P.kt;
       long long g_first = g;
       while (g_first > 0 && range_start(g_first, a.U, a.G) > f) --g_first;
       long long g_last = g;
       while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
       const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
-      unsigned* cnt = a.counters + (p_tile0 + tile);
-      // the hand-off flag: an LDS word of its own behind the ring and the dump slots (the ring is receiving the next segment)
-      unsigned* flag = reinterpret_cast<unsigned*>(smem + NSTAGE * STAGE_B + 8 * 1024);
+      unsigned* cnt = a.counters + (P.tile0 + tile);
+      unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
       if (tid == 0) {
         const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
@@ -704,7 +758,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       __syncthreads();
       LDC_STAMP(3 + 4 * seg_)
       const unsigned is_last = *flag;
-      __syncthreads();  // everyone has read the flag before a later hand-off of this workgroup rewrites it
+      __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
       if (is_last) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -717,16 +771,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane];
           }
         }
-        tile_epilogue<BM, !CONV>(PO, b, bm, bn, acc, wave, lane);
+        tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
       }
     }
+    u += k1 - k0;
     LDC_STAMP(4 + 4 * seg_)
 #ifdef LDC_GEMM_STAMPS
     if (seg_ < 2) ++seg_;
 #endif
-    if (!has_next) break;
-    u = u_next;
-    first_seg = false;
   }
   LDC_STAMP(15)
 }
@@ -894,7 +946,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
-  const size_t lds = NSTAGE * STAGE_B + 8 * 1024 + 16;  // ring + one 1 KiB dump slot per wave + the hand-off flag word
+  const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_v3_kernel<BM, TERMS, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

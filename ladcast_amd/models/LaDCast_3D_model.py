@@ -592,7 +592,11 @@ class LaDCastTransformer3DModel(ModelMixin):
         attention_kwargs=None,
         return_dict: bool = True,
         coords=None,
+        conditioning=None,
     ):
+        """`conditioning` (extension, used by this package's samplers): `(pack, index)` from `prepare_conditioning` - the sample-independent
+        part of the forward, evaluated for all noise levels of a sampler chunk in one batch; `timestep` / `conditioning_tensors` /
+        `time_elapsed` must be the ones the pack was prepared from (entry `index`).  Without it the call computes that part itself."""
         if self._plan is None:
             self._build_plan()
         plan = self._plan
@@ -620,6 +624,12 @@ class LaDCastTransformer3DModel(ModelMixin):
             if te.shape[0] not in (1, B):
                 raise ValueError("time_elapsed must have 1 or batch entries")
 
+        if conditioning is not None:  # the sampler prepared the conditioning path for the whole chunk: only the sample-dependent part
+            pack, idx = conditioning
+            if tuple(pack.shape) != (B,) + tuple(conditioning_tensors.shape[1:]) or not 0 <= idx < pack.levels:
+                raise ValueError("`conditioning` was prepared for another batch / conditioning shape")
+            out = self._main_device(hidden_states, pack, idx)
+            return (out,) if not return_dict else SimpleNamespace(sample=out)
         if self.use_hip_graph:
             gkey = (B, Bt, C_in, R, T_in, Hh, Ww, None if te is None else (te.data_ptr(), te.shape[0]))
             ent = self._graphs.get(gkey)
@@ -675,38 +685,81 @@ class LaDCastTransformer3DModel(ModelMixin):
         return self._capture_stream
 
     @torch.no_grad()
-    def forward_launch_only(self, hidden_states, timestep, conditioning_tensors, te):
+    def forward_launch_only(self, hidden_states, timestep, conditioning_tensors, te, conditioning=None):
         """`forward` without host work: fp32 device tensors in their final shapes, `te` from `time_elapsed_embedding`;
-        only kernel launches on the current stream (capturable).  Returns the sample tensor."""
+        only kernel launches on the current stream (capturable).  Returns the sample tensor.  `conditioning = (pack, index)`:
+        as in `forward`."""
         if self._plan is None:
             self._build_plan()
+        if conditioning is not None:
+            return self._main_device(hidden_states, conditioning[0], conditioning[1])
         return self._forward_device(hidden_states, timestep.reshape(-1), conditioning_tensors, te)
 
+    # sampler chunks evaluate the conditioning path for all their noise levels at once unless this is switched off (A/B measurements,
+    # `bench.py --no-batched-conditioning`); results agree to fp32 rounding (another stream-K cut of the same sums), not bit for bit
+    batch_conditioning = True
+    COND_MAX_ROWS = 96  # (noise level, member) entries per conditioning pass: bounds its workspace (30 MB per entry at 375M)
+
+    @torch.no_grad()
+    def prepare_conditioning(self, timesteps, conditioning_tensors, te=None):
+        """The sample-independent part of the forward (`_conditioning_device`: context embed, token refiner, `temb`, all AdaLN modulation
+        vectors; models/LaDCast_3D_model.py:942-969) for EVERY noise level of a sampler chunk in one batch.  timesteps: (N,) the values
+        the model will be called with (`c_noise` of the EDM sampler, `scheduler.timesteps` of the pipeline loop); conditioning_tensors:
+        (B, C, T_in, h, w) fp32 device tensor; te: `time_elapsed_embedding(timestamps)`.  Launches only (capturable).  Returns the pack to
+        hand to `forward(..., conditioning=(pack, i))` for noise level i; it lives in workspaces of the model and is valid until the
+        next `prepare_conditioning` of the same shape."""
+        if self._plan is None:
+            self._build_plan()
+        dev = self.device
+        timesteps = timesteps.to(device=dev, dtype=torch.float32).reshape(-1)
+        N, B = timesteps.shape[0], conditioning_tensors.shape[0]
+        shape = tuple(conditioning_tensors.shape)
+        per = max(1, self.COND_MAX_ROWS // B)  # noise levels per pass
+        if per >= N:
+            pk = self._conditioning_device(timesteps.repeat_interleave(B).contiguous(),
+                                           conditioning_tensors.unsqueeze(0).expand(N, *shape).reshape(N * B, *shape[1:]).contiguous(), te)
+            return SimpleNamespace(ctx=pk.ctx, mods=pk.mods, shape=shape, levels=N)
+        Nc, D, NM = shape[2] * shape[3] * shape[4], self.inner_dim, self._plan.mod_w.shape[0]
+        key = ("pack", N, B, Nc)
+        if key not in self._ws:
+            self._ws[key] = (torch.empty(N * B, Nc, D, device=dev, dtype=torch.float32), torch.empty(N * B, NM, device=dev, dtype=torch.float32))
+        ctx, mods = self._ws[key]
+        for n0 in range(0, N, per):
+            n = min(per, N - n0)
+            pk = self._conditioning_device(timesteps[n0 : n0 + n].repeat_interleave(B).contiguous(),
+                                           conditioning_tensors.unsqueeze(0).expand(n, *shape).reshape(n * B, *shape[1:]).contiguous(), te)
+            ctx[n0 * B : (n0 + n) * B].copy_(pk.ctx)
+            mods[n0 * B : (n0 + n) * B].copy_(pk.mods)
+        return SimpleNamespace(ctx=ctx, mods=mods, shape=shape, levels=N)
+
     def _forward_device(self, hidden_states, timestep, conditioning_tensors, te):
-        """Kernel launches only (no host sync, no shape-dependent Python state): capturable into a hipGraph."""
+        """one forward = its conditioning path (batch = the call's members) + the sample-dependent part"""
+        pack = self._conditioning_device(timestep, conditioning_tensors, te)
+        return self._main_device(hidden_states, SimpleNamespace(ctx=pack.ctx, mods=pack.mods, shape=tuple(conditioning_tensors.shape), levels=1), 0)
+
+    def _conditioning_device(self, timestep, conditioning_tensors, te):
+        """The part of the forward that does NOT see the sample: context patch embed, token refiner, conditioning embedding `temb`
+        (+ time-elapsed modulation) and every temb-driven AdaLN modulation vector (models/LaDCast_3D_model.py:942-969).  It depends on
+        (timestep, conditioning, timestamp) only, so a sampler evaluates it ONCE PER CHUNK for all its noise levels as one batch
+        (`prepare_conditioning`) instead of once per network evaluation: the batch index is (noise level, member), the refiner's GEMMs
+        see 20 x 450 rows instead of 450, and the 358 MB AdaLN matrix is streamed once per chunk instead of 39 times.  Kernel
+        launches only (capturable).  Returns the pack: refined context `ctx` (Bc, Nc, D) and `mods` (Bc, NM) in a workspace of its own."""
         plan = self._plan
         dev = self.device
         cfg = self.config
         D, H = self.inner_dim, cfg.num_attention_heads
-        B, C_in, R, Hh, Ww = hidden_states.shape
-        T_in = conditioning_tensors.shape[2]
-        Cc = conditioning_tensors.shape[1]
-        Nx, Nc = R * Hh * Ww, T_in * Hh * Ww
-        S = Nx + Nc
-        C_out = cfg.out_channels or cfg.in_channels
+        B, Cc, T_in, Hh, Ww = conditioning_tensors.shape
+        Nx, Nc = 0, T_in * Hh * Ww
+        S = Nc
         Bt = timestep.shape[0]
-
         kpad = max(plan.kx_pad, plan.kc_pad)  # differs between precision modes (k-step of the operand format)
-        key = (B, Bt, Nx, Nc, kpad)
+        key = ("cond", B, Bt, Nc, kpad)
         if key not in self._ws:
-            self._ws[key] = _Workspace(dev, B, Bt, Nx, Nc, D, kpad, C_out, plan.mod_w.shape[0])
+            self._ws[key] = _Workspace(dev, B, Bt, 0, Nc, D, kpad, 4, plan.mod_w.shape[0])
         ws = self._ws[key]
-        pc, ps, cc, cs, pk, ck, jk = self._rope_tables(R, T_in, Hh, Ww, dev)
+        _, _, cc, cs, _, ck, _ = self._rope_tables(1, T_in, Hh, Ww, dev)  # the conditioning stream's tables do not depend on R
         SD = S * D
-        h_x, h_c = ws.h[:, :Nx], ws.h[:, Nx:]
-        nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
-
-        # 1. patch embeds (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
+        h_c, nh_c = ws.h, ws.nh
         split = plan.split
         packed = plan.packed
 
@@ -735,33 +788,28 @@ class LaDCastTransformer3DModel(ModelMixin):
             else:
                 hip.gemm_grouped(problems, split_bf16=split)
 
+        # 1b. context patch embed (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
         if split:
-            KX, KC = plan.kx_pad, plan.kc_pad
-            xtok, ctok = ws.xtok.view(-1)[: B * Nx * KX].view(B, Nx, KX), ws.ctok.view(-1)[: B * Nc * KC].view(B, Nc, KC)
+            KC = plan.kc_pad
+            ctok = ws.ctok.view(-1)[: B * Nc * KC].view(B, Nc, KC)
             # token rows are written in the split format by the transpose itself -> the pre-split GEMM kernel
-            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX, out_split=fmt)
             hip.chan_to_token(conditioning_tensors, ctok, B=B, C=Cc, N=Nc, ldo=KC, fill_cols=KC, out_split=fmt)
-            run([
-                G(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias, flags=AS),
-                G(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias, flags=AS),
-            ])
+            run1(ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=KC, batch=B, a_bs=Nc * KC, c_bs=Nc * D, bias=self.context_embedder.proj.bias, flags=AS)
         else:
-            hip.chan_to_token(hidden_states, ws.xtok.view(-1)[: B * Nx * C_in].view(B, Nx, C_in), B=B, C=C_in, N=Nx, ldo=C_in)
             hip.chan_to_token(conditioning_tensors, ws.ctok.view(-1)[: B * Nc * Cc].view(B, Nc, Cc), B=B, C=Cc, N=Nc, ldo=Cc)
             # K = 84: exact-fp32 tile-per-workgroup kernel (3 k-steps: nothing for stream-K to balance)
-            hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
             hip.gemm(ws.ctok, plan.wc, ws.ctx0, M=Nc, N=D, K=Cc, batch=B, a_bs=Nc * Cc, c_bs=Nc * D, bias=self.context_embedder.proj.bias)
 
         # scale_attn_by_lat: per-key score bias, the same weights tiled over the frames of the keys (:873-880); key order inside a frame is
         # the token order, and the mask does not depend on the frame, so pred-then-cond (ours) and the reference's tiling agree
-        kb_all = kb_cond = None
+        kb_cond = None
         if self.scale_attn_by_lat:
             if Hh * Ww != self.attn_lat_weights.numel():
                 raise ValueError("scale_attn_by_lat is hard-wired to the 15 x 30 latent grid (models/LaDCast_3D_model.py:684-692)")
-            kb_all, kb_cond = self._key_bias(R + T_in, dev), self._key_bias(T_in, dev)
+            kb_cond = self._key_bias(T_in, dev)
         # user-supplied attention processors (set_attn_processor): called on torch views of the fp32 buffers, eager launches only
         foreign = bool(self._foreign_processors())
-        m_all = m_cond = None
+        m_cond = None
         if foreign:
             if split:
                 raise NotImplementedError("a user-supplied attention processor runs on the fp32 path: call set_gemm_precision('fp32') "
@@ -770,7 +818,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 raise NotImplementedError("a user-supplied attention processor cannot be captured into a hipGraph")
             if self.scale_attn_by_lat:  # the reference's (1, 1, 1, keys) float mask (:873-880)
                 w = self.attn_lat_weights.to(dev)
-                m_all, m_cond = w.repeat(1, 1, 1, T_in + R), w.repeat(1, 1, 1, T_in)
+                m_cond = w.repeat(1, 1, 1, T_in)
 
         # 2. context refiner, models/LaDCast_3D_model.py:375-390,280-302
         ref = self.context_refiner
@@ -788,14 +836,14 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.layernorm_mod(h_c, nh_c, B=B, rows=Nc, D=D, ldx=D, x_bs=SD, ldy=D, y_bs=SD, scale=blk.norm1.weight, shift=blk.norm1.bias, mode=1, eps=blk.norm1.eps, out_split=fmt)
             if blk.attn.foreign_processor is not None:  # :280-286
                 a, _ = self._call_processor(blk.attn, nh_c, None, m_cond, (cc, cs), None)
-                ws.att[:, Nx:].copy_(a)
+                ws.att.copy_(a)
             else:
-                run_qkv([G(nh_c, pa.wqkv, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
+                run_qkv([G(nh_c, pa.wqkv, ws.qkv, M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
                         [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
-                self._attention(ws, B, Nx, Nc, 0, ws.att[:, Nx:], D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
+                self._attention(ws, B, Nx, Nc, 0, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
-            hip.gate_residual_layernorm(h_c, ws.att[:, Nx:], ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
+            hip.gate_residual_layernorm(h_c, ws.att, ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
                                         ld_out=D, out_bs=SD, weight=blk.norm2.weight, bias=blk.norm2.bias, eps=blk.norm2.eps, out_split=fmt)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
             F = f0.weight.shape[0]
@@ -809,9 +857,96 @@ class LaDCastTransformer3DModel(ModelMixin):
         NM = plan.mod_w.shape[0]
         hip.linear_small(ws.temb, plan.mod_w, ws.mods, rows=B, N=NM, K=D, bias=plan.mod_b, act_in=hip.ACT_SILU)
 
+        return SimpleNamespace(ctx=ws.h, mods=ws.mods, rows=B, shape=(B, Cc, T_in, Hh, Ww))
+
+    def _main_device(self, hidden_states, pack, idx):
+        """The sample-dependent part of the forward: sample patch embed, dual-stream and single-stream blocks, output head.  `pack` =
+        `_conditioning_device`'s result for a batch of (noise level, member) entries, `idx` = this call's noise level: rows
+        [idx * B, (idx + 1) * B) of the pack.  Kernel launches only (no host sync, no shape-dependent Python state): capturable."""
+        plan = self._plan
+        dev = self.device
+        cfg = self.config
+        D, H = self.inner_dim, cfg.num_attention_heads
+        B, C_in, R, Hh, Ww = hidden_states.shape
+        _, Cc, T_in, _, _ = pack.shape
+        Nx, Nc = R * Hh * Ww, T_in * Hh * Ww
+        S = Nx + Nc
+        C_out = cfg.out_channels or cfg.in_channels
+        kpad = max(plan.kx_pad, plan.kc_pad)  # differs between precision modes (k-step of the operand format)
+        key = (B, Nx, Nc, kpad)
+        if key not in self._ws:
+            self._ws[key] = _Workspace(dev, B, 1, Nx, Nc, D, kpad, C_out, 4)
+        ws = self._ws[key]
+        pc, ps, cc, cs, pk, ck, jk = self._rope_tables(R, T_in, Hh, Ww, dev)
+        SD = S * D
+        h_x, h_c = ws.h[:, :Nx], ws.h[:, Nx:]
+        nh_x, nh_c = ws.nh[:, :Nx], ws.nh[:, Nx:]
+        NM = plan.mod_w.shape[0]
+        mods = pack.mods[idx * B : (idx + 1) * B]
+        split = plan.split
+        packed = plan.packed
+
+        # split-bf16 mode: activations that only feed GEMMs (LayerNorm outputs, attention outputs, MLP hidden states)
+        # are written ONCE in the split format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT / _C_SPLIT); the
+        # buffers, strides and column offsets are the same as in fp32 mode
+        AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
+        CS = hip.GEMM_C_SPLIT if split else 0
+        # what the producers of GEMM operands write: fp32, split-bf16 groups (bf16x3), plain bf16 rows (bf16: a row's K values in the
+        # first 2 K bytes of its fp32 row - same buffers and strides; only COLUMN offsets differ, 2 bytes per column instead of 4)
+        fmt = hip.FMT_BF16 if plan.one_term else hip.FMT_SPLIT if split else hip.FMT_F32
+
+        def G(A, W, C, **kw):  # weight in the format of the active precision mode
+            return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
+
+        def run(problems):
+            hip.gemm_grouped(problems, split_bf16=split)
+
+        def run1(A, W, C, **kw):
+            hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
+
+        def run_qkv(problems, epis):
+            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
+            if split:
+                hip.gemm_grouped_qkv(problems, epis)
+            else:
+                hip.gemm_grouped(problems, split_bf16=split)
+
+        # 1a. sample patch embed (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59; the refined context of this noise level
+        # becomes the conditioning rows of the joint token buffer (the dual blocks update them in place)
+        if split:
+            KX = plan.kx_pad
+            xtok = ws.xtok.view(-1)[: B * Nx * KX].view(B, Nx, KX)
+            hip.chan_to_token(hidden_states, xtok, B=B, C=C_in, N=Nx, ldo=KX, fill_cols=KX, out_split=fmt)
+            run1(xtok, plan.wx, h_x, M=Nx, N=D, K=KX, batch=B, a_bs=Nx * KX, c_bs=SD, bias=self.x_embedder.proj.bias, flags=AS)
+        else:
+            hip.chan_to_token(hidden_states, ws.xtok.view(-1)[: B * Nx * C_in].view(B, Nx, C_in), B=B, C=C_in, N=Nx, ldo=C_in)
+            hip.gemm(ws.xtok, plan.wx, h_x, M=Nx, N=D, K=C_in, batch=B, a_bs=Nx * C_in, c_bs=SD, bias=self.x_embedder.proj.bias)
+        h_c.copy_(pack.ctx[idx * B : (idx + 1) * B])
+
+        # scale_attn_by_lat: per-key score bias, the same weights tiled over the frames of the keys (:873-880); key order inside a frame is
+        # the token order, and the mask does not depend on the frame, so pred-then-cond (ours) and the reference's tiling agree
+        kb_all = None
+        if self.scale_attn_by_lat:
+            if Hh * Ww != self.attn_lat_weights.numel():
+                raise ValueError("scale_attn_by_lat is hard-wired to the 15 x 30 latent grid (models/LaDCast_3D_model.py:684-692)")
+            kb_all = self._key_bias(R + T_in, dev)
+        # user-supplied attention processors (set_attn_processor): called on torch views of the fp32 buffers, eager launches only
+        foreign = bool(self._foreign_processors())
+        m_all = None
+        if foreign:
+            if split:
+                raise NotImplementedError("a user-supplied attention processor runs on the fp32 path: call set_gemm_precision('fp32') "
+                                          "(or change the attention arithmetic through the C ABI, include/ladcast_hip.h)")
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("a user-supplied attention processor cannot be captured into a hipGraph")
+            if self.scale_attn_by_lat:  # the reference's (1, 1, 1, keys) float mask (:873-880)
+                w = self.attn_lat_weights.to(dev)
+                m_all = w.repeat(1, 1, 1, T_in + R)
+
+
         def mod_of(linear, width):
             o = plan.mod_off[id(linear)]
-            return ws.mods[:, o : o + width]
+            return mods[:, o : o + width]
 
         # 4. dual-stream blocks, models/LaDCast_3D_model.py:514-566
         for blk in self.transformer_blocks:

@@ -61,6 +61,11 @@ def edm_AR_sampler(
     # copies around 39 per-forward graphs (2.5 % of the chunk), and the host's speed stops mattering (8 ranks on one box).
     # Used when the model runs in hipGraph mode and exposes its launch-only forward; same kernels, same numbers.
     chunk_graph = bool(getattr(net, "use_hip_graph", False)) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs")
+    # The part of the network that does not see the sample (context refiner, conditioning embedding, AdaLN modulation vectors) depends
+    # on (noise level, conditioning, timestamp) only: a model that offers `prepare_conditioning` evaluates it for the chunk's N noise
+    # levels as ONE batch at the start of the chunk, every chunk; each of the 2N - 1 network evaluations then runs the sample-dependent
+    # part only (same arithmetic per entry; the Heun correction at t_next and the next Euler step at t_cur = t_next share an entry).
+    batched = bool(getattr(net, "batch_conditioning", False)) and hasattr(net, "prepare_conditioning")
     if not deterministic:
         # stochastic churn (:67-76; never enabled by the reference's own rollout driver, pipelines/utils.py:716-727): the noise comes
         # from the caller's `randn_like` at every step, so the chunk is launched eagerly - nothing to capture once and replay
@@ -73,7 +78,8 @@ def edm_AR_sampler(
         te = net.time_elapsed_embedding(timestamps)  # eager, cached per chunk; the graph reads its persistent buffer
         plan_id = net.plan_identity()  # a re-packed / re-loaded model gets new graphs
         key = (tuple(shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in t_steps.tolist()),
-               None if te is None else (te.data_ptr(), tuple(te.shape)), str(device), plan_id)
+               None if te is None else (te.data_ptr(), tuple(te.shape)), str(device), plan_id, batched)
+        prepare = net.prepare_conditioning if batched else None
         key = ("edm_chunk",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
@@ -85,11 +91,11 @@ def edm_AR_sampler(
             side = net.capture_stream() if hasattr(net, "capture_stream") else torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):  # warm-up on the capture stream: per-stream workspaces are created here
-                _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps)
+                _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps, prepare)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime
-                _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps)
+                _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps, prepare)
             ent = (graph, st_lat, st_known, st_out, cn, side)
             cache[key] = ent
         graph, st_lat, st_known, st_out = ent[:4]
@@ -99,13 +105,20 @@ def edm_AR_sampler(
         return st_out.clone()
 
     out = torch.empty(shape, device=device, dtype=torch.float32)
-    fwd = lambda x, t, k, te_: net(x, t, k, time_elapsed=timestamps).sample  # noqa: E731
-    _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, None, out, shape, device, num_inference_steps)
+    fwd = lambda x, t, k, te_, ci=None: net(x, t, k, time_elapsed=timestamps, **({} if ci is None else {"conditioning": ci})).sample  # noqa: E731
+    prepare = None
+    if batched:
+        te = net.time_elapsed_embedding(timestamps)
+        prepare = lambda cn, kn, te_: net.prepare_conditioning(cn, kn, te)  # noqa: E731
+    _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, None, out, shape, device, num_inference_steps, prepare)
     return out
 
 
-def _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, te, out, shape, device, num_inference_steps):
-    """the 2N-1 evaluations of pipelines/edm_sampler.py:60-113 as launches only: fwd(x, timestep, known, te) -> F"""
+def _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, te, out, shape, device, num_inference_steps, prepare=None):
+    """the 2N-1 evaluations of pipelines/edm_sampler.py:60-113 as launches only: fwd(x, timestep, known, te, conditioning) -> F;
+    prepare(c_noise, known, te) -> the model's conditioning pack for the N noise levels (or None: every evaluation computes its own)"""
+    cond = prepare(c_noise, known, te) if prepare is not None else None
+    ci = (lambda i: None) if cond is None else (lambda i: (cond, i))  # noqa: E731
     x_hat = torch.empty(shape, device=device, dtype=torch.float64)
     x_next = torch.empty_like(x_hat)
     d_cur = torch.empty_like(x_hat)
@@ -117,12 +130,12 @@ def _heun_chunk(fwd, noise_scheduler, t_steps, c_noise, latents, known, te, out,
         x_hat, x_next = x_next, x_hat  # x_hat = previous x_next
         c_skip, c_out = noise_scheduler._c_skip_out(t_cur)
         hip.edm_scale_f64_to_f32(x_hat, float(noise_scheduler._c_in(t_cur)), x_in)
-        F = fwd(x_in, c_noise[i : i + 1], known, te)
+        F = fwd(x_in, c_noise[i : i + 1], known, te, ci(i))
         hip.edm_euler(x_hat, F, float(c_skip), float(c_out), float(t_cur), float(t_next - t_cur), x_next, d_cur)
         if i < num_inference_steps - 1:
             c_skip, c_out = noise_scheduler._c_skip_out(t_next)
             hip.edm_scale_f64_to_f32(x_next, float(noise_scheduler._c_in(t_next)), x_in)
-            F = fwd(x_in, c_noise[i + 1 : i + 2], known, te)
+            F = fwd(x_in, c_noise[i + 1 : i + 2], known, te, ci(i + 1))
             hip.edm_heun(x_hat, x_next, F, d_cur, float(c_skip), float(c_out), float(t_next), float(t_next - t_cur))
     hip.f64_to_f32(x_next, out)
 

@@ -70,12 +70,19 @@ class AutoRegressive2DPipeline:
                 return (image,)
             return Fields2DPipelineOutput(fields=image)
         self.scheduler.set_timesteps(num_inference_steps)
-        for t in self.scheduler.timesteps:
+        # the sample-independent part of the network for all timesteps of the loop in one batch (ladcast_amd models only; see
+        # LaDCastTransformer3DModel.prepare_conditioning and pipelines/edm_sampler.py)
+        pack = None
+        if getattr(net, "batch_conditioning", False) and hasattr(net, "prepare_conditioning"):
+            kn = known_latents if known_latents.shape[0] == batch_size else known_latents.expand(batch_size, *known_latents.shape[1:])
+            pack = net.prepare_conditioning(self.scheduler.timesteps, kn.contiguous(), net.time_elapsed_embedding(timestamps))
+        for i, t in enumerate(self.scheduler.timesteps):
             if not do_edm_style:
                 raise NotImplementedError("Only EDM style is supported for now")
             x_in = self.scheduler.scale_model_input(image, t)
             t = t.expand(batch_size).to(dev)
-            model_output = self.ar_model(x_in, t, known_latents, time_elapsed=timestamps, return_dict=False)[0]
+            ckw = {} if pack is None else {"conditioning": (pack, i)}
+            model_output = self.ar_model(x_in, t, known_latents, time_elapsed=timestamps, return_dict=False, **ckw)[0]
             image = self.scheduler.step(model_output, t, image, **self.scheduler_step_kwargs, return_dict=False)[0]
         if not return_dict:
             return (image,)
@@ -91,15 +98,18 @@ class AutoRegressive2DPipeline:
         c = sch.config
         key = (tuple(image.shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in sch.sigmas.tolist()),
                (c.solver_order, c.prediction_type, c.final_sigmas_type, c.euler_at_final, c.lower_order_final, c.sigma_data),
-               tuple(sorted(self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity())
+               tuple(sorted(self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity(),
+               bool(getattr(net, "batch_conditioning", False)))
         key = ("pipeline_loop",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
 
         def loop(img, kn, tsteps):
-            for t, t_dev in zip(sch.timesteps, tsteps):
+            kb = kn if kn.shape[0] == batch_size else kn.expand(batch_size, *kn.shape[1:]).contiguous()
+            pack = net.prepare_conditioning(sch.timesteps, kb, te) if getattr(net, "batch_conditioning", False) else None
+            for i, (t, t_dev) in enumerate(zip(sch.timesteps, tsteps)):
                 x_in = sch.scale_model_input(img, t)
-                out = net.forward_launch_only(x_in, t_dev, kn, te)
+                out = net.forward_launch_only(x_in, t_dev, kb, te, None if pack is None else (pack, i))
                 img = sch.step(out, t, img, **self.scheduler_step_kwargs, return_dict=False)[0]
             return img
 

@@ -553,3 +553,44 @@ def test_duck_typed_ddim_scheduler_through_the_hip_model(tiny_pair):
     e = rel_l2(outs[0].cpu(), want)
     print(f"\nduck-typed DDIM scheduler, 6 steps, tiny AR model: rel-L2 vs the oracle pipeline with the same scheduler {e:.2e}")
     assert e < TOL
+
+
+def test_batched_conditioning_equals_per_evaluation_conditioning(tiny_pair):
+    """`prepare_conditioning`: the sample-independent part of the forward (context refiner, conditioning embedding, AdaLN modulation
+    vectors) for all noise levels of a chunk in one batch == the same part computed inside each forward (same kernels on a (level,
+    member) batch: equal to fp32 rounding - another stream-K cut of the same sums -, not bit for bit), also when the batch is cut
+    into several passes; and a whole Heun chunk with the batching switched off gives the same sample."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o, g = tiny_pair
+    known, stamp = synth_known(2).cuda(), torch.tensor([2019063012]).cuda()
+    ts = torch.tensor([0.3, -0.7, 1.05, -1.4])
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+    try:
+        for mode, tol in (("fp32", 1e-6), ("bf16x3", 2e-5), ("bf16", 5e-3)):
+            g.set_gemm_precision(mode)
+            te = g.time_elapsed_embedding(stamp)
+            plain = [g(x, t.reshape(1).cuda(), known, time_elapsed=stamp).sample.clone() for t in ts]
+            for rows in (96, 4, 2):  # one pass; two passes of two levels; four passes
+                g.COND_MAX_ROWS = rows
+                pack = g.prepare_conditioning(ts.cuda(), known, te)
+                assert pack.levels == 4 and pack.ctx.shape[0] == 8
+                for i, t in enumerate(ts):
+                    got = g(x, t.reshape(1).cuda(), known, time_elapsed=stamp, conditioning=(pack, i)).sample
+                    assert rel_l2(got, plain[i]) < tol, (mode, rows, i)
+            g.COND_MAX_ROWS = 96
+            with pytest.raises(ValueError):
+                g(x[:1], ts[:1].cuda(), known[:1], time_elapsed=stamp, conditioning=(pack, 0))  # prepared for two members
+            pipe = AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())
+            outs = {}
+            for flag in (True, False):
+                g.batch_conditioning = flag
+                outs[flag] = ensemble_AR_sampler(pipe, 2, 4, 6, known_latents=known[:1], timestamps=stamp, sampler_type="edm", device="cuda")
+                pl = ensemble_AR_sampler(pipe, 2, 4, 6, known_latents=known[:1], timestamps=stamp, sampler_type="pipeline", device="cuda")
+                outs[("p", flag)] = pl
+            assert rel_l2(outs[True], outs[False]) < 20 * tol and rel_l2(outs[("p", True)], outs[("p", False)]) < 20 * tol, mode
+    finally:
+        g.COND_MAX_ROWS = 96
+        g.batch_conditioning = True
+        g.set_gemm_precision("fp32")
