@@ -153,29 +153,31 @@ __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm,
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
     asm volatile("" ::: "memory");  // one row tile's loads at a time
     if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
-    float4 tv[8];  // (cos, sin) of this lane's two rotary pairs per column tile: one 16-byte load each
+    // (cos, sin) of this lane's two rotary pairs per column tile: one 16-byte load each, all eight in flight before the row's
+    // sum of squares is formed
+    float4 tv[8];
     if (rope) {
       const float* __restrict__ cs = rope + static_cast<long long>(P.rope_row0 + m) * 128 + nl;
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) tv[ct] = *reinterpret_cast<const float4*>(cs + 16 * ct);
     }
-    float x[8][4];
-    float ss = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const f32x4 av = acc[rt * 8 + ct];
-      x[ct][0] = av[0] + bv[ct].x; x[ct][1] = av[1] + bv[ct].y; x[ct][2] = av[2] + bv[ct].z; x[ct][3] = av[3] + bv[ct].w;
-      ss += x[ct][0] * x[ct][0] + x[ct][1] * x[ct][1] + x[ct][2] * x[ct][2] + x[ct][3] * x[ct][3];
-    }
     float r = 1.f;
-    if (w) {  // RMSNorm(128, eps) of the head row: the 4 lanes 16 / 32 / 48 further hold the rest of it
-      ss = xor32_add(xor16_add(ss));
+    if (w) {  // RMSNorm(128, eps) of the head row (acc + bias, recomputed below: registers are scarce on the 256-row tile)
+      float ss = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const f32x4 av = acc[rt * 8 + ct];
+        const float a0 = av[0] + bv[ct].x, a1 = av[1] + bv[ct].y, a2 = av[2] + bv[ct].z, a3 = av[3] + bv[ct].w;
+        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      }
+      ss = xor32_add(xor16_add(ss));  // the lanes 16 / 32 / 48 further hold the rest of the head row
       r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
     }
     unsigned char* row = reinterpret_cast<unsigned char*>(C + static_cast<long long>(m) * P.d.ldc + bn * BN);
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-      float x0 = x[ct][0], x1 = x[ct][1], x2 = x[ct][2], x3 = x[ct][3];
+      const f32x4 av = acc[rt * 8 + ct];
+      float x0 = av[0] + bv[ct].x, x1 = av[1] + bv[ct].y, x2 = av[2] + bv[ct].z, x3 = av[3] + bv[ct].w;
       if (w) {
         x0 = x0 * r * wv[ct].x; x1 = x1 * r * wv[ct].y; x2 = x2 * r * wv[ct].z; x3 = x3 * r * wv[ct].w;
       }

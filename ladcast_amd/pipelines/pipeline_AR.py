@@ -104,9 +104,11 @@ class AutoRegressive2DPipeline:
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
 
+        ts_dev = sch.timesteps.to(device=dev, dtype=torch.float32).contiguous()  # outside the capture: a host-to-device copy
+
         def loop(img, kn, tsteps):
             kb = kn if kn.shape[0] == batch_size else kn.expand(batch_size, *kn.shape[1:]).contiguous()
-            pack = net.prepare_conditioning(sch.timesteps, kb, te) if getattr(net, "batch_conditioning", False) else None
+            pack = net.prepare_conditioning(ts_dev, kb, te) if getattr(net, "batch_conditioning", False) else None
             for i, (t, t_dev) in enumerate(zip(sch.timesteps, tsteps)):
                 x_in = sch.scale_model_input(img, t)
                 out = net.forward_launch_only(x_in, t_dev, kb, te, None if pack is None else (pack, i))

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ladcast_amd.build_id import csrc_sha16  # noqa: E402
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join("profiles", "pmc_summary.json")  # on the GPU box: a path under gpurun_out/
 out = {}
 vals = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
 for c in vals:
@@ -32,6 +33,6 @@ try:
 except OSError:
     head = None
 out["_build"] = dict(csrc_sha16=csrc_sha16(), git_head=head)
-json.dump(out, open(os.path.join("profiles", "pmc_summary.json"), "w"), indent=1)
+json.dump(out, open(out_path, "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in out.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]:
     print(f"{k[:44]:44s} launches={v['launches']:5d} fetch_raw={v['fetch_size_kib_raw']/1024:9.2f} MiB write={v['write_size_kib']/1024:9.2f} MiB -> HBM/launch={v['hbm_bytes_per_launch']/1e6:9.2f} MB")
