@@ -104,7 +104,9 @@ class AutoRegressive2DPipeline:
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
         ent = cache.get(key)
 
-        ts_dev = sch.timesteps.to(device=dev, dtype=torch.float32).contiguous()  # outside the capture: a host-to-device copy
+        # device copy of the timesteps for `prepare_conditioning`, made outside the capture (a host-to-device copy) and kept alive with
+        # the graph that reads it
+        ts_dev = sch.timesteps.to(device=dev, dtype=torch.float32).contiguous() if ent is None else None
 
         def loop(img, kn, tsteps):
             kb = kn if kn.shape[0] == batch_size else kn.expand(batch_size, *kn.shape[1:]).contiguous()
@@ -129,7 +131,7 @@ class AutoRegressive2DPipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 st_out = loop(st_img, st_known, tsteps)
-            ent = (graph, st_img, st_known, st_out, tsteps, side, list(sch.model_outputs), sch.lower_order_nums, sch._step_index)
+            ent = (graph, st_img, st_known, st_out, tsteps, side, list(sch.model_outputs), sch.lower_order_nums, sch._step_index, ts_dev)  # ts_dev: read by the graph
             cache[key] = ent
         graph, st_img, st_known, st_out = ent[:4]
         st_img.copy_(image)
