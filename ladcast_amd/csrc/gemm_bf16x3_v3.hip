@@ -485,6 +485,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 
     // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
     // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
+#ifdef LDC_GEMM_STAMPS_PROLOGUE  // one-off diagnosis of the first segment's start-up (launches of <= 2 segments: slots 9-11 are free)
+    if (seg_ == 0) { LDC_STAMP(9) }
+#endif
     const unsigned char* a_src[NAI];
     const unsigned char* w_src[2];
     int pix_b[NAI], pix_hw[NAI];  // CONV: first pixel of the row's image, (h << 16 | w) inside it
@@ -680,10 +683,16 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   }
 
     // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
+#ifdef LDC_GEMM_STAMPS_PROLOGUE
+    if (seg_ == 0) { LDC_STAMP(10) }
+#endif
 #pragma unroll
     for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
 #pragma unroll
     for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+#ifdef LDC_GEMM_STAMPS_PROLOGUE
+    if (seg_ == 0) { LDC_STAMP(11) }
+#endif
     if constexpr (ND == 6) {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {

@@ -480,7 +480,7 @@ def test_bf16_single_term_mode(tiny_pair):
 def test_foreign_attention_processor_is_called_not_ignored(tiny_pair):
     """`set_attn_processor` (models/LaDCast_3D_model.py:793-827) with a processor that is not the built-in one: the forward calls it
     with the reference's protocol.  (1) The oracle's restatement of the reference processor, installed as a FOREIGN processor on the
-    HIP model, reproduces the oracle forward (fp32 tolerance) and the fused path; (2) a processor that zeroes the context stream's
+    HIP model, reproduces the oracle forward (fp32 tolerance) and the fused path; (2) a processor that drops the sample stream's
     attention output changes the result - it really ran; (3) a mixed dict; (4) the split modes and hipGraph capture refuse it."""
     from ladcast_amd.models import LaDCastAttnProcessor2_0
     from oracle.ar_model import LaDCastAttnProcessor as OracleProcessor
@@ -506,13 +506,13 @@ def test_foreign_attention_processor_is_called_not_ignored(tiny_pair):
         assert seen == [((2, 450, 256), None, True, False), ((2, 1800, 256), (2, 450, 256), True, True), ((2, 1800, 256), (2, 450, 256), True, True)]
         assert rel_l2(got.cpu(), want) < 2e-5 and rel_l2(got, fused) < 2e-5
 
-        class ZeroContext(OracleProcessor):
+        class ZeroAttention(OracleProcessor):  # a processor with different arithmetic: the sample stream's attention output is dropped
             def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
                 a, ca = super().__call__(attn, hidden_states, encoder_hidden_states, **kw)
-                return a, (None if ca is None else torch.zeros_like(ca))
+                return torch.zeros_like(a), ca
 
         names = list(g.attn_processors)
-        g.set_attn_processor({k: (ZeroContext() if "single" in k else LaDCastAttnProcessor2_0()) for k in names})
+        g.set_attn_processor({k: (ZeroAttention() if "single" in k else LaDCastAttnProcessor2_0()) for k in names})
         changed = g(*args, time_elapsed=ts.cuda()).sample
         assert rel_l2(changed, fused) > 1e-3
         g.set_gemm_precision("bf16x3")

@@ -96,6 +96,8 @@ flops = {"dual_qkv": 2 * S * 3 * D * D, "dual_out": 2 * S * D * D, "dual_up": 2 
 names = {0: "entry", 1: "seg0 first DMA landed", 2: "seg0 loop done", 3: "seg0 published/ticket", 4: "seg0 done",
          5: "seg1 first DMA landed", 6: "seg1 loop done", 7: "seg1 published/ticket", 8: "seg1 done",
          9: "seg2+ first DMA", 10: "seg2+ loop done", 11: "seg2+ ticket", 12: "seg2+ done", 15: "exit"}
+if os.environ.get("LDC_STAMPS_PROLOGUE"):  # library built with DIAG=-DLDC_GEMM_STAMPS_PROLOGUE: start-up of the first segment (<= 2-segment launches)
+    names.update({9: "seg0 decoded (scalars)", 10: "seg0 sources set", 11: "seg0 prologue DMAs issued"})
 
 for name, run in launches.items():
     if args.launch not in ("all", name):
