@@ -71,9 +71,15 @@ struct SKArgs {
   long long tiles;
   float* ws;
   unsigned* counters;  // one per tile
+  unsigned upg, urem;  // U / G and U % G: unit range g = [g upg + min(g, urem), ...) - sizes differ by at most one, no division in the kernel
 };
 
-__device__ __forceinline__ long long range_start(long long g, long long U, int G) { return (g * U) / G; }
+// Round 3: the unit ranges are cut without a division (the kernel's start-up was 2.5 / 5.8 us of scalar code before the first DMA
+// instruction, most of it inlined 64-bit divisions: profiles/r03_f_gemm_startup_diagnostics.log).  U < 2^31 (checked by the host).
+__device__ __forceinline__ long long range_start(long long g, const SKArgs& a) {
+  const unsigned gu = static_cast<unsigned>(g);
+  return static_cast<long long>(gu * a.upg + (gu < a.urem ? gu : a.urem));
+}
 
 __device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u) {
   int pi = 0;
@@ -151,7 +157,9 @@ __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm,
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
+#ifndef LDC_QKV_EPI_HOIST  // experiment (make ... DIAG=-DLDC_QKV_EPI_HOIST): let the second row tile's rotary loads be hoisted over the first's arithmetic
     asm volatile("" ::: "memory");  // one row tile's loads at a time
+#endif
     if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
     // (cos, sin) of this lane's two rotary pairs per column tile: one 16-byte load each, all eight in flight before the row's
     // sum of squares is formed
@@ -437,8 +445,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(static_cast<unsigned long long>(v) >> 32));
     return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
   };
-  const long long u_begin = uniform64(range_start(g, a.U, a.G));
-  const long long u_end = uniform64(range_start(g + 1, a.U, a.G));
+  const long long u_begin = uniform64(range_start(g, a));
+  const long long u_end = uniform64(range_start(g + 1, a));
   const int fr = lane & 15;   // fragment row (of the 16-row / 16-column MFMA tile)
   const int kg = lane >> 4;   // k-group: k = 8 kg .. 8 kg + 7 of the k-step
   // DMA lane geometry: a wave instruction covers 8 rows x 128 B; lane -> (row lr, 16-byte slot lp)
@@ -454,27 +462,44 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
   const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
 
-  long long u = u_begin;
-  while (u < u_end) {
-    const int pi = find_problem_by_unit(a, u);
-    const DevProblem& P = a.pr[pi];
-    const long long local = u - P.unit0;
-    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / P.kt));
-    const int k0 = static_cast<int>(local - static_cast<long long>(tile) * P.kt);
-    const long long left = u_end - u;
-    const int k1 = (P.kt - k0 <= left) ? P.kt : k0 + static_cast<int>(left);
+  // One SEGMENT = the k-steps [k0, k1) of one output tile (a whole tile when the unit ranges are tile-aligned).  Its coordinates are
+  // wave-uniform scalars decoded with 32-bit arithmetic; the NEXT segment is decoded while the current one's prologue DMAs are in flight.
+  struct Seg {
+    int pi, tile, k0, k1, b, bm, bn;
+  };
+  auto decode = [&](long long u_) {
+    Seg sg;
+    sg.pi = find_problem_by_unit(a, u_);
+    const DevProblem& Q = a.pr[sg.pi];
+    const unsigned local = static_cast<unsigned>(u_ - Q.unit0), kt_u = static_cast<unsigned>(Q.kt);
+    sg.tile = __builtin_amdgcn_readfirstlane(static_cast<int>(local / kt_u));
+    sg.k0 = static_cast<int>(local - static_cast<unsigned>(sg.tile) * kt_u);
+    const long long left = u_end - u_;
+    sg.k1 = (Q.kt - sg.k0 <= left) ? Q.kt : sg.k0 + static_cast<int>(left);
     // tile order (speed only): batch, then super-rows of rm row tiles, then column panels, row tile fastest.  An XCD owns a
     // contiguous run of units, i.e. about rm row panels x (tiles per XCD / rm) column panels: with rm = tm (one super-row)
     // every XCD streams ALL of A and 1/8 of W; a squarer block fetches fewer bytes through the fabric (launch_v3 picks rm)
-    const int per_b = P.tm * P.tn;
-    const int b = tile / per_b;
-    const int t_in = tile - b * per_b;
-    const int strip = P.rm * P.tn;
-    const int sr = t_in / strip;
-    const int r_in = t_in - sr * strip;
-    const int h_sr = (P.tm - sr * P.rm) < P.rm ? (P.tm - sr * P.rm) : P.rm;
-    const int bn = r_in / h_sr;
-    const int bm = sr * P.rm + (r_in - bn * h_sr);
+    const unsigned per_b = static_cast<unsigned>(Q.tm * Q.tn), tile_u = static_cast<unsigned>(sg.tile);
+    const unsigned b_ = tile_u / per_b;
+    const unsigned t_in = tile_u - b_ * per_b;
+    const unsigned strip = static_cast<unsigned>(Q.rm * Q.tn);
+    const unsigned sr = t_in / strip;
+    const unsigned r_in = t_in - sr * strip;
+    const int rest = Q.tm - static_cast<int>(sr) * Q.rm;
+    const unsigned h_sr = static_cast<unsigned>(rest < Q.rm ? rest : Q.rm);
+    const unsigned bn_ = r_in / h_sr;
+    sg.b = __builtin_amdgcn_readfirstlane(static_cast<int>(b_));
+    sg.bn = __builtin_amdgcn_readfirstlane(static_cast<int>(bn_));
+    sg.bm = __builtin_amdgcn_readfirstlane(static_cast<int>(sr) * Q.rm + static_cast<int>(r_in - bn_ * h_sr));
+    return sg;
+  };
+  long long u = u_begin;
+  Seg cur{};
+  if (u < u_end) cur = decode(u);
+  while (u < u_end) {
+    const int pi = cur.pi;
+    const DevProblem& P = a.pr[pi];
+    const int tile = cur.tile, k0 = cur.k0, k1 = cur.k1, b = cur.b, bm = cur.bm, bn = cur.bn;
     const int M = P.d.M, N = P.d.N, K = P.d.K;
     // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
     // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
@@ -693,6 +718,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #ifdef LDC_GEMM_STAMPS_PROLOGUE
     if (seg_ == 0) { LDC_STAMP(11) }
 #endif
+    // the next segment's coordinates, while this one's first two stages are in flight
+    const long long u_next = u + (k1 - k0);
+    Seg nxt = cur;
+    if (u_next < u_end) nxt = decode(u_next);
     if constexpr (ND == 6) {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
@@ -750,9 +779,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;
       const long long l = f + P.kt;
       long long g_first = g;
-      while (g_first > 0 && range_start(g_first, a.U, a.G) > f) --g_first;
+      while (g_first > 0 && range_start(g_first, a) > f) --g_first;
       long long g_last = g;
-      while (g_last + 1 < a.G && range_start(g_last + 1, a.U, a.G) < l) ++g_last;
+      while (g_last + 1 < a.G && range_start(g_last + 1, a) < l) ++g_last;
       const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
       unsigned* cnt = a.counters + (P.tile0 + tile);
       unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (long long gp = g_first; gp <= g_last; ++gp) {
-          const long long s = range_start(gp, a.U, a.G);
+          const long long s = range_start(gp, a);
           const float* sl = a.ws + (2 * gp + (s > f ? 0 : 1)) * SLOT_FLOATS;
 #pragma unroll
           for (int i = 0; i < NACC; ++i) {
@@ -785,7 +814,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
         tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
       }
     }
-    u += k1 - k0;
+    u = u_next;
+    cur = nxt;
     LDC_STAMP(4 + 4 * seg_)
 #ifdef LDC_GEMM_STAMPS
     if (seg_ < 2) ++seg_;
@@ -952,8 +982,11 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     if (fit < G) G = fit;
   }
   LDC_CHECK_ALIGN16(workspace);
+  if (U >= (1LL << 31)) return LDC_ERR_UNSUPPORTED;  // 32-bit unit arithmetic in the kernel
   a.G = static_cast<int>(G);
   a.U = U;
+  a.upg = static_cast<unsigned>(U / G);
+  a.urem = static_cast<unsigned>(U % G);
   a.tiles = tiles;
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
