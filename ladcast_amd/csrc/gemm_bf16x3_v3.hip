@@ -130,6 +130,7 @@ template <int BM>
 __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                              int lane) {
   constexpr int RT = BM / 128;
+  asm volatile("" : "+v"(lane));  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
   const int M = P.d.M;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v (wave-uniform)
@@ -222,6 +223,7 @@ template <int BM, int ACT, int FMT>
 __device__ __forceinline__ void tile_epilogue_fast(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                                    int lane) {
   constexpr int RT = BM / 128;
+  asm volatile("" : "+v"(lane));  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
   const int M = P.d.M;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -325,6 +327,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
     return;
   }
 #endif
+  asm volatile("" : "+v"(lane));
   const int M = P.d.M, N = P.d.N;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -415,9 +418,14 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 // sphere padding rule, a per-lane DMA source recomputed when a tap starts (wave-uniform branch, 2^kshift k-steps apart); everything
 // behind the DMA issue is the GEMM.  X is NHWC in the split format (TERMS = 3: 32 channels per k-step) or plain bf16 rows (TERMS = 1:
 // 64 channels per k-step), written by the DCAE's producers (dcae.hip).
+// TERMS = 0 (round 3, the exact-fp32 mode): the operands are PLAIN fp32 rows - 32 k per 128-byte k-step, the same row geometry as the
+// split groups - through the same ring, swizzle and fragment reads; the lane that the split mode hands the hi / lo chunks of k-group
+// g holds k = 8 g .. 8 g + 7 as floats, and MFMA j of a column tile (v_mfma_f32_16x16x4_f32: one float per lane and operand, 4 k per
+// instruction) takes element j of both operands: k = 8 (lane / 16) + j.  8 MFMAs of 32 cycles per column and row tile: the loop is
+// matrix-pipe bound by construction (4096 cycles of MFMA per k-step and wave at 256 rows, against 1536 in the split mode).
 template <int BM, int TERMS, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
-  constexpr int CPK = TERMS == 3 ? BK : 2 * BK;  // CONV: channels per 128-byte k-step (split groups / plain bf16)
+  constexpr int CPK = TERMS == 1 ? 2 * BK : BK;  // CONV: channels per 128-byte k-step (plain bf16 | split groups, fp32)
   constexpr int RT = BM / 128;                 // 16-row tiles per wave
   constexpr int NACC = RT * 8;                 // accumulators (f32x4) per lane
   constexpr int STAGE_B = (BM + BN) * ROW_B;   // 48 KiB / 32 KiB
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const bool wave_rows = bm * BM + 16 * RT * wave < M;
     const float* __restrict__ A = P.A + static_cast<long long>(b) * P.d.a_bs;
     const int lda = P.d.lda;
-    const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 3 ? 4 : 2);  // packed split row / plain bf16 row
+    const long long w_row_bytes = static_cast<long long>(K) * (TERMS == 1 ? 2 : 4);  // plain bf16 row | packed split row, fp32 row
 
     // per-lane DMA sources (k-step 0); rows past the edge are clamped (their outputs are never stored).
     // A instruction q (0..BM/8-1) covers tile rows [8q, 8q+8): this wave issues q = wave + 8 i; W likewise (16 of them)
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
           const unsigned char* src = a_src[i] + chunk * (BK * 4);
           if (chunk * CPK + CPK > P.cin) {  // the tap's last k-step: 8-column groups behind cin read zeros (their weights are zero too)
             // this lane's 16-byte slot: split rows - the hi or lo half of group cslot / 2; plain bf16 rows - columns 8 cslot .. + 7
-            if (chunk * CPK + 8 * (TERMS == 3 ? (cslot >> 1) : cslot) >= P.cin) src = P.zero16;
+            if (chunk * CPK + (TERMS == 0 ? 4 * cslot : 8 * (TERMS == 3 ? (cslot >> 1) : cslot)) >= P.cin) src = P.zero16;
           }
           dma16(src, live ? sA + (wave + 8 * i) * 1024 : dump);
         } else {
@@ -607,9 +615,25 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WF), __builtin_bit_cast(bf16x8, AF), ACC, 0, 0, 0); \
   LDC_SB;
     // the 3 RT MFMAs of column tile CT with A fragments (AH, AL); with two row tiles their accumulation chains alternate
+#define LDC_MMF(ACC, WF, AF, J)                                                                               \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(WF[J]), __int_as_float(AF[J]), ACC, 0, 0, 0);     \
+  LDC_SB;
 #define LDC_CT(CT, WH, WL, AH, AL)                                               \
   if (wave_rows) {                                                               \
-    if constexpr (TERMS == 1) {                                                  \
+    if constexpr (TERMS == 0) {                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                         \
+        LDC_MMF(acc[(CT)], WH, AH[0], j_)                                        \
+        if constexpr (RT == 2) {                                                 \
+          LDC_MMF(acc[8 + (CT)], WH, AH[RT - 1], j_)                             \
+        }                                                                        \
+      }                                                                          \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                         \
+        LDC_MMF(acc[(CT)], WL, AL[0], j_)                                        \
+        if constexpr (RT == 2) {                                                 \
+          LDC_MMF(acc[8 + (CT)], WL, AL[RT - 1], j_)                             \
+        }                                                                        \
+      }                                                                          \
+    } else if constexpr (TERMS == 1) {                                           \
       LDC_MM(acc[(CT)], WH, AH[0])                                               \
       if constexpr (RT == 2) {                                                   \
         LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])                                    \
@@ -754,6 +778,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #undef LDC_KSTEP
 #undef LDC_WAIT
 #undef LDC_CT
+#undef LDC_MMF
 #undef LDC_MM
 #undef LDC_RD_A
 #undef LDC_RD_W
@@ -768,12 +793,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
-      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS;
+      int lane_h = lane;
+      asm volatile("" : "+v"(lane_h));  // slab addresses are formed here, not hoisted to the kernel entry and spilled across the main loop
+      float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS + lane_h;
 #pragma unroll
       for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64 + lane, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const long long f = P.unit0 + static_cast<long long>(tile) * P.kt;
@@ -808,7 +835,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #pragma unroll
           for (int i = 0; i < NACC; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane_h];
           }
         }
         tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
@@ -844,11 +871,19 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     LDC_CHECK_PTR(q.C);
     const ldc_gemm_desc& d = q.d;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
-    if (d.K % (TERMS == 3 ? BK : 2 * BK)) return LDC_ERR_UNSUPPORTED;  // a 128-byte k-step: 32 split / 64 plain-bf16 values
-    if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
+    if (d.K % (TERMS == 1 ? 2 * BK : BK)) return LDC_ERR_UNSUPPORTED;  // a 128-byte k-step: 64 plain-bf16 / 32 split / 32 fp32 values
+    if constexpr (TERMS == 0) {  // exact fp32: plain fp32 rows in, fp32 rows out, a contiguous [N][K] weight
+      if (d.flags != 0 || d.ldw != d.K) return LDC_ERR_UNSUPPORTED;
+    } else {
+      if (!(d.flags & LDC_GEMM_A_SPLIT)) return LDC_ERR_UNSUPPORTED;
+    }
     LDC_CHECK_ALIGN16(q.A);
     LDC_CHECK_ALIGN16(q.W);
-    if ((d.lda & 7) || (d.a_bs & 7) || (reinterpret_cast<unsigned long long>(q.A) & 31ull)) return LDC_ERR_ALIGN;
+    if constexpr (TERMS == 0) {
+      if ((d.lda & 3) || (d.a_bs & 3)) return LDC_ERR_UNSUPPORTED;  // the caller falls back to the register-staged kernel
+    } else {
+      if ((d.lda & 7) || (d.a_bs & 7) || (reinterpret_cast<unsigned long long>(q.A) & 31ull)) return LDC_ERR_ALIGN;
+    }
     if (d.act < LDC_ACT_NONE || d.act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
     DevProblem& P = a.pr[i];
     P.A = q.A;
@@ -865,7 +900,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (q.gate) v4 = v4 && al16(q.gate) && (d.gate_bs % 4 == 0);
       if (q.R) v4 = v4 && al16(q.R) && (d.ldr % 4 == 0) && (d.r_bs % 4 == 0);
       P.vec4 = v4 ? 1 : 0;
-      P.c_split = (d.flags & LDC_GEMM_C_SPLIT) ? (TERMS == 3 ? LDC_FMT_SPLIT : LDC_FMT_BF16) : 0;
+      P.c_split = (TERMS != 0 && (d.flags & LDC_GEMM_C_SPLIT)) ? (TERMS == 3 ? LDC_FMT_SPLIT : LDC_FMT_BF16) : 0;
       // operand rows out: N % 4 == 0 (v4), the pad half of a last half-filled 8-column group is zeroed
       if (P.c_split && !(v4 && d.ldc % 8 == 0 && d.ldc >= ((d.N + 7) & ~7) &&
                          d.c_bs % 8 == 0 && (reinterpret_cast<unsigned long long>(q.C) & 31ull) == 0))
@@ -893,7 +928,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     }
     P.tm = ldc_cdiv(d.M, BM);
     P.tn = ldc_cdiv(d.N, BN);
-    P.kt = d.K / (TERMS == 3 ? BK : 2 * BK);
+    P.kt = d.K / (TERMS == 1 ? 2 * BK : BK);
     P.unit0 = U;
     P.tile0 = tiles;
     {
@@ -1027,6 +1062,25 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
                  : launch_v3<256, 1>(problems, epi, n, workspace, workspace_bytes, stream);
   return small ? launch_v3<128, 3>(problems, epi, n, workspace, workspace_bytes, stream)
                : launch_v3<256, 3>(problems, epi, n, workspace, workspace_bytes, stream);
+}
+
+// exact-fp32 grouped GEMM on the ring kernel (TERMS = 0); LDC_ERR_UNSUPPORTED -> the caller (ldc_gemm_grouped, gemm_streamk.hip) runs
+// its register-staged stream-K kernel instead (K % 32 != 0, strided weights, unaligned rows)
+int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(problems);
+  if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
+  static const char* const off = getenv("LDC_F32_RING");  // measurement aid, read once: LDC_F32_RING=0 keeps the round-2 fp32 kernel
+  if (off && atoi(off) == 0) return LDC_ERR_UNSUPPORTED;
+  long long tiles256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const ldc_gemm_desc& d = problems[i].d;
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
+    tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
+  }
+  // a tile takes ~2.7x the split kernel's time: keep more, smaller tiles for balance until the chip is filled several times over
+  const bool small = tiles256 < 800;
+  return small ? launch_v3<128, 0>(problems, nullptr, n, workspace, workspace_bytes, stream)
+               : launch_v3<256, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
 }
 
 int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,

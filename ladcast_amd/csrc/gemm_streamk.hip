@@ -547,8 +547,15 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
   return ldc_launch_status();
 }
 
+int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                              void* stream);  // gemm_bf16x3_v3.hip, TERMS = 0
+
 extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                                 void* stream) {
+  // round 3: the LDS-DMA ring kernel with fp32 operand rows and the fp32 matrix instruction where the shapes allow (K % 32 == 0,
+  // contiguous weights, 16-byte rows); the register-staged stream-K kernel below otherwise
+  const int st = ldc_gemm_grouped_f32_ring(problems, n, workspace, workspace_bytes, stream);
+  if (st != LDC_ERR_UNSUPPORTED) return st;
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, false);
 }
 

@@ -447,9 +447,10 @@ def test_driver_counterpart_writes_the_reference_file_layout(tmp_path):
 def test_bf16_single_term_mode(tiny_pair):
     """BASELINE configs[4] ("fp16/bf16 mixed"): `set_gemm_precision("bf16")` = one bf16 MFMA per product in the token-stream GEMMs and
     both attention contractions, everything the reference pins to fp32 under autocast left in fp32 (temb: LaDCast_3D_model.py:953;
-    norms, softmax statistics, residual stream, fp64 sampler state).  STATED TOLERANCE vs the fp32 oracle: 5e-3 rel-L2 per forward,
-    2e-2 per 20-step Heun chunk (bf16 has 8 significand bits: 2^-9 = 2e-3 per rounding); the 1e-4 budget does not apply to this mode."""
+    norms, softmax statistics, residual stream, fp64 sampler state).  Stated tolerances vs the fp32 oracle: ladcast_amd/precision.py (measured x 2: 7e-3 per forward, 4e-3 per 20-step Heun chunk; bf16 has
+    8 significand bits: 2^-9 = 2e-3 per rounding); the 1e-4 budget does not apply to this mode."""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.precision import tolerance
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 
     o, g = tiny_pair
@@ -470,8 +471,8 @@ def test_bf16_single_term_mode(tiny_pair):
         got_g = ensemble_AR_sampler(gpipe, 2, 4, 20, known_latents=known.cuda(), timestamps=ts.cuda(), sampler_type="edm", device="cuda")
         g.enable_hip_graph(False)
         print(f"\nbf16 (single-term): tiny forward rel-L2 {e_fwd:.2e}, 20-step Heun chunk rel-L2 {e_chunk:.2e}")
-        assert 1e-5 < e_fwd < 5e-3, e_fwd  # lower bound: the mode is really on
-        assert e_chunk < 2e-2, e_chunk
+        assert 1e-5 < e_fwd < tolerance("bf16", "forward"), e_fwd  # lower bound: the mode is really on
+        assert e_chunk < tolerance("bf16", "chunk_edm"), e_chunk
         assert torch.equal(got_g, got)
     finally:
         g.set_gemm_precision("fp32")
