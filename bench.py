@@ -140,8 +140,9 @@ class KernelTimer:
             work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
             # which kernel the C ABI dispatches to (gemm_streamk.hip, ldc_gemm_grouped_bf16x3): pre-split activations and
             # K % 32 == 0 -> the 16x16x32 kernel; fp32 activations and K % 32 == 0 -> the 32x32x16 LDS-DMA kernel
-            if not split_bf16:
-                name = "gemm_streamk_kernel"
+            if not split_bf16:  # exact fp32: the ring kernel (gemm_bf16x3_v3.hip, TERMS = 0) when K % 32 == 0, else the register-staged one
+                ring = all(p[0].d.K % 32 == 0 and p[0].d.ldw == p[0].d.K for p in problems) and os.environ.get("LDC_F32_RING", "1") != "0"
+                name = "gemm_bf16x3_v3_kernel<fp32 rows>" if ring else "gemm_streamk_kernel"
             elif all(p[0].d.K % 32 == 0 for p in problems):
                 name = "gemm_bf16x3_v3_kernel" if all(p[0].d.flags & 1 for p in problems) else "gemm_bf16x3_dma_kernel"
             else:

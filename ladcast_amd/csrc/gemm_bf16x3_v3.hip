@@ -72,6 +72,11 @@ struct SKArgs {
   float* ws;
   unsigned* counters;  // one per tile
   unsigned upg, urem;  // U / G and U % G: unit range g = [g upg + min(g, urem), ...) - sizes differ by at most one, no division in the kernel
+  // Round-robin tiles (0 = contiguous ranges): workgroup g runs the WHOLE tiles g, g + G, g + 2 G, ... (rr = G kt units apart; upg = kt,
+  // urem = 0).  For launches whose problems have epilogues of different cost - the single block's [MLP up | QKV] launch: 432 tiles
+  // with a GELU epilogue, then 324 with the norm / RoPE / split one, 3 per workgroup - contiguous ranges hand some workgroups three
+  // of the expensive kind; dealt round-robin nobody gets more than two.  An XCD still works on G / 8 consecutive tiles at a time.
+  unsigned rr;
 };
 
 // Round 3: the unit ranges are cut without a division (the kernel's start-up was 2.5 / 5.8 us of scalar code before the first DMA
@@ -113,6 +118,16 @@ __device__ __forceinline__ float xor32_add(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// This lane's index, produced where it is asked for.  Everything per-lane in the kernel (fragment addresses, DMA row / slot, output
+// row and column) derives from it; derived from threadIdx at the kernel entry those values stay live across the main loop AND the
+// epilogue, the 256-row kernel spills them at entry, and the segment loop then waits for the scratch stores (first touch of the
+// wave's scratch page: ~4 us before the first DMA, measured with the prologue stamps).  Two VALU instructions instead, per use site.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // Epilogue of the fused QKV projection (models/LaDCast_3D_model.py:92-169,175-190): the 128-column tile is exactly one head, so the
 // tile holds whole head rows - a lane has 32 of a row's 128 values (4 per column tile), the lanes 16 / 32 / 48 further the rest.
 // bias -> RMSNorm(128, eps) * weight -> adjacent-pair rotary embedding (q and k heads; same operation order as
@@ -130,7 +145,7 @@ template <int BM>
 __device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                              int lane) {
   constexpr int RT = BM / 128;
-  asm volatile("" : "+v"(lane));  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
+  lane = fresh_lane();  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
   const int M = P.d.M;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v (wave-uniform)
@@ -223,7 +238,7 @@ template <int BM, int ACT, int FMT>
 __device__ __forceinline__ void tile_epilogue_fast(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
                                                    int lane) {
   constexpr int RT = BM / 128;
-  asm volatile("" : "+v"(lane));  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
+  lane = fresh_lane();  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
   const int M = P.d.M;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -327,7 +342,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
     return;
   }
 #endif
-  asm volatile("" : "+v"(lane));
+  lane = fresh_lane();
   const int M = P.d.M, N = P.d.N;
   float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
   const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
@@ -434,9 +449,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   constexpr int ND = NAI + 2;                  // DMA instructions per wave and k-step (6 / 4)
   constexpr int NDH = ND / 2;                  // issued per half k-step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   LDC_STAMP(0)
   int seg_ = 0;
   (void)seg_;
@@ -454,21 +467,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
   };
   const long long u_begin = uniform64(range_start(g, a));
-  const long long u_end = uniform64(range_start(g + 1, a));
-  const int fr = lane & 15;   // fragment row (of the 16-row / 16-column MFMA tile)
-  const int kg = lane >> 4;   // k-group: k = 8 kg .. 8 kg + 7 of the k-step
-  // DMA lane geometry: a wave instruction covers 8 rows x 128 B; lane -> (row lr, 16-byte slot lp)
-  const int lr = lane >> 3, lp = lane & 7;
+  const unsigned rr = a.rr;
+  const long long u_end = rr ? a.U : uniform64(range_start(g + 1, a));
   const unsigned smem_lds = lds_addr(smem);
-
-  // fragment read addresses inside a stage: A row tile rt of this wave, W column tile ct; hi chunk 2 kg, lo chunk 2 kg + 1
-  const unsigned f_r = swz(fr);  // f only depends on r & 15, and every 16-row tile starts at a multiple of 16
-  const unsigned off_hi = fr * ROW_B + (((2 * kg) ^ f_r) << 4);
-  const unsigned off_lo = fr * ROW_B + (((2 * kg + 1) ^ f_r) << 4);
-  const unsigned a_hi = smem_lds + (16 * RT * wave) * ROW_B + off_hi;  // + rt * 16 * ROW_B
-  const unsigned a_lo = smem_lds + (16 * RT * wave) * ROW_B + off_lo;
-  const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
-  const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
 
   // One SEGMENT = the k-steps [k0, k1) of one output tile (a whole tile when the unit ranges are tile-aligned).  Its coordinates are
   // wave-uniform scalars decoded with 32-bit arithmetic; the NEXT segment is decoded while the current one's prologue DMAs are in flight.
@@ -508,6 +509,20 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     const int pi = cur.pi;
     const DevProblem& P = a.pr[pi];
     const int tile = cur.tile, k0 = cur.k0, k1 = cur.k1, b = cur.b, bm = cur.bm, bn = cur.bn;
+    // per-lane geometry, formed per segment from a fresh lane index (fresh_lane: nothing per-lane is live across the epilogue)
+    const int lane = fresh_lane();
+    const int fr = lane & 15;   // fragment row (of the 16-row / 16-column MFMA tile)
+    const int kg = lane >> 4;   // k-group: k = 8 kg .. 8 kg + 7 of the k-step
+    // DMA lane geometry: a wave instruction covers 8 rows x 128 B; lane -> (row lr, 16-byte slot lp)
+    const int lr = lane >> 3, lp = lane & 7;
+    // fragment read addresses inside a stage: A row tile rt of this wave, W column tile ct; hi chunk 2 kg, lo chunk 2 kg + 1
+    const unsigned f_r = swz(fr);  // f only depends on r & 15, and every 16-row tile starts at a multiple of 16
+    const unsigned off_hi = fr * ROW_B + (((2 * kg) ^ f_r) << 4);
+    const unsigned off_lo = fr * ROW_B + (((2 * kg + 1) ^ f_r) << 4);
+    const unsigned a_hi = smem_lds + (16 * RT * wave) * ROW_B + off_hi;  // + rt * 16 * ROW_B
+    const unsigned a_lo = smem_lds + (16 * RT * wave) * ROW_B + off_lo;
+    const unsigned w_hi = smem_lds + BM * ROW_B + off_hi;                // + ct * 16 * ROW_B
+    const unsigned w_lo = smem_lds + BM * ROW_B + off_lo;
     const int M = P.d.M, N = P.d.N, K = P.d.K;
     // a wave whose 16 RT rows all lie past the last row of a ragged tile (1800 = 14 x 128 + 8 rows: seven of the last tile's eight
     // waves) issues no MFMA: its share of the tile's matrix-core energy is what the power-limited launch gets back as clock
@@ -743,7 +758,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     if (seg_ == 0) { LDC_STAMP(11) }
 #endif
     // the next segment's coordinates, while this one's first two stages are in flight
-    const long long u_next = u + (k1 - k0);
+    const long long u_next = u + (rr ? static_cast<int>(rr) : k1 - k0);
     Seg nxt = cur;
     if (u_next < u_end) nxt = decode(u_next);
     if constexpr (ND == 6) {
@@ -793,8 +808,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
-      int lane_h = lane;
-      asm volatile("" : "+v"(lane_h));  // slab addresses are formed here, not hoisted to the kernel entry and spilled across the main loop
+      const int lane_h = fresh_lane();  // slab addresses are formed here, not hoisted to the kernel entry and spilled across the main loop
       float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS + lane_h;
 #pragma unroll
       for (int i = 0; i < NACC; ++i)
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
       unsigned* cnt = a.counters + (P.tile0 + tile);
       unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
-      if (tid == 0) {
+      if (wave == 0 && lane_h == 0) {
         const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
         if (last) {
@@ -962,10 +976,12 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
   // grid size: as gemm_bf16x3_dma.hip (phase-aligned divisor of tiles * s when every problem has the same k-depth)
   long long G = CUS;
+  bool whole_tiles = false;  // G divides the tile count and every range is a run of whole tiles
   {
     bool same_kt = true;
     for (int i = 1; i < n; ++i) same_kt = same_kt && (a.pr[i].kt == a.pr[0].kt);
     long long best = 0;
+    int best_sfac = 0;
     if (same_kt) {
       const int kt = a.pr[0].kt;
       // more workgroups win unless they are bought with many more pieces per tile (a hand-off each): 2 % per extra split factor.
@@ -980,6 +996,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
         if (score > best_score) {
           best_score = score;
           best = gd;
+          best_sfac = sfac;
         }
       }
     }
@@ -994,6 +1011,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     }
     if (best >= 160) {
       G = best;
+      whole_tiles = best_sfac == 1;
     } else if (few > 0) {
       G = few;  // measured on 1800 x 84 x 1536: 24.7 us at the stream-K default (36 ranges), 18.0 at 90
     } else {
@@ -1023,6 +1041,19 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   a.upg = static_cast<unsigned>(U / G);
   a.urem = static_cast<unsigned>(U % G);
   a.tiles = tiles;
+  {
+    // round-robin whole tiles (SKArgs::rr): a launch that mixes the QKV epilogue with plain ones, cut into whole tiles, >= 2 per range
+    bool mixed = false;
+    if (epi != nullptr)
+      for (int i = 1; i < n; ++i) mixed = mixed || ((epi[i].heads > 0) != (epi[0].heads > 0));
+    bool on = mixed && whole_tiles && !force_g && tiles % G == 0 && tiles / G >= 2 && U == tiles * a.pr[0].kt;
+    if (const char* e = getenv("LDC_BF16X3_RR")) on = on && atoi(e) != 0;  // measurement aid, read per call: 0 = contiguous ranges
+    if (on) {
+      a.upg = static_cast<unsigned>(a.pr[0].kt);
+      a.urem = 0;
+      a.rr = static_cast<unsigned>(G) * a.upg;
+    }
+  }
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
@@ -1069,12 +1100,17 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
 int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(problems);
   if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
-  static const char* const off = getenv("LDC_F32_RING");  // measurement aid, read once: LDC_F32_RING=0 keeps the round-2 fp32 kernel
+  const char* const off = getenv("LDC_F32_RING");  // measurement / test aid, read per call: LDC_F32_RING=0 -> the register-staged kernel
   if (off && atoi(off) == 0) return LDC_ERR_UNSUPPORTED;
+  auto al16 = [](const void* q_) { return q_ != nullptr && (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
+  // what the register-staged kernel accepts and this one does not goes there, not back to the caller as an error
+  if (!al16(workspace) || workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2ll * 256 * BN * static_cast<long long>(sizeof(float)))
+    return LDC_ERR_UNSUPPORTED;
   long long tiles256 = 0;
   for (int i = 0; i < n; ++i) {
     const ldc_gemm_desc& d = problems[i].d;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
+    if (!al16(problems[i].A) || !al16(problems[i].W)) return LDC_ERR_UNSUPPORTED;
     tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
   }
   // a tile takes ~2.7x the split kernel's time: keep more, smaller tiles for balance until the chip is filled several times over
