@@ -348,9 +348,11 @@ int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* y, long lon
  * y[B][P][groups*32] (models/DCAE.py:158-175,239-253; fp32, eps 1e-15). */
 int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                               void* workspace, long long workspace_bytes, void* stream);
-/* One launch: a 16-wave workgroup per (batch, group), both contractions on the fp32 matrix core (exact fp32 products), the partial
- * KV of the waves added in wave order (bitwise reproducible).  workspace: unused since round 2 (may be NULL;
- * ldc_relu_linear_attn_workspace_bytes returns 0) - the argument stays for callers of the earlier slice-partials form. */
+/* Both contractions on the fp32 matrix core (exact fp32 products).  With `workspace` >= ldc_relu_linear_attn_workspace_bytes(B, P,
+ * groups) bytes (16-byte aligned): two launches over 128-pixel slices - partial KV matrices (33 x 32 per slice) to the workspace,
+ * then KV = the partials added in slice order and the output of the same pixels; the order only depends on P, so a frame's result
+ * does not depend on the batch it is in (bitwise reproducible).  With a NULL / smaller workspace: one launch, a 16-wave workgroup
+ * per (batch, group), partials added in wave order - the same result up to fp32 rounding. */
 long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups);
 /* y = act(RMSNorm_C(x) * w + b (+ resid)) per pixel row (models/DCAE.py:259-260,317-322,371-377,729-730). */
 int ldc_rmsnorm_rows(const float* x, const float* w, const float* b, const float* resid, float* y, long long rows,

@@ -263,12 +263,23 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
   const unsigned ring_lds = lds_addr(ring);
   // K DMA: wave w fills rows [8 w, 8 w + 8) of the four sub-images; lane -> (row lr, 16-byte slot lp), source chunk lp ^ swz(row)
   const int krow = 8 * wave + (lane >> 3);
-  const unsigned char* const k_lane = p.K + bh_off + (((lane & 7) ^ swz(krow)) << 4);
+  // DMA sources = wave-uniform base (scalar register pair) + a 32-bit per-lane offset: one address register per source instead of
+  // two (the <2, 3> kernel sat 4 registers over its budget: a Q fragment lived in scratch and was re-loaded - with a full vmcnt(0)
+  // wait - in front of its MFMA in every iteration)
+  auto uniform_ptr = [](const unsigned char* q_) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q_);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<const unsigned char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+  };
+  const unsigned char* const k_base = uniform_ptr(p.K + bh_off);
+  const unsigned char* const v_base = uniform_ptr(p.V + bh_off);
+  const unsigned k_lane = ((lane & 7) ^ swz(krow)) << 4;
   // V DMA: wave w fills d-tile pair w of the four [hi | lo][key tile] block rows; lane -> (d tile 2 w + (lane >> 5), key (lane & 31) >> 1,
   // 16-byte half lane & 1): 64 contiguous bytes of a plane per key
   const int vkey = (lane & 31) >> 1;
-  const unsigned char* const v_lane = p.V + bh_off + (4 * wave + 2 * (lane >> 5) + (lane & 1)) * 16;
-  auto k_src = [&](int t) {
+  const unsigned v_lane = (4 * wave + 2 * (lane >> 5) + (lane & 1)) * 16;
+  auto k_src = [&](int t) {  // 32-bit offset from k_base (S * ldb < 2^32, checked on the host)
     int key = t * KT + krow;
     key = key < S ? key : S - 1;  // rows past S are masked in the scores: any finite data
     return k_lane + static_cast<unsigned>(key) * ldb;
@@ -279,17 +290,17 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
     return v_lane + static_cast<unsigned>(key) * ldb;
   };
   auto issue_k = [&](int t, int stage) {
-    const unsigned char* src = k_src(t);
+    const unsigned src = k_src(t);
     unsigned char* dst = ring + stage * KTILE_B + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(src + i * 128, dst + i * 4096);
+    for (int i = 0; i < 4; ++i) dma16(k_base + (src + i * 128), dst + i * 4096);
   };
   auto issue_v = [&](int t, int stage) {
-    const unsigned char* s0 = v_src(t, 0);
-    const unsigned char* s1 = v_src(t, 1);
+    const unsigned s0 = v_src(t, 0);
+    const unsigned s1 = v_src(t, 1);
     unsigned char* dst = ring + 2 * KTILE_B + stage * VTILE_B + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(((i & 1) ? s1 : s0) + (i >> 1) * 256, dst + i * 4096);
+    for (int i = 0; i < 4; ++i) dma16(v_base + (((i & 1) ? s1 : s0) + (i >> 1) * 256), dst + i * 4096);
   };
 
   f32x4 o[8][2];
@@ -403,13 +414,13 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
     const bool vq = t + 1 < t_end;
     const bool live_next = vq;  // S_next is a real tile (the last iteration computes it from a stale stage: NaN / inf possible)
     const bool mask_next = (t + 1 == nt - 1);  // ... and may hold keys past S
-    const unsigned char* const ksrc = k_src(t + 2 < t_end ? t + 2 : t_end - 1);
-    const unsigned char* const vsrc0 = v_src(vq ? t + 1 : t_end - 1, 0);
-    const unsigned char* const vsrc1 = v_src(vq ? t + 1 : t_end - 1, 1);
+    const unsigned ksrc = k_src(t + 2 < t_end ? t + 2 : t_end - 1);
+    const unsigned vsrc0 = v_src(vq ? t + 1 : t_end - 1, 0);
+    const unsigned vsrc1 = v_src(vq ? t + 1 : t_end - 1, 1);
     unsigned char* const kdst = ring + (it & 1) * KTILE_B + wave * 1024;
     unsigned char* const vdst = ring + 2 * KTILE_B + ((it + 1) & 1) * VTILE_B + wave * 1024;
-    auto dma_k = [&](int j) __attribute__((always_inline)) { dma16(ksrc + j * 128, kdst + j * 4096); };
-    auto dma_v = [&](int j) __attribute__((always_inline)) { dma16(((j & 1) ? vsrc1 : vsrc0) + (j >> 1) * 256, vdst + j * 4096); };
+    auto dma_k = [&](int j) __attribute__((always_inline)) { dma16(k_base + (ksrc + j * 128), kdst + j * 4096); };
+    auto dma_v = [&](int j) __attribute__((always_inline)) { dma16(v_base + (((j & 1) ? vsrc1 : vsrc0) + (j >> 1) * 256), vdst + j * 4096); };
     const unsigned k_hi = ring_lds + ((it + 1) & 1) * KTILE_B + k_hi_off;  // K_{t+1}
     const unsigned k_lo = ring_lds + ((it + 1) & 1) * KTILE_B + k_lo_off;
     const unsigned v_ad = ring_lds + (it & 1) * VTILE_B + v_off;            // V_t

@@ -299,6 +299,124 @@ __global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const 
   }
 }
 
+// The same attention cut into pixel slices (round 3): a frame has 30 / 62 groups, so the one-workgroup-per-group kernel above keeps
+// 30 - 62 CUs busy and every wave walks its pixels through 4 + 4 dependent rounds of memory latency (50 / 15 us per call inside the
+// decoder, profiles/r02_m_dcae_decode_1frame_timeline_after.txt).  Here a 4-wave workgroup owns 128 pixels of a group:
+//   launch 1: its partial KV (33 x 32) over those pixels - ONE round of 16 pixel pairs per wave - to `part`;
+//   launch 2: KV = the group's partials added in slice order (fixed order, independent of the batch size: a frame's result does not
+//             depend on what it is batched with), then out / denominator for the same 128 pixels, one 32-pixel tile per wave.
+// 450 / 248 workgroups per frame, one memory round trip per phase.  `part`: B x groups x slices x 33 x 32 floats of caller scratch.
+constexpr int RLA_SL_WAVES = 4;
+constexpr int RLA_SL_PIX = 128;
+
+__global__ __launch_bounds__(RLA_SL_WAVES * 64) void relu_linear_attn_kv_slice_kernel(const float* __restrict__ qkv, float* __restrict__ part,
+                                                                                 int P, int ldq) {
+  __shared__ float red[RLA_SL_WAVES * KV_N];
+  const int g = blockIdx.x, b = blockIdx.y, sl = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int n = lane & 31, h = lane >> 5;
+  const float* base = qkv + static_cast<long long>(b) * P * ldq + g * 96;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ksum = 0.f;
+  constexpr int UN = RLA_SL_PIX / (2 * RLA_SL_WAVES);  // 16 pixel pairs per wave, all 32 loads in flight together
+  float kk[UN], vv[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int p = sl * RLA_SL_PIX + 2 * (wave + u * RLA_SL_WAVES) + h;
+    kk[u] = 0.f;
+    vv[u] = 0.f;
+    if (p < P) {
+      const float* row = base + static_cast<long long>(p) * ldq;
+      kk[u] = fmaxf(row[32 + n], 0.f);
+      vv[u] = row[64 + n];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    ksum += kk[u];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[u], kk[u], acc, 0, 0, 0);
+  }
+  ksum += __shfl_xor(ksum, 32, 64);
+  {
+    float* mine = red + wave * KV_N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r >> 2) * 8 + h * 4 + (r & 3)) * 32 + n] = acc[r];  // KV[c][j = n]
+    if (h == 0) mine[32 * 32 + n] = ksum;
+  }
+  __syncthreads();
+  float* out = part + ((static_cast<long long>(b) * gridDim.x + g) * gridDim.z + sl) * KV_N;
+  for (int e = tid; e < KV_N; e += RLA_SL_WAVES * 64) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < RLA_SL_WAVES; ++w) s_ += red[w * KV_N + e];
+    out[e] = s_;
+  }
+}
+
+__global__ __launch_bounds__(RLA_SL_WAVES * 64) void relu_linear_attn_apply_slice_kernel(const float* __restrict__ qkv, const float* __restrict__ part,
+                                                                                    float* __restrict__ y, int P, int ldq, int ldy, float eps,
+                                                                                    int out_fmt) {
+  __shared__ float kv[KV_N];
+  const int g = blockIdx.x, b = blockIdx.y, sl = blockIdx.z, slices = gridDim.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int n = lane & 31, h = lane >> 5;
+  const float* base = qkv + static_cast<long long>(b) * P * ldq + g * 96;
+  // this wave's 32 pixels: q[p][16 h .. 16 h + 15] (loads issued before the partials are summed)
+  const int p = sl * RLA_SL_PIX + 32 * wave + n;
+  float4 qn[4];
+  {
+    const float* qp = base + static_cast<long long>(p < P ? p : P - 1) * ldq + 16 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qn[i] = *reinterpret_cast<const float4*>(qp + 4 * i);
+  }
+  const float* pg = part + (static_cast<long long>(b) * gridDim.x + g) * slices * KV_N;
+  for (int e = tid; e < KV_N; e += RLA_SL_WAVES * 64) {
+    float s_ = 0.f;
+    for (int i = 0; i < slices; ++i) s_ += pg[static_cast<long long>(i) * KV_N + e];  // slice order: fixed
+    kv[e] = s_;
+  }
+  __syncthreads();
+  if (sl * RLA_SL_PIX + 32 * wave >= P) return;  // (after the only barrier)
+  float ka[16], kd[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    ka[kk] = kv[n * 32 + 16 * h + kk];
+    kd[kk] = kv[32 * 32 + 16 * h + kk];
+  }
+  float q[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q[4 * i] = fmaxf(qn[i].x, 0.f);
+    q[4 * i + 1] = fmaxf(qn[i].y, 0.f);
+    q[4 * i + 2] = fmaxf(qn[i].z, 0.f);
+    q[4 * i + 3] = fmaxf(qn[i].w, 0.f);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) den = fmaf(kd[kk], q[kk], den);
+  den += __shfl_xor(den, 32, 64);
+  const float inv = 1.0f / (den + eps);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk], q[kk], o, 0, 0, 0);  // out^T[c][p = n]
+  if (p < P) {
+    float* yrow = y + (static_cast<long long>(b) * P + p) * ldy;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int ch = g * 32 + 8 * r4 + 4 * h;
+      const float o0 = o[4 * r4] * inv, o1 = o[4 * r4 + 1] * inv, o2 = o[4 * r4 + 2] * inv, o3 = o[4 * r4 + 3] * inv;
+      if (out_fmt != LDC_FMT_F32) ldc_store_fmt4(reinterpret_cast<unsigned char*>(yrow), ch, out_fmt, o0, o1, o2, o3);
+      else *reinterpret_cast<float4*>(yrow + ch) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 // RMSNorm over channels of an NHWC row with weight + bias, then optional residual add and activation:
 //   y = act(x * rsqrt(mean(x^2) + eps) * w + b (+ resid))          (models/DCAE.py:259-260,317-322,371-377,729-730)
 // NV4 float4 per lane hold the row: 4 (C <= 1024: the 84-variable autoencoder's widths) or 8 (C <= 2048: configs/DC_AE_ray_1024.yaml)
@@ -505,12 +623,11 @@ extern "C" int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* 
   return ldc_launch_status();
 }
 
-// (the kernel needs no scratch since round 2: kept for callers that size a workspace; returns 0)
+// scratch of the sliced form (B x groups x ceil(P / 128) partial 33 x 32 matrices); a call with less (or NULL) runs the one-launch
+// kernel, whose sums are taken in another order (same result up to fp32 rounding)
 extern "C" long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups) {
-  (void)B;
-  (void)P;
-  (void)groups;
-  return 0;
+  if (B <= 0 || P <= 0 || groups <= 0) return 0;
+  return static_cast<long long>(B) * groups * ldc_cdiv(P, RLA_SL_PIX) * KV_N * static_cast<long long>(sizeof(float));
 }
 
 extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
@@ -520,8 +637,6 @@ extern "C" int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int 
 
 extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                                              int out_fmt, void* workspace, long long workspace_bytes, void* stream) {
-  (void)workspace;  // unused (may be NULL)
-  (void)workspace_bytes;
   LDC_CHECK_PTR(qkv);
   LDC_CHECK_PTR(y);
   if (B <= 0 || P <= 0 || groups <= 0) return LDC_ERR_ARG;
@@ -531,6 +646,16 @@ extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, 
   if (out_fmt != LDC_FMT_F32 && ((ldy & 7) || (reinterpret_cast<uintptr_t>(y) & 31u))) return LDC_ERR_ALIGN;
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
+  const int slices = ldc_cdiv(P, RLA_SL_PIX);
+  if (workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 && slices <= 65535 &&
+      workspace_bytes >= ldc_relu_linear_attn_workspace_bytes(B, P, groups)) {
+    float* part = static_cast<float*>(workspace);
+    const dim3 grid(groups, B, slices);
+    hipLaunchKernelGGL(relu_linear_attn_kv_slice_kernel, grid, dim3(RLA_SL_WAVES * 64), 0, static_cast<hipStream_t>(stream), qkv, part, P, ldq);
+    hipLaunchKernelGGL(relu_linear_attn_apply_slice_kernel, grid, dim3(RLA_SL_WAVES * 64), 0, static_cast<hipStream_t>(stream), qkv, part, y, P,
+                       ldq, ldy, eps, out_fmt);
+    return ldc_launch_status();
+  }
   const size_t lds = (RLA_WAVES + 1) * KV_N * sizeof(float);  // 71.8 KB
   static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relu_linear_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

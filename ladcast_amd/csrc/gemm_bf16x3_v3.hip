@@ -72,11 +72,6 @@ struct SKArgs {
   float* ws;
   unsigned* counters;  // one per tile
   unsigned upg, urem;  // U / G and U % G: unit range g = [g upg + min(g, urem), ...) - sizes differ by at most one, no division in the kernel
-  // Round-robin tiles (0 = contiguous ranges): workgroup g runs the WHOLE tiles g, g + G, g + 2 G, ... (rr = G kt units apart; upg = kt,
-  // urem = 0).  For launches whose problems have epilogues of different cost - the single block's [MLP up | QKV] launch: 432 tiles
-  // with a GELU epilogue, then 324 with the norm / RoPE / split one, 3 per workgroup - contiguous ranges hand some workgroups three
-  // of the expensive kind; dealt round-robin nobody gets more than two.  An XCD still works on G / 8 consecutive tiles at a time.
-  unsigned rr;
 };
 
 // Round 3: the unit ranges are cut without a division (the kernel's start-up was 2.5 / 5.8 us of scalar code before the first DMA
@@ -437,7 +432,7 @@ __device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm
 // split groups - through the same ring, swizzle and fragment reads; the lane that the split mode hands the hi / lo chunks of k-group
 // g holds k = 8 g .. 8 g + 7 as floats, and MFMA j of a column tile (v_mfma_f32_16x16x4_f32: one float per lane and operand, 4 k per
 // instruction) takes element j of both operands: k = 8 (lane / 16) + j.  8 MFMAs of 32 cycles per column and row tile: the loop is
-// matrix-pipe bound by construction (4096 cycles of MFMA per k-step and wave at 256 rows, against 1536 in the split mode).
+// matrix-pipe bound by construction (2.7x the split mode's MFMA cycles per k-step).  Launched with 128-row tiles only.
 template <int BM, int TERMS, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   constexpr int CPK = TERMS == 1 ? 2 * BK : BK;  // CONV: channels per 128-byte k-step (plain bf16 | split groups, fp32)
@@ -467,8 +462,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
   };
   const long long u_begin = uniform64(range_start(g, a));
-  const unsigned rr = a.rr;
-  const long long u_end = rr ? a.U : uniform64(range_start(g + 1, a));
+  const long long u_end = uniform64(range_start(g + 1, a));
   const unsigned smem_lds = lds_addr(smem);
 
   // One SEGMENT = the k-steps [k0, k1) of one output tile (a whole tile when the unit ranges are tile-aligned).  Its coordinates are
@@ -758,7 +752,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     if (seg_ == 0) { LDC_STAMP(11) }
 #endif
     // the next segment's coordinates, while this one's first two stages are in flight
-    const long long u_next = u + (rr ? static_cast<int>(rr) : k1 - k0);
+    const long long u_next = u + (k1 - k0);
     Seg nxt = cur;
     if (u_next < u_end) nxt = decode(u_next);
     if constexpr (ND == 6) {
@@ -976,12 +970,10 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
   // grid size: as gemm_bf16x3_dma.hip (phase-aligned divisor of tiles * s when every problem has the same k-depth)
   long long G = CUS;
-  bool whole_tiles = false;  // G divides the tile count and every range is a run of whole tiles
   {
     bool same_kt = true;
     for (int i = 1; i < n; ++i) same_kt = same_kt && (a.pr[i].kt == a.pr[0].kt);
     long long best = 0;
-    int best_sfac = 0;
     if (same_kt) {
       const int kt = a.pr[0].kt;
       // more workgroups win unless they are bought with many more pieces per tile (a hand-off each): 2 % per extra split factor.
@@ -996,7 +988,6 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
         if (score > best_score) {
           best_score = score;
           best = gd;
-          best_sfac = sfac;
         }
       }
     }
@@ -1011,7 +1002,6 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
     }
     if (best >= 160) {
       G = best;
-      whole_tiles = best_sfac == 1;
     } else if (few > 0) {
       G = few;  // measured on 1800 x 84 x 1536: 24.7 us at the stream-K default (36 ranges), 18.0 at 90
     } else {
@@ -1041,19 +1031,6 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   a.upg = static_cast<unsigned>(U / G);
   a.urem = static_cast<unsigned>(U % G);
   a.tiles = tiles;
-  {
-    // round-robin whole tiles (SKArgs::rr): a launch that mixes the QKV epilogue with plain ones, cut into whole tiles, >= 2 per range
-    bool mixed = false;
-    if (epi != nullptr)
-      for (int i = 1; i < n; ++i) mixed = mixed || ((epi[i].heads > 0) != (epi[0].heads > 0));
-    bool on = mixed && whole_tiles && !force_g && tiles % G == 0 && tiles / G >= 2 && U == tiles * a.pr[0].kt;
-    if (const char* e = getenv("LDC_BF16X3_RR")) on = on && atoi(e) != 0;  // measurement aid, read per call: 0 = contiguous ranges
-    if (on) {
-      a.upg = static_cast<unsigned>(a.pr[0].kt);
-      a.urem = 0;
-      a.rr = static_cast<unsigned>(G) * a.upg;
-    }
-  }
   a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
   a.counters = static_cast<unsigned*>(workspace);
   const size_t lds = NSTAGE * STAGE_B + 8 * 1024;  // ring + one 1 KiB dump slot per wave
@@ -1106,17 +1083,14 @@ int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* wor
   // what the register-staged kernel accepts and this one does not goes there, not back to the caller as an error
   if (!al16(workspace) || workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2ll * 256 * BN * static_cast<long long>(sizeof(float)))
     return LDC_ERR_UNSUPPORTED;
-  long long tiles256 = 0;
   for (int i = 0; i < n; ++i) {
     const ldc_gemm_desc& d = problems[i].d;
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0) return LDC_ERR_ARG;
     if (!al16(problems[i].A) || !al16(problems[i].W)) return LDC_ERR_UNSUPPORTED;
-    tiles256 += static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN);
   }
-  // a tile takes ~2.7x the split kernel's time: keep more, smaller tiles for balance until the chip is filled several times over
-  const bool small = tiles256 < 800;
-  return small ? launch_v3<128, 0>(problems, nullptr, n, workspace, workspace_bytes, stream)
-               : launch_v3<256, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
+  // 128-row tiles only: a tile is 2.7x the split kernel's MFMA time, so balance matters more than the halved W traffic per FLOP of
+  // the 256-row tile (375M model in fp32 mode, same box: 113.6 TFLOP/s against 111.0 with 256 rows forced; profiles/r03_j_*)
+  return launch_v3<128, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
 }
 
 int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,

@@ -538,11 +538,16 @@ def grouped_conv1x1_nhwc(x, wt, y, *, M, groups, ldx, ldy):
     _check(lib.ldc_grouped_conv1x1_nhwc(_p(x), _p(wt), _p(y), M, groups, ldx, ldy, _stream()), "ldc_grouped_conv1x1_nhwc")
 
 
-def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F32):
-    """ReLU linear attention over consecutive 96-channel (q | k | v) groups; one launch, no scratch (ldc_relu_linear_attn_workspace_bytes
-    is 0 since round 2)"""
+def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F32, sliced=True):
+    """ReLU linear attention over consecutive 96-channel (q | k | v) groups.  sliced (default): 128-pixel slices, partial KV matrices
+    in a scratch buffer of ldc_relu_linear_attn_workspace_bytes, two launches; sliced=False: one workgroup per (frame, group)"""
     _dev(qkv, y)
-    _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), None, 0, _stream()),
+    ws, nbytes = None, 0
+    if sliced:
+        nbytes = lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups)
+        ws = torch.empty(nbytes // 4, device=qkv.device, dtype=torch.float32)
+    _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), _p(ws), nbytes,
+                                             _stream()),
            "ldc_relu_linear_attn_nhwc_fmt")
 
 

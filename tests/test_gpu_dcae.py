@@ -118,6 +118,19 @@ def test_linear_attention_and_grouped_conv():
     out = (v @ k.transpose(-1, -2)) @ q
     want = (out[:, :, :-1] / (out[:, :, -1:] + 1e-15)).reshape(B, groups * 32, P).permute(0, 2, 1)
     assert rel_l2(y.cpu(), want) < 2e-6
+    # round 3: the default form cuts a group's pixels into 128-pixel slices (two launches, partial KV matrices in scratch); the one-launch
+    # form (a caller without scratch) sums in another order: equal to fp32 rounding.  The sliced order only depends on P: a frame's
+    # result is bitwise the same alone and inside a batch; P not a multiple of 128 / of 32 / below one slice
+    for B2, P2, g2 in ((1, 1800, 5), (3, 450, 4), (2, 77, 3), (1, 129, 2)):
+        q2 = rnd(B2, P2, g2 * 96, seed=5).cuda()
+        ya = torch.full((B2, P2, g2 * 32), float("nan"), device="cuda")
+        yb = torch.full((B2, P2, g2 * 32), float("nan"), device="cuda")
+        hip.relu_linear_attn_nhwc(q2, ya, B=B2, P=P2, groups=g2, ldq=g2 * 96, ldy=g2 * 32, eps=1e-15)
+        hip.relu_linear_attn_nhwc(q2, yb, B=B2, P=P2, groups=g2, ldq=g2 * 96, ldy=g2 * 32, eps=1e-15, sliced=False)
+        assert torch.isfinite(ya).all() and rel_l2(ya.cpu(), yb.cpu()) < 2e-6
+        y1 = torch.empty(1, P2, g2 * 32, device="cuda")
+        hip.relu_linear_attn_nhwc(q2[B2 - 1 :].contiguous(), y1, B=1, P=P2, groups=g2, ldq=g2 * 96, ldy=g2 * 32, eps=1e-15)
+        assert torch.equal(y1[0], ya[B2 - 1])
     M, G = 77, 5
     x, w = rnd(M, G * 32, seed=2), rnd(G * 32, 32, seed=3)
     y = torch.empty(M, G * 32, device="cuda")

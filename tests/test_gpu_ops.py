@@ -279,7 +279,7 @@ def test_gemm_fp32_streamk_inlaunch_reduction_is_deterministic_and_rearmed(hip):
 def test_gemm_fp32_ring_kernel_vs_register_staged_kernel(hip, monkeypatch):
     """round 3: exact-fp32 problems with K % 32 == 0, contiguous weights and 16-byte rows run on the LDS-DMA ring kernel (fp32 operand
     rows, v_mfma_f32_16x16x4_f32); LDC_F32_RING=0 (read per call) keeps them on the register-staged stream-K kernel.  Both against
-    fp64 and against each other: ragged M / N, both tile heights, batches, every epilogue term, C as a strided slab, in-place residual."""
+    fp64 and against each other: ragged M / N, batches, every epilogue term, C as a strided slab, in-place residual."""
     cases = [(2250, 1536, 1536, 1, 0), (300, 260, 128, 2, 2), (4500, 4608, 1536, 1, 1), (77, 96, 6144, 1, 3), (1800, 84, 1536, 2, 0),
              (9000, 6144, 1536, 1, 2)]
     for i, (M, N, K, B, act) in enumerate(cases):
@@ -799,35 +799,6 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     hip.attn_fwd_split(qkv[:, :, :D], qkv[:, :, D : 2 * D], qkv[:, :, 2 * D :], out_fb, B=batch, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D)
     assert rel(out_fb, want) < 2e-5 and rel(out_fb, out.double().cpu()) < 1e-5
     assert rel(mlp, F.gelu(A.double() @ Wm.double().T + bm.double(), approximate="tanh")) < 1e-5
-
-
-def test_gemm_mixed_epilogue_launch_round_robin_tiles_is_bitwise_the_contiguous_order(hip, monkeypatch):
-    """round 3: the single block's [MLP up | QKV] launch at the 375M shape (432 + 324 whole tiles on 252 workgroups) deals its tiles
-    round-robin (SKArgs::rr) so that no workgroup gets three of the expensive QKV epilogues; LDC_BF16X3_RR=0 keeps contiguous
-    ranges.  Same tiles, same arithmetic per tile: bitwise the same outputs; and a shape whose tile count the grid does not divide."""
-    for S, H in ((2250, 12), (2250 - 256, 12), (700, 2)):
-        D, K, Fh = H * 128, 1536, 4 * H * 128
-        A = rnd(S, K, seed=1)
-        Wq, bq = rnd(3 * D, K, seed=2) / math.sqrt(K), rnd(3 * D, seed=4) * 0.1
-        Wm, bm = rnd(Fh, K, seed=6) / math.sqrt(K), rnd(Fh, seed=7)
-        wq, wk = [1 + 0.1 * rnd(128, seed=s_) for s_ in (12, 13)]
-        cos, sin = L.get_1d_rotary_pos_embed(128, torch.arange(S).float() * 0.37, 256.0)
-        Ap = hip.pack_weight_bf16x2(dev(A))
-        Wqp, Wmp, rope = hip.pack_weight_bf16x2(dev(Wq)), hip.pack_weight_bf16x2(dev(Wm)), hip.compact_rope_table(dev(cos), dev(sin))
-        f, res = hip.GEMM_A_SPLIT, {}
-        for rr in ("1", "0"):
-            monkeypatch.setenv("LDC_BF16X3_RR", rr)
-            qkv = torch.full((S, 3 * D), float("nan"), device="cuda")
-            mlp = torch.full((S, Fh), float("nan"), device="cuda")
-            hip.gemm_grouped_qkv([hip.gemm_problem(Ap, Wmp, mlp, M=S, N=Fh, K=K, bias=dev(bm), act=hip.ACT_GELU_TANH, flags=f | hip.GEMM_C_SPLIT),
-                                  hip.gemm_problem(Ap, Wqp, qkv, M=S, N=3 * D, K=K, bias=dev(bq), flags=f)],
-                                 [None, hip.qkv_epilogue(dev(wq), dev(wk), rope, eps=1e-7, heads=H)])
-            res[rr] = (qkv.view(torch.int32).cpu(), mlp.view(torch.int32).cpu())
-        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), (S, H)
-        hi, lo = _unsplit(mlp, S, Fh)
-        assert rel(hi + lo, F.gelu(A.double() @ Wm.double().T + bm.double(), approximate="tanh")) < 1e-5
-    ws = hip._grouped_workspace(torch.device("cuda:0"))
-    assert int(ws.view(torch.int32)[: (1 << 20) // 4].abs().sum().item()) == 0
 
 
 # -- launch merges: each fused launch is bit-identical to the two launches it replaces ---------------------------------------------------
