@@ -93,9 +93,12 @@ int ldc_gemm_bias_act(const float* A, const float* W, const float* bias, const f
                       const float* R, float* C, const ldc_gemm_desc* d, void* stream);
 
 /* Same contraction for up to LDC_GEMM_MAX_PROBLEMS independent problems in ONE persistent launch
- * with stream-K scheduling (work = (tile, 32-deep k-step) units cut into equal contiguous ranges,
- * 2 workgroups per CU); tiles whose K range was split are summed INSIDE the launch by the piece that
- * arrives last, in workgroup order (bitwise reproducible; no second launch since ABI 2).  Built for the
+ * with stream-K scheduling (work = (tile, 32-deep k-step) units cut into equal contiguous ranges);
+ * tiles whose K range was split are summed INSIDE the launch by the piece that arrives last, in
+ * workgroup order (bitwise reproducible; no second launch since ABI 2).  Problems with K % 32 == 0,
+ * ldw == K, lda % 4 == 0 and 16-byte aligned A / W run on the LDS-DMA ring kernel (fp32 operand rows,
+ * v_mfma_f32_16x16x4_f32, one workgroup per CU); the others - same results up to the summation
+ * order - on the register-staged kernel (2 workgroups per CU).  Exact fp32 products either way.  Built for the
  * small grids of the AR transformer (e.g. the pred- and cond-stream projections of a dual block,
  * models/LaDCast_3D_model.py:92-94,175-177,558-563).  `workspace` is caller-owned device scratch of
  * at least ldc_gemm_grouped_workspace_bytes() bytes (16-byte aligned), initialised ONCE with
@@ -348,8 +351,8 @@ int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* y, long lon
  * y[B][P][groups*32] (models/DCAE.py:158-175,239-253; fp32, eps 1e-15). */
 int ldc_relu_linear_attn_nhwc(const float* qkv, float* y, int B, int P, int groups, int ldq, int ldy, float eps,
                               void* workspace, long long workspace_bytes, void* stream);
-/* Both contractions on the fp32 matrix core (exact fp32 products).  With `workspace` >= ldc_relu_linear_attn_workspace_bytes(B, P,
- * groups) bytes (16-byte aligned): two launches over 128-pixel slices - partial KV matrices (33 x 32 per slice) to the workspace,
+/* Both contractions on the fp32 matrix core (exact fp32 products).  P >= 1024 and `workspace` >= ldc_relu_linear_attn_workspace_bytes(B, P,
+ * groups) bytes (16-byte aligned; 0 bytes for P < 1024): two launches over 128-pixel slices - partial KV matrices (33 x 32 per slice) to the workspace,
  * then KV = the partials added in slice order and the output of the same pixels; the order only depends on P, so a frame's result
  * does not depend on the batch it is in (bitwise reproducible).  With a NULL / smaller workspace: one launch, a 16-wave workgroup
  * per (batch, group), partials added in wave order - the same result up to fp32 rounding. */

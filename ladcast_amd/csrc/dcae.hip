@@ -308,6 +308,7 @@ __global__ __launch_bounds__(RLA_WAVES * 64) void relu_linear_attn_kernel(const 
 // 450 / 248 workgroups per frame, one memory round trip per phase.  `part`: B x groups x slices x 33 x 32 floats of caller scratch.
 constexpr int RLA_SL_WAVES = 4;
 constexpr int RLA_SL_PIX = 128;
+constexpr int RLA_SLICED_MIN_P = 1024;
 
 __global__ __launch_bounds__(RLA_SL_WAVES * 64) void relu_linear_attn_kv_slice_kernel(const float* __restrict__ qkv, float* __restrict__ part,
                                                                                  int P, int ldq) {
@@ -374,10 +375,32 @@ __global__ __launch_bounds__(RLA_SL_WAVES * 64) void relu_linear_attn_apply_slic
     for (int i = 0; i < 4; ++i) qn[i] = *reinterpret_cast<const float4*>(qp + 4 * i);
   }
   const float* pg = part + (static_cast<long long>(b) * gridDim.x + g) * slices * KV_N;
-  for (int e = tid; e < KV_N; e += RLA_SL_WAVES * 64) {
-    float s_ = 0.f;
-    for (int i = 0; i < slices; ++i) s_ += pg[static_cast<long long>(i) * KV_N + e];  // slice order: fixed
-    kv[e] = s_;
+  {
+    // KV = the partials in slice order.  All loads of 16 slices x this thread's 5 elements are in flight together (a dependent
+    // load-add chain per element made this the longest part of the launch: 24 us at 15 slices)
+    constexpr int NE = (KV_N + RLA_SL_WAVES * 64 - 1) / (RLA_SL_WAVES * 64);  // 5
+    float acc_[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) acc_[j] = 0.f;
+    for (int i0 = 0; i0 < slices; i0 += 16) {
+      float v_[NE][16];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int e = tid + j * RLA_SL_WAVES * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          v_[j][i] = (e < KV_N && i0 + i < slices) ? pg[static_cast<long long>(i0 + i) * KV_N + e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NE; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_[j] += v_[j][i];  // fixed order; the padding zeros do not change a sum
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + j * RLA_SL_WAVES * 64;
+      if (e < KV_N) kv[e] = acc_[j];
+    }
   }
   __syncthreads();
   if (sl * RLA_SL_PIX + 32 * wave >= P) return;  // (after the only barrier)
@@ -626,7 +649,7 @@ extern "C" int ldc_grouped_conv1x1_nhwc(const float* x, const float* wt, float* 
 // scratch of the sliced form (B x groups x ceil(P / 128) partial 33 x 32 matrices); a call with less (or NULL) runs the one-launch
 // kernel, whose sums are taken in another order (same result up to fp32 rounding)
 extern "C" long long ldc_relu_linear_attn_workspace_bytes(int B, int P, int groups) {
-  if (B <= 0 || P <= 0 || groups <= 0) return 0;
+  if (B <= 0 || P < RLA_SLICED_MIN_P || groups <= 0) return 0;  // below: the one-launch kernel, no scratch
   return static_cast<long long>(B) * groups * ldc_cdiv(P, RLA_SL_PIX) * KV_N * static_cast<long long>(sizeof(float));
 }
 
@@ -647,7 +670,9 @@ extern "C" int ldc_relu_linear_attn_nhwc_fmt(const float* qkv, float* y, int B, 
   LDC_CHECK_ALIGN16(qkv);
   LDC_CHECK_ALIGN16(y);
   const int slices = ldc_cdiv(P, RLA_SL_PIX);
-  if (workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 && slices <= 65535 &&
+  // sliced only where a group has enough pixels to pay for the second launch (measured at one frame, back to back: 1800 pixels 40.3 ->
+  // 20.5 us, 450 pixels 10.8 -> 13.7 us); the rule looks at P alone, so a frame's result does not depend on its batch
+  if (P >= RLA_SLICED_MIN_P && workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 && slices <= 65535 &&
       workspace_bytes >= ldc_relu_linear_attn_workspace_bytes(B, P, groups)) {
     float* part = static_cast<float*>(workspace);
     const dim3 grid(groups, B, slices);

@@ -544,8 +544,8 @@ def relu_linear_attn_nhwc(qkv, y, *, B, P, groups, ldq, ldy, eps, out_fmt=FMT_F3
     _dev(qkv, y)
     ws, nbytes = None, 0
     if sliced:
-        nbytes = lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups)
-        ws = torch.empty(nbytes // 4, device=qkv.device, dtype=torch.float32)
+        nbytes = lib.ldc_relu_linear_attn_workspace_bytes(B, P, groups)  # 0 below 1024 pixels: one launch there
+        ws = torch.empty(nbytes // 4, device=qkv.device, dtype=torch.float32) if nbytes else None
     _check(lib.ldc_relu_linear_attn_nhwc_fmt(_p(qkv), _p(y), B, P, groups, ldq, ldy, eps, int(out_fmt), _p(ws), nbytes,
                                              _stream()),
            "ldc_relu_linear_attn_nhwc_fmt")
