@@ -25,4 +25,4 @@ for i in range(n):
     if not torch.equal(run(k, 3 * k), ref[k]):
         bad += 1
 dt = time.time() - t0
-print(f"{prec}: {n} chunk replays ({39 * n} forwards, {39 * 52 * n} kernel launches) in {dt:.0f} s, {1e3 * dt / n:.1f} ms each: {bad} mismatching replays")
+print(f"{prec}: {n} chunk replays ({39 * n} forwards, {(39 * 36 + 20) * n} kernel launches) in {dt:.0f} s, {1e3 * dt / n:.1f} ms each: {bad} mismatching replays")
