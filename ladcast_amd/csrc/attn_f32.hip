@@ -19,6 +19,10 @@
 // The softmax scale 1/sqrt(128) and log2(e) are folded into Q once; exp2 is used.
 // K/V tiles are staged HBM -> VGPR -> LDS double-buffered (66 KiB -> 2 workgroups / CU);
 // the K tile uses a 132-float pitch (conflict-free for the b128 lane groups).
+// NGRP = 2 (round 3, grids of at most 256 workgroups - one member of the 375M model has 216): the workgroup is 8 waves, waves 0-3 sweep
+// the first half of the key tiles and waves 4-7 the second, each group through its own double buffer (133 KiB, one workgroup per CU),
+// merged through LDS at the end - as in attn_split.hip.  With one 4-wave workgroup per CU every SIMD held a single wave, whose MFMAs
+// waited for its own softmax and LDS traffic (0.59 of the fp32 matrix peak); two waves per SIMD overlap them.
 #include "common.h"
 
 namespace {
@@ -41,9 +45,12 @@ struct AttnArgs {
   const float* kbias;  // additive per-key score bias (an SDPA float mask that only depends on the key), [S] or nullptr
 };
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
+template <int NGRP>
+__global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 8) : 0;  // key-range group (wave-uniform)
+  float* const smem = smem_all + grp * 2 * STAGE;
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int half = lane >> 5;
@@ -125,13 +132,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
   float l_run = 0.f;
 
   const int nt = (S + KT - 1) / KT;
-  gload(0);
-  sstore(0);
+  const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
+  const int t_begin = grp ? nhalf : 0;
+  const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
+  if (t_begin < t_end) {
+    gload(t_begin * KT);
+    sstore(0);
+  }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) gload((t + 1) * KT);
-    const float* Ks = smem + (t & 1) * STAGE;
+  for (int it = 0; it < nhalf; ++it) {
+    const int t = t_begin + it;
+    if (t >= t_end) {  // (wave-uniform) the shorter group only keeps the barrier count
+      __syncthreads();
+      continue;
+    }
+    if (t + 1 < t_end) gload((t + 1) * KT);
+    const float* Ks = smem + (it & 1) * STAGE;
     const float* Vs = Ks + KT * KP;
 
     // ---- S^T = K . Q^T ------------------------------------------------------
@@ -198,8 +215,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnArgs p) {
       }
     }
 
-    if (t + 1 < nt) sstore((t + 1) & 1);
+    if (t + 1 < t_end) sstore((it + 1) & 1);
     __syncthreads();
+  }
+
+  // ---- merge the two key halves: group 1 hands (m, l, O) to group 0 through LDS (the rings are idle: barrier above) ----
+  if constexpr (NGRP == 2) {
+    float* xch = smem_all + tid;  // [66][256]
+    if (grp == 1) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 256] = o[d][r];
+      xch[64 * 256] = m_run;
+      xch[65 * 256] = l_run;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = xch[64 * 256], l1 = xch[65 * 256];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(d * 16 + r) * 256] * a1;
   }
 
   // ---- normalise and store: lane holds O[q0+l31][32d + 8g + 4half + (0..3)] in o[d][4g..4g+3]
@@ -237,13 +277,18 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
   p.nq = ldc_cdiv(S, QB);
   p.kbias = key_bias;
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
-  const size_t lds = 2 * STAGE * sizeof(float);
+  // at most one workgroup per CU anyway -> 8 waves with the keys split over two wave groups; more -> 4 waves, two workgroups per CU
+  const bool two = grid.x <= 256 && getenv("LDC_ATTN_F32_ONE_GROUP") == nullptr;  // (env: measurement aid, read per call)
+  const size_t lds = (two ? 4 : 2) * STAGE * sizeof(float);
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(2 * STAGE * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(4 * STAGE * sizeof(float)));
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  if (two) hipLaunchKernelGGL(attn_fwd_f32_kernel<2>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_fwd_f32_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
 }
