@@ -256,6 +256,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; nccl (= RCCL over xGMI) is the real one, "
                     "gloo only lets the N > 1 code path be dry-run on a box with fewer GPUs than ranks")
     ap.add_argument("--share-gpus", action="store_true", help="dry-run aid: map ranks onto the available GPUs modulo their count")
+    ap.add_argument("--host-outputs", action="store_true", help="A/B aid: return every step's latents on the host as the reference's roll_out_serial does (one device "
+                    "-> host copy + synchronise per step) instead of leaving them in HBM")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying one captured hipGraph per model forward "
                     "(graph replay keeps the GPU fed regardless of host speed; kernels and numerics are identical)")
     ap.add_argument("--decode", action="store_true", help="secondary workload (BASELINE configs[4]): encode the IC field with the DCAE, roll out, DECODE "
@@ -315,6 +317,9 @@ def main():
     m = len(member_ids)  # this rank's members: --members-per-gpu (weak) or its share of the fixed ensemble (strong; may be 0)
     R, lead = args.return_seq_len, args.lead_steps
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).to(dev)  # IC latent, resident in HBM
+    # results stay in HBM (with N > 1 the one collective gathers them there): no host copy and therefore no host stall per step - the host
+    # prepares step k + 1 (noise draw, timestamps) while the GPU still runs step k; the timed region ends with a synchronise as the contract says
+    out_dev = None if args.host_outputs else dev
     targs = {"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5}
     from ladcast_amd.pipelines.distributed import gather_members
 
@@ -333,13 +338,13 @@ def main():
             return roll_out_serial(
                 lambda t: field, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
                 latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=False,
-                member_ids=member_ids, **dec_kw)
+                member_ids=member_ids, output_device=out_dev, **dec_kw)
 
     def step_local():
         return roll_out_serial(
             None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
             latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
-            known_latents_override=ic, member_ids=member_ids,
+            known_latents_override=ic, member_ids=member_ids, output_device=out_dev,
         )
 
     def step():
@@ -348,10 +353,10 @@ def main():
         out = roll_out_serial(
             None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
             latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
-            known_latents_override=ic, member_ids=member_ids,
+            known_latents_override=ic, member_ids=member_ids, output_device=out_dev,
         )
         if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
-            out = gather_members(out.to(dev) if args.backend == "nccl" else out, total_members, member_dim=1)
+            out = gather_members(out.to(dev) if args.backend == "nccl" else out.to("cpu"), total_members, member_dim=1)
         return out
 
     def fence():
@@ -365,13 +370,19 @@ def main():
     timer = KernelTimer()
     fence()
     t0 = time.perf_counter()
-    marks = []
+    marks, evs = [], [torch.cuda.Event(enable_timing=True)]
+    evs[0].record()
     for _ in range(args.steps):
         step()
-        marks.append(time.perf_counter())  # every step returns host tensors, i.e. is complete here: no extra synchronisation
+        marks.append(time.perf_counter())  # --host-outputs: every step returns host tensors, i.e. is complete here
+        evs.append(torch.cuda.Event(enable_timing=True))
+        evs[-1].record()  # device outputs: the host runs ahead; the step boundaries are read from the stream afterwards
     fence()
     elapsed = time.perf_counter() - t0
-    step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
+    if out_dev is None:
+        step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
+    else:
+        step_ms = [round(a.elapsed_time(b), 2) for a, b in zip(evs[:-1], evs[1:])]
     if world > 1:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -523,6 +534,9 @@ def main():
                                       "0.026 of the 0.979 TFLOP and 17 of the 52 launches of a 375M forward) runs once per chunk as ONE batch over the chunk's "
                                       f"{args.solver_steps} noise levels, inside the timed region, every chunk; --no-batched-conditioning runs it per evaluation")
                 if model.batch_conditioning else "per network evaluation (as the reference)",
+                "outputs": ("left in HBM (with N > 1: gathered there); no per-step host copy, so the host prepares step k + 1 while the GPU runs step k - the "
+                            "timed region ends with barrier + synchronise (two alternating instances of the captured chunk); --host-outputs copies every step's result to the host as the reference's "
+                            "roll_out_serial does") if out_dev is not None else "copied to the host after every step (as the reference)",
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
             "other_sampler": other_sampler,

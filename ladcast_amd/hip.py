@@ -143,6 +143,16 @@ def _check(status: int, what: str):
         raise RuntimeError(f"{what} failed with status {status}")
 
 
+def upload_nonblocking(t, device):
+    """host -> device without stalling the host: a pageable source makes the copy synchronous, i.e. the host would wait for everything
+    queued on the stream - the previous sampler chunk - before it can prepare the next one.  Pinned source + non_blocking: the copy
+    is only stream-ordered (torch's pinned-memory allocator does not hand the block out again before the copy has run)."""
+    device = torch.device(device)
+    if device.type != "cuda" or t.device.type != "cpu":
+        return t.to(device)
+    return (t if t.is_pinned() else t.pin_memory()).to(device, non_blocking=True)
+
+
 def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 

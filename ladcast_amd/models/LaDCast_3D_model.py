@@ -508,9 +508,16 @@ class LaDCastTransformer3DModel(ModelMixin):
         key = (time_elapsed.data_ptr(), time_elapsed._version, tuple(time_elapsed.shape), str(time_elapsed.device))
         if self._te_cache is not None and self._te_cache[0] == key:
             return self._te_cache[1]
-        stamps = [int(v) for v in time_elapsed.reshape(-1).tolist()]  # host sync once per chunk (reference: every call)
+        # the timestamps are needed on the HOST (calendar arithmetic).  Reading a device tensor back stalls the host until everything queued
+        # on the stream - the previous sampler chunk - has run; callers that made the tensor from host integers attach them as
+        # `tensor.host_values` (pipelines/utils.py does) and no read-back happens.  Reference: a `.item()` sync in every forward.
+        stamps = getattr(time_elapsed, "host_values", None)
+        if stamps is None or len(stamps) != time_elapsed.numel():
+            stamps = time_elapsed.reshape(-1).tolist()
+        stamps = [int(v) for v in stamps]
         n, d2 = len(stamps), 2 * self.inner_dim
-        emb = get_year_sincos_embedding(stamps, 256).to(dev)
+        emb = get_year_sincos_embedding(stamps, 256)
+        emb = hip.upload_nonblocking(emb, dev)  # no host stall either
         te = self.time_elapsed_embed
         if n not in self._te_buf:  # persistent buffers: a captured graph keeps reading the same addresses
             self._te_buf[n] = (torch.empty(n, d2, device=dev, dtype=torch.float32), torch.empty(n, d2, device=dev, dtype=torch.float32))

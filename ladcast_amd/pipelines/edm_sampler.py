@@ -50,7 +50,8 @@ def edm_AR_sampler(
     latents = randn_tensor(shape, generator=generator, device=device, dtype=net.dtype).contiguous()
     noise_scheduler.set_timesteps(num_inference_steps, device=device)
     t_steps = noise_scheduler.sigmas  # (N+1,) fp32 on the host
-    c_noise = noise_scheduler.precondition_noise(t_steps[:-1]).to(device)  # (N,) fed to the model as (1,) views
+    # (N,) fed to the model as (1,) views; a captured chunk holds its own device copy, so the upload happens on the paths that need it
+    c_noise_host = noise_scheduler.precondition_noise(t_steps[:-1])
     known = known_latents.to(device)
     if known.shape[0] != batch_size:
         known = known.expand(batch_size, *known.shape[1:])
@@ -82,12 +83,18 @@ def edm_AR_sampler(
         prepare = net.prepare_conditioning if batched else None
         key = ("edm_chunk",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
+        # TWO instances of the captured chunk, used alternately: launching an executable graph that is still running blocks the host
+        # until it has finished, and the GPU then idles through the ~0.4 ms the launch call takes to build its packets; the other
+        # instance is queued behind the running one instead (same stream: they never overlap on the GPU, and share the workspaces)
+        turn = cache.get(key + ("turn",), 0)
+        cache[key + ("turn",)] = turn ^ 1
+        key = key + (turn,)
         ent = cache.get(key)
         if ent is None:
             st_lat, st_known, st_out = torch.empty_like(latents), torch.empty_like(known), torch.empty(shape, device=device, dtype=torch.float32)
             st_lat.copy_(latents)
             st_known.copy_(known)
-            cn = c_noise.clone()
+            cn = c_noise_host.to(device)
             side = net.capture_stream() if hasattr(net, "capture_stream") else torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):  # warm-up on the capture stream: per-stream workspaces are created here
@@ -105,6 +112,7 @@ def edm_AR_sampler(
         return st_out.clone()
 
     out = torch.empty(shape, device=device, dtype=torch.float32)
+    c_noise = hip.upload_nonblocking(c_noise_host, device)
     fwd = lambda x, t, k, te_, ci=None: net(x, t, k, time_elapsed=timestamps, **({} if ci is None else {"conditioning": ci})).sample  # noqa: E731
     prepare = None
     if batched:

@@ -7,22 +7,35 @@ from __future__ import annotations
 
 import torch
 
+from .. import hip
+
 
 def randn_tensor(shape, generator=None, device=None, dtype=None):
     with few_host_threads():
         return _randn_tensor(shape, generator, device, dtype)
 
 
+_upload = hip.upload_nonblocking
+
+
 def _randn_tensor(shape, generator=None, device=None, dtype=None):
     device = torch.device(device) if device is not None else torch.device("cpu")
     batch = shape[0]
+    pin = device.type == "cuda"
     if isinstance(generator, list) and len(generator) == 1:
         generator = generator[0]
     if isinstance(generator, list):
+        if all(g.device.type == "cpu" for g in generator):  # one (1, ...) draw per generator, written into one (pinned) host buffer
+            buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=pin)
+            for i in range(batch):
+                torch.randn((1,) + tuple(shape[1:]), generator=generator[i], dtype=dtype, out=buf[i : i + 1])
+            return _upload(buf, device)
         one = (1,) + tuple(shape[1:])
         parts = [torch.randn(one, generator=generator[i], device=generator[i].device, dtype=dtype) for i in range(batch)]
         return torch.cat(parts, dim=0).to(device)
     rand_device = generator.device if generator is not None else device
+    if rand_device.type == "cpu":
+        return _upload(torch.randn(tuple(shape), generator=generator, dtype=dtype, pin_memory=pin), device)
     return torch.randn(tuple(shape), generator=generator, device=rand_device, dtype=dtype).to(device)
 
 

@@ -44,14 +44,39 @@ def convert_datetime_to_int(dt) -> int:
 
 
 # -- per-channel latent / field transforms (dataloader/utils.py:223-269) on the device ----------
+_host_to_device = hip.upload_nonblocking
+
+
+# results of a rollout are collected on the GPU and copied to the host ONCE at the end while they fit this many bytes: a per-chunk
+# `.to("cpu")` stalls the host on every chunk, and the GPU then idles through the host's preparation of the next one (~1 ms of 111)
+DEVICE_OUTPUT_MAX_BYTES = 8 << 30
+
+
+_vector_cache: Dict = {}
+
+
+def _device_vector(v, dev):
+    """per-channel statistics as an fp32 device vector.  Host values (the lists of the reference's JSON) are uploaded once per
+    (device, values) and kept: a fresh pageable upload per call is a synchronous copy, i.e. a host stall on the previous chunk."""
+    if isinstance(v, torch.Tensor) and v.device.type != "cpu":
+        return v.to(dev, torch.float32)
+    host = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+    key = (str(dev), host.numpy().tobytes())
+    hit = _vector_cache.get(key)
+    if hit is None:
+        if len(_vector_cache) >= 64:
+            _vector_cache.clear()
+        hit = _vector_cache[key] = host.to(dev)
+    return hit
+
+
 def _chan_affine(x, mean, std, target_std, inverse):
     """x: (C, T, H, W) or (B, C, T, H, W) contiguous fp32 device tensor."""
     x = x.contiguous()
     if x.numel() == 0:  # a rank that owns no members: nothing to launch
         return torch.empty_like(x)
     dev = x.device
-    mean = torch.as_tensor(mean, dtype=torch.float32).to(dev)
-    std = torch.as_tensor(std, dtype=torch.float32).to(dev)
+    mean, std = _device_vector(mean, dev), _device_vector(std, dev)
     C = mean.numel()
     cdim = 0 if x.dim() == 4 else 1
     assert x.shape[cdim] == C
@@ -202,6 +227,7 @@ def roll_out_serial(
     known_latents_override: Optional[torch.Tensor] = None,
     raw_input_fields: Optional[Callable[[datetime], torch.Tensor]] = None,
     ic_noise_seed: Optional[int] = None,
+    output_device=None,
     **_ignored,  # e.g. log_pred_interval_hour, which the reference CLI passes (evaluate/pred_rollout.py:384, Q2)
 ) -> torch.Tensor:
     """Tensor mode of pipelines/utils.py:249-661.
@@ -222,6 +248,9 @@ def roll_out_serial(
     (:518-528).  ``ic_noise_seed=None`` draws that perturbation from torch's global RNG as the reference does; an integer draws it
     from a CPU generator seeded with ``ic_noise_seed + YYYYMMDDHH`` of the initial time, so that every call that touches this initial
     time - e.g. the pieces of one forecast cut over several ranks (``pipelines/distributed.py``) - perturbs it identically.
+    ``output_device`` (extension; default: the host, as the reference): where the result tensor is returned.  A CUDA device returns it
+    WITHOUT synchronising - the caller's next call then prepares its inputs while this one still runs on the GPU (``bench.py``, and the
+    sharded driver, whose gather runs on the device anyway).
     """
     if not return_tensor:
         raise NotImplementedError("xarray output is out of scope; use return_tensor=True")
@@ -263,9 +292,12 @@ def roll_out_serial(
                 c_out = encdec_model.config.out_channels - encdec_model.config.static_channels
                 hw = field_hw if field_hw is not None else tuple(s * encdec_model.spatial_compression_ratio for s in known.shape[-2:])
                 shape = (len(pred_timestamp), return_size, c_out, total + 1, *hw)
-            out = torch.full(shape, float("nan"), dtype=torch.float32, device="cpu")
+            # collected where the sampler runs (one copy to the host at the end) unless that would hold too much device memory
+            nbytes = 4 * math.prod(shape)
+            acc = torch.device(dev) if (torch.device(dev).type == "cuda" and nbytes <= DEVICE_OUTPUT_MAX_BYTES) else torch.device("cpu")
+            out = torch.full(shape, float("nan"), dtype=torch.float32, device=acc)
         if return_latent:
-            out[pi, :, :, 0] = known[:, -1].to("cpu").unsqueeze(0).expand(return_size, -1, -1, -1)
+            out[pi, :, :, 0] = known[:, -1].to(acc).unsqueeze(0).expand(return_size, -1, -1, -1)
         elif field_hw is not None:  # raw IC field in slot 0 (:462-468)
             raw = None
             if raw_input_fields is not None:
@@ -276,7 +308,7 @@ def roll_out_serial(
                 s_ = torch.as_tensor(std_tensor, dtype=torch.float32).to("cpu")[:, None, None]
                 raw = field[:, -1].to("cpu", torch.float32) * s_ + m_
             if raw is not None:
-                out[pi, :, :, 0] = raw.unsqueeze(0).expand(return_size, -1, -1, -1)
+                out[pi, :, :, 0] = _host_to_device(raw, acc).unsqueeze(0).expand(return_size, -1, -1, -1)
         if ensemble_size == 0:
             continue
         known = fwd(known.contiguous())
@@ -292,8 +324,9 @@ def roll_out_serial(
         for step in range(reps):
             cur = min(1 + (step + 1) * return_seq_len, total + 1)
             sel = cur - (1 + step * return_seq_len)
-            ts = convert_datetime_to_int(t0 + timedelta(hours=step * step_size_hour * return_seq_len))
-            ts = torch.tensor([ts], device=dev)
+            ts_host = convert_datetime_to_int(t0 + timedelta(hours=step * step_size_hour * return_seq_len))
+            ts = _host_to_device(torch.tensor([ts_host]), dev)
+            ts.host_values = [ts_host]  # the model needs the value on the host: spares it a device read-back (= a stall on the previous chunk)
             smp = ensemble_AR_sampler(
                 pipeline, sample_size=ensemble_size, return_seq_len=return_seq_len, num_inference_steps=num_inference_steps,
                 known_latents=known, timestamps=ts, sampler_type=sampler_type, device=dev, member_ids=member_ids,
@@ -301,11 +334,13 @@ def roll_out_serial(
             known = smp[:, :, -input_seq_len:].contiguous()
             smp = inv(smp)  # per-channel inverse on (B, C, T, h, w): same values as the reference's rearranged call (:566-574)
             if return_latent:
-                out[pi, :, :, 1 + step * return_seq_len : cur] = smp[:, :, :sel].to("cpu")
+                out[pi, :, :, 1 + step * return_seq_len : cur] = smp[:, :, :sel].to(acc)
             else:
                 dec = decode_latent_ens(encdec_model, smp[:, :, :sel], mean_tensor=mean_tensor, std_tensor=std_tensor)
                 if return_ensemble_mean:
-                    out[pi, 0, :, 1 + step * return_seq_len : cur] = dec.mean(dim=0).to("cpu")
+                    out[pi, 0, :, 1 + step * return_seq_len : cur] = dec.mean(dim=0).to(acc)
                 else:
-                    out[pi, :, :, 1 + step * return_seq_len : cur] = dec.to("cpu")
-    return out
+                    out[pi, :, :, 1 + step * return_seq_len : cur] = dec.to(acc)
+    if out is None:
+        return out
+    return out.to(torch.device(output_device) if output_device is not None else torch.device("cpu"))

@@ -91,7 +91,8 @@ class EDMDPMSolverMultistepScheduler:
         last = self.config.sigma_min if self.config.final_sigmas_type == "sigma_min" else 0
         self.sigmas = torch.cat([sigmas, torch.tensor([last], dtype=torch.float32)])  # lives on the host, as in diffusers
         self.timesteps = self.precondition_noise(sigmas)  # host copy drives the loop ...
-        self._timesteps_dev = self.timesteps.to(device) if device is not None else None  # ... device copy feeds the model
+        # ... device copy feeds the model; uploaded without stalling the host on the work already queued (hip.upload_nonblocking)
+        self._timesteps_dev = hip.upload_nonblocking(self.timesteps, device) if device is not None else None
         self.model_outputs = [None] * self.config.solver_order
         self.lower_order_nums = 0
         self._step_index = None
