@@ -102,6 +102,9 @@ class AutoRegressive2DPipeline:
                bool(getattr(net, "batch_conditioning", False)))
         key = ("pipeline_loop",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
+        turn = cache.get(key + ("turn",), 0)  # two instances used alternately (edm_sampler.py: a running graph blocks its own next launch)
+        cache[key + ("turn",)] = turn ^ 1
+        key = key + (turn,)
         ent = cache.get(key)
 
         # device copy of the timesteps for `prepare_conditioning`, made outside the capture (a host-to-device copy) and kept alive with

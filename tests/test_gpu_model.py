@@ -84,7 +84,9 @@ def test_edm_chunk_graph_is_bitwise_equal_to_eager(tiny_pair):
             res.append(ensemble_AR_sampler(pipe, n, 4, 3, known_latents=known.cuda(), timestamps=torch.tensor([stamp]).cuda(), sampler_type="edm",
                                            device="cuda", **kw).clone())
         outs.setdefault(mode, []).append(res)
-    assert sum(1 for k in g._graphs if k[0] == "edm_chunk") == 2  # one graph per chunk shape: new timestamps / conditioning / noise replay it
+    # one captured chunk per chunk shape (new timestamps / conditioning / noise replay it), kept as two alternating instances
+    assert len({k[:-1] for k in g._graphs if k[0] == "edm_chunk"}) == 2
+    assert sum(1 for k, v in g._graphs.items() if k[0] == "edm_chunk" and isinstance(v, tuple)) == 4
     g.enable_hip_graph(False)
     assert g._graphs == {}
     eager, first, second = outs[False][0], outs[True][0], outs[True][1]
@@ -121,7 +123,7 @@ def test_pipeline_loop_graph_is_bitwise_equal_to_eager(tiny_pair):
     g.enable_hip_graph(True)
     AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler())(batch_size=2, return_seq_len=4, known_latents=synth_known(2).cuda(), timestamps=torch.tensor([2018010100]).cuda(),
                                                                   num_inference_steps=5)
-    assert sum(1 for k in g._graphs if k[0] == "pipeline_loop") == 1
+    assert len({k[:-1] for k in g._graphs if k[0] == "pipeline_loop"}) == 1
     g.enable_hip_graph(False)
     assert g._graphs == {}
 
