@@ -86,11 +86,11 @@ def edm_AR_sampler(
         # TWO instances of the captured chunk, used alternately: launching an executable graph that is still running blocks the host
         # until it has finished, and the GPU then idles through the ~0.4 ms the launch call takes to build its packets; the other
         # instance is queued behind the running one instead (same stream: they never overlap on the GPU, and share the workspaces)
+        # Both are captured at the first use of a chunk shape: whoever warms up once has warmed up.
         turn = cache.get(key + ("turn",), 0)
         cache[key + ("turn",)] = turn ^ 1
-        key = key + (turn,)
-        ent = cache.get(key)
-        if ent is None:
+
+        def capture():
             st_lat, st_known, st_out = torch.empty_like(latents), torch.empty_like(known), torch.empty(shape, device=device, dtype=torch.float32)
             st_lat.copy_(latents)
             st_known.copy_(known)
@@ -103,8 +103,12 @@ def edm_AR_sampler(
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps, prepare)
-            ent = (graph, st_lat, st_known, st_out, cn, side)
-            cache[key] = ent
+            return (graph, st_lat, st_known, st_out, cn, side)
+
+        for inst in (turn, turn ^ 1):
+            if cache.get(key + (inst,)) is None:
+                cache[key + (inst,)] = capture()
+        ent = cache[key + (turn,)]
         graph, st_lat, st_known, st_out = ent[:4]
         st_lat.copy_(latents)
         st_known.copy_(known)

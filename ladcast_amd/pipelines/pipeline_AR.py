@@ -102,10 +102,7 @@ class AutoRegressive2DPipeline:
                bool(getattr(net, "batch_conditioning", False)))
         key = ("pipeline_loop",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
-        turn = cache.get(key + ("turn",), 0)  # two instances used alternately (edm_sampler.py: a running graph blocks its own next launch)
-        cache[key + ("turn",)] = turn ^ 1
-        key = key + (turn,)
-        ent = cache.get(key)
+        ent = cache.get(key)  # (one instance: the two-instance scheme of edm_sampler.py is not applied to this secondary loop)
 
         # device copy of the timesteps for `prepare_conditioning`, made outside the capture (a host-to-device copy) and kept alive with
         # the graph that reads it
