@@ -161,8 +161,9 @@ def test_ten_chunk_chain_bf16x3_error_growth():
 
 def test_1_6b_heun_step_truncated_chunk():
     """BASELINE configs[3] in shape: the 1.6B model, 10 lead steps at R = 4 means the LAST chunk is truncated; here 6 lead steps =
-    one full chunk + one chunk cut to 2 frames, 4 solver steps per chunk (7 forwards each: Euler + Heun correction three times, then the final
-    Euler step - VERDICT r02 weak 3 asked for a 1.6B chunk longer than 3 forwards), both modes."""
+    one full chunk + one chunk cut to 2 frames, 3 solver steps per chunk (5 forwards each: Euler + Heun correction twice, then the final
+    Euler step - VERDICT r02 weak 3 asked for a 1.6B chunk longer than 3 forwards; 7 forwards each measured the same errors,
+    profiles/r03_w_1p6B_chunks_7_forwards.log, at 100 s more oracle time), both modes."""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
     from oracle.ar_model import CONFIG_1_6B
@@ -180,7 +181,7 @@ def test_1_6b_heun_step_truncated_chunk():
             return type("o", (), dict(latent=ic.permute(1, 0, 2, 3)))
 
     t0 = [datetime(2018, 1, 1, 0)]
-    kw = dict(ensemble_size=1, num_inference_steps=4, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=36, sampler_type="edm",
+    kw = dict(ensemble_size=1, num_inference_steps=3, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=36, sampler_type="edm",
               return_latent=True)
     tc = time.perf_counter()
     want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
@@ -193,5 +194,5 @@ def test_1_6b_heun_step_truncated_chunk():
         got = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **kw)
         assert got.shape == want.shape and not torch.isnan(got).any()
         e1, e2 = rel_l2(got[:, :, :, 1:5], want[:, :, :, 1:5]), rel_l2(got[:, :, :, 5:7], want[:, :, :, 5:7])
-        print(f"\n1.6B, 6 lead steps = chunk + truncated chunk, 7 forwards each (oracle {tc:.0f} s) [{mode}]: rel-L2 {e1:.2e} / {e2:.2e}")
+        print(f"\n1.6B, 6 lead steps = chunk + truncated chunk, 5 forwards each (oracle {tc:.0f} s) [{mode}]: rel-L2 {e1:.2e} / {e2:.2e}")
         assert e1 < TOL and e2 < TOL, (mode, e1, e2)
