@@ -97,3 +97,25 @@ def fullsize_chunk_oracle(full_dcae_oracle, oracle_375m):
     decoded = OP.decode_latent_ens(d.model, lat)
     return SimpleNamespace(ar=ar, cfg=dict(CONFIG_375M), targs=targs, known=known, ts=ts, want=want, ins=rec.ins, outs=rec.outs, latents=lat,
                            decoded=decoded, seconds=time.perf_counter() - t0)
+
+
+@pytest.fixture(autouse=True)
+def _few_threads_unless_full_size(request):
+    """Everything but the full-size parity tests runs its CPU oracle on 16 threads: the ops of the tiny-width models are small, and on a
+    busy 128-core host waking the whole OpenMP pool for each of them costs 50-100 ms at random (a 20-step chunk of the tiny model: 1.8 s
+    on 16 threads, 15 s with the default pool, 73 s on one noisy box).  The full-size oracle runs (375M, 1.6B, the full DCAE, the
+    1.09 G-parameter autoencoder) keep every core.  Values do not depend on the thread count beyond ~1e-7."""
+    name = request.node.name.lower()
+    full = any(k in name for k in ("full", "375m", "1_6b", "1p6b", "ray_1024")) or any(
+        f in request.fixturenames for f in ("oracle_375m", "full_dcae_oracle", "fullsize_chunk_oracle"))
+    if full:
+        yield
+        return
+    import torch
+
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(16, old))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(old)
