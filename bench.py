@@ -103,20 +103,26 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is never used)
 
 
-def model_flops_per_forward(cfg, R, T_in=1, hw=450):
-    """Analytic 2*MAC count of one forward per member; returns (gemm_flops, attn_flops)."""
+def model_flops_per_forward(cfg, R, T_in=1, hw=450, split=False):
+    """Analytic 2*MAC count of one forward per member; returns (gemm_flops, attn_flops), or with `split` the pair
+    ((gemm, attn) of the sample-dependent part, (gemm, attn) of the conditioning path: context embed + token refiner - the part a
+    sampler chunk evaluates once per noise level instead of once per network evaluation, LaDCastTransformer3DModel.prepare_conditioning)."""
     D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
     Nx, Nc = R * hw, T_in * hw
     S = Nx + Nc
     F = int(D * cfg["mlp_ratio"])
     lin = lambda m, n, k: 2.0 * m * n * k  # noqa: E731
-    g = lin(Nx, D, 84) + lin(Nc, D, 84) + lin(Nc, D, D)  # embeds + refiner proj_in
-    g += cfg["num_refiner_layers"] * (lin(Nc, 3 * D, D) + lin(Nc, F, D) + lin(Nc, D, F))
+    cg = lin(Nc, D, 84) + lin(Nc, D, D)  # context embed + refiner proj_in
+    cg += cfg["num_refiner_layers"] * (lin(Nc, 3 * D, D) + lin(Nc, F, D) + lin(Nc, D, F))
+    ca = cfg["num_refiner_layers"] * 4.0 * Nc * Nc * D
+    g = lin(Nx, D, 84)  # sample embed
     g += cfg["num_layers"] * (lin(S, 3 * D, D) + lin(S, D, D) + lin(S, F, D) + lin(S, D, F))
     g += cfg["num_single_layers"] * (lin(S, 3 * D, D) + lin(S, F, D) + lin(S, D, D + F))
     g += lin(Nx, 84, D)
-    a = cfg["num_refiner_layers"] * 4.0 * Nc * Nc * D + (cfg["num_layers"] + cfg["num_single_layers"]) * 4.0 * S * S * D
-    return g, a
+    a = (cfg["num_layers"] + cfg["num_single_layers"]) * 4.0 * S * S * D
+    if split:
+        return (g, a), (cg, ca)
+    return g + cg, a + ca
 
 
 class KernelTimer:
@@ -250,7 +256,10 @@ def main():
     ap.add_argument("--return-seq-len", type=int, default=4)
     ap.add_argument("--lead-steps", type=int, default=1, help="lead steps requested per rollout call (1 chunk covers up to return_seq_len)")
     ap.add_argument("--solver-steps", type=int, default=20)
-    ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = DPM-Solver++(2M), N forwards")
+    ap.add_argument("--sampler", default="edm", choices=["edm", "pipeline", "ddim"], help="edm = Heun, 2N-1 forwards (reference default); pipeline = the "
+                    "reference's scheduler loop with its EDM DPM-Solver++(2M) scheduler, N forwards; ddim = the same loop with ladcast_amd.schedulers.DDIMScheduler "
+                    "(diffusers defaults, eta = 0), N forwards - BASELINE's literal '20-step DDIM'")
+    ap.add_argument("--dump-output", default=None, help="rank 0 saves the (gathered) result tensor of the LAST timed step to this .pt file (tests)")
     ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; nccl (= RCCL over xGMI) is the real one, "
@@ -307,7 +316,12 @@ def main():
     model = LaDCastTransformer3DModel.from_config(cfg).to(dev).eval().set_gemm_precision(args.precision)
     model.enable_hip_graph(not args.no_graph)
     model.batch_conditioning = not args.no_batched_conditioning
-    pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
+    from ladcast_amd.schedulers import DDIMScheduler
+
+    pipes = {"edm": AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler()), "ddim": AutoRegressive2DPipeline(model, DDIMScheduler())}
+    pipes["pipeline"] = pipes["edm"]
+    pipe = pipes[args.sampler]
+    sampler_type = "edm" if args.sampler == "edm" else "pipeline"  # roll_out_serial's switch: Heun sampler | the pipeline's scheduler loop
     from ladcast_amd.pipelines.distributed import shard_members
     from ladcast_amd.precision import tolerance
 
@@ -337,26 +351,33 @@ def main():
         def step_decode():
             return roll_out_serial(
                 lambda t: field, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
-                latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=False,
+                latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=sampler_type, return_latent=False,
                 member_ids=member_ids, output_device=out_dev, **dec_kw)
 
-    def step_local():
+    def step_local(od=out_dev):
         return roll_out_serial(
             None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
-            latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
-            known_latents_override=ic, member_ids=member_ids, output_device=out_dev,
+            latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=sampler_type, return_latent=True,
+            known_latents_override=ic, member_ids=member_ids, output_device=od,
         )
+
+    phase = []  # per step of this rank: (event before the rollout, after it = before the gather, after the gather) + host times around the gather
 
     def step():
         if args.decode:
             return step_decode()
-        out = roll_out_serial(
-            None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
-            latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=args.sampler, return_latent=True,
-            known_latents_override=ic, member_ids=member_ids, output_device=out_dev,
-        )
+        if world > 1:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = step_local()
         if world > 1:  # the one collective of the path: gather the per-rank latents (evaluate/pred_rollout.py:398-400)
+            e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e1.record()
+            h0 = time.perf_counter()
             out = gather_members(out.to(dev) if args.backend == "nccl" else out.to("cpu"), total_members, member_dim=1)
+            h1 = time.perf_counter()
+            e2.record()
+            phase.append((e0, e1, e2, h1 - h0))
         return out
 
     def fence():
@@ -372,8 +393,10 @@ def main():
     t0 = time.perf_counter()
     marks, evs = [], [torch.cuda.Event(enable_timing=True)]
     evs[0].record()
+    phase.clear()
+    last_out = None
     for _ in range(args.steps):
-        step()
+        last_out = step()
         marks.append(time.perf_counter())  # --host-outputs: every step returns host tensors, i.e. is complete here
         evs.append(torch.cuda.Event(enable_timing=True))
         evs[-1].record()  # device outputs: the host runs ahead; the step boundaries are read from the stream afterwards
@@ -383,10 +406,27 @@ def main():
         step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
     else:
         step_ms = [round(a.elapsed_time(b), 2) for a, b in zip(evs[:-1], evs[1:])]
+    rank_stats = None
     if world > 1:
+        # per-rank diagnostics (a SCALE run must be readable from the one line): this rank's own wall time, its rollout time per step
+        # (events on the stream: start of the step -> result ready for the collective) and the gather's own time (stream events with
+        # nccl - the collective is stream-ordered; host clock with gloo, whose all_gather blocks the host)
+        roll_ms = sum(a.elapsed_time(b) for a, b, _, _ in phase) / max(len(phase), 1)
+        gath_ms = (sum(b.elapsed_time(c) for _, b, c, _ in phase) if args.backend == "nccl" else 1e3 * sum(h for _, _, _, h in phase)) / max(len(phase), 1)
+        mine = torch.tensor([1e3 * elapsed / args.steps, roll_ms, gath_ms, float(m)], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        rank_stats = dict(ms_per_step=[round(v, 3) for v in allr[:, 0].tolist()], ms_per_step_min=round(allr[:, 0].min().item(), 3),
+                          ms_per_step_max=round(allr[:, 0].max().item(), 3), rollout_ms_per_step=[round(v, 3) for v in allr[:, 1].tolist()],
+                          gather_ms_per_step=[round(v, 3) for v in allr[:, 2].tolist()], members=[int(v) for v in allr[:, 3].tolist()],
+                          note="per rank: wall ms per step incl. barrier + synchronise; rollout = this rank's chunks up to the collective; gather = the one "
+                               "all_gather of the result latents (a rank that finishes early waits here for the slowest)")
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if args.dump_output and rank == 0 and last_out is not None:
+        torch.save(last_out.detach().to("cpu"), args.dump_output)
     # Sustained window (not `value`): keep running back-to-back chunks until >= --sustained-seconds have passed, so the number
     # reflects the clock the chip holds under sustained load; the step count is fixed up front so every rank runs the same.
     sustained = None
@@ -403,28 +443,43 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         sustained = dict(steps=n_sus, seconds=round(dt, 3), ms_per_step=round(1e3 * dt / n_sus, 3), value=round(total_members * lead * n_sus / dt, 4))
-    other_sampler = None
-    if not args.no_kernel_timers and rank == 0 and world == 1:
-        # Secondary number (not `value`): the same workload with the reference's other sampler -- BASELINE's metric says
-        # "20-step DDIM"; `edm` (the reference's default, 39 forwards per chunk) is the headline, `pipeline`
-        # (DPM-Solver++ 2M, 20 forwards per chunk) is reported beside it, and vice versa.
-        alt = "pipeline" if args.sampler == "edm" else "edm"
+    other_sampler, ddim_sampler, host_outputs = None, None, None
+    if not args.no_kernel_timers and rank == 0 and world == 1 and not args.decode:
+        # Secondary numbers (not `value`): the same workload with the other samplers - BASELINE's metric says "20-step DDIM"; `edm` (the
+        # reference's default, 39 forwards per chunk) is the headline, `pipeline` (the reference's scheduler loop with its EDM
+        # DPM-Solver++(2M) scheduler, 20 forwards per chunk) and `ddim` (the same loop with DDIMScheduler, 20 forwards) are reported
+        # beside it; and the headline workload with the reference's output placement (a host copy + synchronise per step).
+        def timed(fn, n):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
 
-        def step_alt():
-            return roll_out_serial(
-                None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
-                latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=alt, return_latent=True,
-                known_latents_override=ic, member_ids=member_ids,
-            )
+        def alt_block(alt):
+            st = "edm" if alt == "edm" else "pipeline"
 
-        step_alt()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step_alt()
-        torch.cuda.synchronize()
-        other_sampler = dict(sampler=alt, forwards_per_step=(-(-lead // R)) * (args.solver_steps if alt == "pipeline" else 2 * args.solver_steps - 1),
-                             value=round(m * lead * 2 / (time.perf_counter() - t1), 4), unit="member-steps/s", steps=2)
+            def step_alt():
+                return roll_out_serial(
+                    None, [datetime(2018, 1, 1, 0)], pipes[alt], ensemble_size=m, num_inference_steps=args.solver_steps, return_seq_len=R,
+                    latent_transform_args=targs, total_lead_time_hour=6 * lead, sampler_type=st, return_latent=True,
+                    known_latents_override=ic, member_ids=member_ids,
+                )
+
+            dt_ = timed(step_alt, 2)
+            return dict(sampler=alt, forwards_per_step=(-(-lead // R)) * (2 * args.solver_steps - 1 if alt == "edm" else args.solver_steps),
+                        value=round(m * lead * 2 / dt_, 4), unit="member-steps/s", steps=2, ms_per_step=round(1e3 * dt_ / 2, 3))
+
+        other_sampler = alt_block("pipeline" if args.sampler == "edm" else "edm")
+        if args.sampler != "ddim":
+            ddim_sampler = alt_block("ddim")
+            ddim_sampler["scheduler"] = "ladcast_amd.schedulers.DDIMScheduler (diffusers defaults: linear betas, leading spacing, clip_sample, eta = 0), whole loop in one hipGraph"
+        if out_dev is not None:
+            dt_ = timed(lambda: step_local(None), 3)
+            host_outputs = dict(value=round(m * lead * 3 / dt_, 4), unit="member-steps/s", steps=3, ms_per_step=round(1e3 * dt_ / 3, 3),
+                                note="the headline workload with every step's result copied to the host + synchronised, as the reference's roll_out_serial returns it (--host-outputs)")
 
     def instrumented_step():
         """Kernel-level numbers for `roofline`: ONE more step of the same workload, right after the timed region, with a
@@ -472,10 +527,15 @@ def main():
                                                  frac=round(k["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_us=round(k["avg_us"], 2))
         model.set_gemm_precision(args.precision)
 
+    chunks = -(-lead // R)
+    fwd_per_chunk = (2 * args.solver_steps - 1) if args.sampler == "edm" else args.solver_steps
     if rank == 0:
-        chunks = -(-lead // R)
-        fwd_per_chunk = (2 * args.solver_steps - 1) if args.sampler == "edm" else args.solver_steps
         gflops, aflops = model_flops_per_forward(cfg, R)
+        (mg, ma), (cg, ca) = model_flops_per_forward(cfg, R, split=True)
+        # flops that RAN per member and chunk: the sample-dependent part once per network evaluation, the conditioning path once per
+        # noise level when it is batched per chunk (2N - 1 evaluations share N noise levels in the Heun sampler), else per evaluation
+        cond_evals = args.solver_steps if model.batch_conditioning else fwd_per_chunk
+        flops_per_chunk = fwd_per_chunk * (mg + ma) + cond_evals * (cg + ca)
         value = total_members * lead * args.steps / elapsed
         roof = None
         split = args.precision == "bf16x3"
@@ -502,7 +562,12 @@ def main():
                                           f"sources {built}; this run's sources are {csrc_sha16()}; not re-measured in this run")
                 except Exception:
                     traffic = None
+            import glob
+
+            stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench_cfg2.csv")))
             roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s",
+                        kernel_stats_source=(os.path.relpath(stats[-1], ROOT) + ": rocprofv3 --kernel-trace --stats summary of this command (committed; the "
+                                             "kernel's AverageNs there x `flops_per_launch` reproduces `achieved`)") if stats else None,
                         frac=round(k["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale, launches=k["launches"],
                         avg_launch_us=round(k["avg_us"], 2),
                         flops_per_launch=k["work_per_launch"],
@@ -540,12 +605,18 @@ def main():
             },
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
             "other_sampler": other_sampler,
+            "ddim_sampler": ddim_sampler,
+            "host_outputs": host_outputs,
             "sustained": sustained,
             "fp32_mode": fp32_mode,
+            # the like-for-like-precision reader's roofline (exact fp32 everywhere), at the top level beside the split one
+            "roofline_fp32": None if not fp32_mode else fp32_mode.get("roofline"),
             "ranks": {"world_size": world if dist is None else dist.get_world_size(), "backend": "none" if dist is None else args.backend,
                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and args.backend == "nccl") else None,
-                      "visible_gpus": torch.cuda.device_count()},
-            "model_tflops": round(total_members * chunks * fwd_per_chunk * (gflops + aflops) * args.steps / elapsed / 1e12, 2),
+                      "visible_gpus": torch.cuda.device_count(), "per_rank": rank_stats},
+            "model_tflops": round(total_members * chunks * flops_per_chunk * args.steps / elapsed / 1e12, 2),
+            "model_tflops_note": f"algorithmic flops that ran: {fwd_per_chunk} x {round((mg + ma) / 1e12, 4)} TFLOP (sample-dependent part) + {cond_evals} x "
+                                 f"{round((cg + ca) / 1e12, 4)} TFLOP (conditioning path) per member and chunk",
             "roofline": roof,
         }
         for an, apeak in (("attn_fwd_f32_kernel", PEAK_F32_MFMA_TFLOPS), ("attn_fwd_split_kernel", PEAK_BF16_MFMA_TFLOPS)):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 2
+#define LDC_ABI_VERSION 3
 
 #define LDC_OK 0
 #define LDC_ERR_ARG (-1)       /* null pointer / non-positive size */
@@ -84,6 +84,11 @@ typedef struct ldc_gemm_desc {
  *                     K % 64 == 0; all problems of one call must agree.  Measured 3.2e-3 rel-L2 per 375M forward instead of 6e-6
  *                     (stated tolerance 7e-3 = measured x 2; the table of all stated tolerances is ladcast_amd/precision.py). */
 #define LDC_GEMM_BF16_1TERM 4
+/*   LDC_GEMM_F32_REGSTAGE  (ldc_gemm_grouped, exact-fp32 problems only) keep the launch on the register-staged stream-K kernel
+ *                     (v_mfma_f32_32x32x2_f32) even where the LDS-DMA ring kernel would serve it (K % 32 == 0, contiguous weights,
+ *                     16-byte rows): the second exact-fp32 implementation as a caller's choice - cross-checks, and shapes a caller
+ *                     knows to be launch-bound.  Same results to fp32 rounding (another summation order). */
+#define LDC_GEMM_F32_REGSTAGE 8
 /* activation formats of the producers' `out_split` / `x_fmt` arguments: fp32, split-bf16 groups (LDC_GEMM_A_SPLIT), plain bf16 rows */
 #define LDC_FMT_F32 0
 #define LDC_FMT_SPLIT 1
@@ -324,6 +329,20 @@ int ldc_f64_to_f32(const double* x, float* y, long long n, void* stream);
 int ldc_dpm_step(const float* sample, const float* F, const float* m1, float* x0, float* prev,
                  float c_skip, float c_out, float a, float b, float inv_r0, int order, long long n,
                  void* stream);
+/* One solver step of the scheduler classes the reference's pipeline loop names (pipelines/pipeline_AR.py:19-21,100-102:
+ * diffusers DDIMScheduler.step / DDPMScheduler.step, v0.32.1) as one fused fp32 kernel; coefficients are the host's fp32 0-dim
+ * tensor arithmetic, widened nowhere.  prediction_type: 0 epsilon, 1 sample, 2 v_prediction; clip_range <= 0: no clamp of x0;
+ * noise == NULL: no noise term (DDIM eta = 0; DDPM at t = 0).
+ *   x0 = (s - sqrt_beta_t F) / sqrt_alpha_t | F | sqrt_alpha_t s - sqrt_beta_t F   (clamped)
+ *   ldc_ddim_step: prev = sqrt_alpha_prev x0 + dir_coef eps [+ std_dev noise], eps = F | (s - sqrt_alpha_t x0)/sqrt_beta_t |
+ *                  sqrt_alpha_t F + sqrt_beta_t s  (use_clipped_model_output: eps re-derived from the clamped x0)
+ *   ldc_ddpm_step: prev = x0_coef x0 + sample_coef s [+ std_dev noise] */
+int ldc_ddim_step(const float* sample, const float* F, const float* noise, float* x0, float* prev, float sqrt_alpha_t,
+                  float sqrt_beta_t, float sqrt_alpha_prev, float dir_coef, float std_dev, float clip_range,
+                  int prediction_type, int use_clipped_model_output, long long n, void* stream);
+int ldc_ddpm_step(const float* sample, const float* F, const float* noise, float* x0, float* prev, float sqrt_alpha_t,
+                  float sqrt_beta_t, float x0_coef, float sample_coef, float std_dev, float clip_range, int prediction_type,
+                  long long n, void* stream);
 int ldc_scale_f32(const float* x, float s, float* y, long long n, void* stream);
 /* out = a*x + b*y (fp32): scheduler.precondition_outputs (c_skip*sample + c_out*F) and
  * add_noise (x0 + sigma*noise) on whole tensors */
@@ -372,19 +391,12 @@ int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B,
  * or repeat_interleave (cin < cout; decoder in shortcut, :720-722). */
 int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, void* stream);
 
-/* Split-bf16 form of ldc_sphere_conv_nhwc (dense SphereConv2d, same contract): Wp is ldc_pack_weight_bf16x2 of the
- * tap-major weight [cout][k*k][cin_p], cin_p = 32 * 2^j >= cin with zeros behind cin; runs on the LDS-DMA stream-K
- * kernel (pole mirror / roll / wrap are per-lane DMA source addresses).  ksize = 1 is the pointwise conv / Linear for
- * any cin % 4 == 0 (K need not be a multiple of 32: the padding lanes read a zero page).  workspace: as ldc_gemm_grouped. */
-int ldc_sphere_conv_nhwc_bf16x3(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B,
-                                int H, int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act,
-                                void* workspace, long long workspace_bytes, void* stream);
-
-/* The same convolution on PRE-SPLIT activations (the DCAE's `bf16x3` path since round 2): X holds NHWC rows in the split format
+/* ldc_sphere_conv_nhwc (dense SphereConv2d, same contract) on PRE-SPLIT activations (the DCAE's `bf16x3` path since round 2; round 1's
+ * fp32-rows-in entry point ldc_sphere_conv_nhwc_bf16x3 left the ABI in version 3 - it survives in the `make ab` build for tools/conv_bench.py): X holds NHWC rows in the split format
  * (in_fmt = LDC_FMT_SPLIT: columns 8g..8g+7 in 32 bytes [hi x8 | lo x8]; ldx % 8 == 0, ldx >= cin rounded up to 8, pad columns
  * zero), written by the producers below, so the conv's main loop is the pre-split GEMM kernel (gemm_bf16x3_v3.hip: 16x16x32 MFMA, no
- * VALU in the loop) with the sphere gather as per-lane LDS-DMA source addresses.  Wp: the weight format of
- * ldc_sphere_conv_nhwc_bf16x3.  out_fmt: LDC_FMT_F32 (Y fp32 rows) or LDC_FMT_SPLIT (Y split rows for the next conv, ldy % 8 == 0,
+ * VALU in the loop) with the sphere gather as per-lane LDS-DMA source addresses.  Wp: ldc_pack_weight_bf16x2 of the tap-major weight
+ * [cout][k*k][cin_p], cin_p = 32 * 2^j >= cin with zeros behind cin.  out_fmt: LDC_FMT_F32 (Y fp32 rows) or LDC_FMT_SPLIT (Y split rows for the next conv, ldy % 8 == 0,
  * ldy >= cout rounded up to 8; cout % 4 == 0, the pad half of a last half-filled group is written as zeros).  cin % 8 need not
  * hold (252: the last group's pad columns are zero in X and in Wp).  ksize 1 / 3 / 5.
  * in_fmt = LDC_FMT_BF16 is the single-term `bf16` mode of the same conv (see LDC_GEMM_BF16_1TERM): X plain bf16 rows (same ldx, in

@@ -278,7 +278,11 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
   p.kbias = key_bias;
   dim3 grid(static_cast<unsigned>(p.nq) * H * B);
   // at most one workgroup per CU anyway -> 8 waves with the keys split over two wave groups; more -> 4 waves, two workgroups per CU
-  const bool two = grid.x <= 256 && getenv("LDC_ATTN_F32_ONE_GROUP") == nullptr;  // (env: measurement aid, read per call)
+  // NOTE the choice looks at the whole launch (B included), and the two forms add the key tiles in different orders: a member's fp32
+  // result can differ at rounding level (~1e-7) with how many members share the launch, like the stream-K cut of the GEMMs.  Partition
+  // independence of the sharded rollout is therefore "to fp32 rounding", bitwise only for equal per-rank batches (pipelines/distributed.py).
+  static const bool one_group_forced = LDC_AB_GETENV("LDC_ATTN_F32_ONE_GROUP") != nullptr;  // measurement aid, read once
+  const bool two = grid.x <= 256 && !one_group_forced;
   const size_t lds = (two ? 4 : 2) * STAGE * sizeof(float);
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -113,6 +113,14 @@ __device__ __forceinline__ int ldc_sphere_src_pixel(int h, int w, int ky, int kx
   return r * W + c;
 }
 
+// Measurement switches (tile height / unit ranges / tile order / kernel choice forced from the environment) exist only in the A/B build
+// (`make ab` -> libladcast_hip_ab.so, loaded by tools/ through LDC_LIB_PATH); the shipped library reads no environment variable.
+#ifdef LDC_AB_BUILD
+#define LDC_AB_GETENV(name) getenv(name)
+#else
+#define LDC_AB_GETENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 // wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

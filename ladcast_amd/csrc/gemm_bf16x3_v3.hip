@@ -957,7 +957,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
         if (nsr > P.tm) nsr = P.tm;
         P.rm = ldc_cdiv(P.tm, nsr);
       }
-      if (const char* e = getenv("LDC_BF16X3_RM")) {
+      if (const char* e = LDC_AB_GETENV("LDC_BF16X3_RM")) {
         const int f = atoi(e);
         if (f >= 0) P.rm = (f == 0 || f > P.tm) ? P.tm : f;
       }
@@ -1012,7 +1012,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (gmax < G) G = gmax;
     }
   }
-  static const char* const force_g = getenv("LDC_BF16X3_G");  // measurement aid (read once): force the number of unit ranges
+  static const char* const force_g = LDC_AB_GETENV("LDC_BF16X3_G");  // measurement aid (read once): force the number of unit ranges
   if (force_g) {
     const long long g_ = atoll(force_g);
     if (g_ > 0 && g_ <= CUS) G = g_;
@@ -1061,9 +1061,9 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
   }
   // half-height tiles while 256-row tiles would not fill the chip twice over (both heights run 8 waves here, so the
   // half-height tile costs no MFMA efficiency, only twice the W traffic per FLOP); LDC_BF16X3_BM forces one
-  static const char* const force_thr = getenv("LDC_BF16X3_SMALL_TILES");  // measurement aid, read once: the cross-over below
+  static const char* const force_thr = LDC_AB_GETENV("LDC_BF16X3_SMALL_TILES");  // measurement aid, read once: the cross-over below
   bool small = tiles256 < (force_thr ? atoll(force_thr) : 400);  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
-  static const char* const force_bm = getenv("LDC_BF16X3_BM");  // measurement aid, read once
+  static const char* const force_bm = LDC_AB_GETENV("LDC_BF16X3_BM");  // measurement aid, read once
   if (force_bm) small = (atoi(force_bm) == 128);
   if (problems[0].d.flags & LDC_GEMM_BF16_1TERM)
     return small ? launch_v3<128, 1>(problems, epi, n, workspace, workspace_bytes, stream)
@@ -1077,8 +1077,8 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
 int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(problems);
   if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
-  const char* const off = getenv("LDC_F32_RING");  // measurement / test aid, read per call: LDC_F32_RING=0 -> the register-staged kernel
-  if (off && atoi(off) == 0) return LDC_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i)  // the caller's choice (include/ladcast_hip.h): this launch stays on the register-staged kernel
+    if (problems[i].d.flags & LDC_GEMM_F32_REGSTAGE) return LDC_ERR_UNSUPPORTED;
   auto al16 = [](const void* q_) { return q_ != nullptr && (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
   // what the register-staged kernel accepts and this one does not goes there, not back to the caller as an error
   if (!al16(workspace) || workspace_bytes < LDC_GEMM_COUNTER_BYTES + 2ll * 256 * BN * static_cast<long long>(sizeof(float)))
@@ -1151,7 +1151,7 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
   const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
   // tile height: measured cross-over (tools/conv_bench.py) - 252 -> 252 at 120 x 240 (226 tiles of 256 rows): 101 us at 256 rows, 121 at
   // 128; 504 -> 504 at 60 x 120 (116 tiles): 122 / 111; four frames of it (464): 350 / 437.  LDC_CONV_SMALL_TILES: measurement aid
-  static const char* const force_thr = getenv("LDC_CONV_SMALL_TILES");
+  static const char* const force_thr = LDC_AB_GETENV("LDC_CONV_SMALL_TILES");
   const bool small = tiles256 < (force_thr ? atoll(force_thr) : 200);
   if (one)
     return small ? launch_v3<128, 1, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp)

@@ -490,7 +490,7 @@ static int gemm_grouped_impl(const ldc_gemm_problem* problems, int n, void* work
     if ((d.K & 3) || (d.lda & 3) || (d.a_bs & 3)) return LDC_ERR_ALIGN;
     if (split_bf16 ? (d.K & 7) != 0 : (d.ldw & 3) != 0) return LDC_ERR_ALIGN;
     if (d.act < LDC_ACT_NONE || d.act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
-    if (d.flags != 0) return LDC_ERR_UNSUPPORTED;  // split activation formats: the LDS-DMA bf16x3 kernel only (K % 32 == 0)
+    if ((d.flags & ~LDC_GEMM_F32_REGSTAGE) != 0) return LDC_ERR_UNSUPPORTED;  // split activation formats: the LDS-DMA bf16x3 kernel only (K % 32 == 0)
     DevProblem& P = a.pr[i];
     P.A = q.A;
     P.W = q.W;
@@ -559,31 +559,38 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, false);
 }
 
-int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
-                                void* stream);  // gemm_bf16x3_dma.hip
 int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                                void* stream);  // gemm_bf16x3_v3.hip
+#ifdef LDC_AB_BUILD
+int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
+                                void* stream);  // gemm_bf16x3_dma.hip: round 1's 32x32x16 kernel for fp32 activations, A/B build only
+#endif
 
 extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace,
                                        long long workspace_bytes, void* stream) {
-  // Pre-split activations (LDC_GEMM_A_SPLIT) and K % 32 == 0: the 16x16x32 kernel (gemm_bf16x3_v3.hip); fp32
-  // activations and K % 32 == 0: the 32x32x16 LDS-DMA kernel (gemm_bf16x3_dma.hip); otherwise the register-staged
-  // kernel.  LDC_BF16X3_KERNEL=regstage / dma forces the older ones (A/B measurements).
-  static const int force = [] {
+  // Pre-split activations (LDC_GEMM_A_SPLIT) and K % 32 == 0 - every launch of the models: the 16x16x32 ring kernel
+  // (gemm_bf16x3_v3.hip); anything else (fp32 activations, K % 32 != 0): the register-staged kernel below, which splits in its loop.
+  // A/B build only: round 1's LDS-DMA kernel for fp32 activations in between, LDC_BF16X3_KERNEL=regstage / dma forces the older ones.
+  int force = 0;
+#ifdef LDC_AB_BUILD
+  static const int force_env = [] {
     const char* e = getenv("LDC_BF16X3_KERNEL");
     if (e != nullptr && strcmp(e, "regstage") == 0) return 1;
     if (e != nullptr && strcmp(e, "dma") == 0) return 2;
     return 0;
   }();
-  const bool force_v1 = force == 1;
+  force = force_env;
+#endif
   if (force == 0) {
     const int st = ldc_gemm_grouped_bf16x3_v3(problems, n, workspace, workspace_bytes, stream);
     if (st != LDC_ERR_UNSUPPORTED) return st;
   }
-  if (!force_v1) {
+#ifdef LDC_AB_BUILD
+  if (force != 1) {
     const int st = ldc_gemm_grouped_bf16x3_dma(problems, n, workspace, workspace_bytes, stream);
     if (st != LDC_ERR_UNSUPPORTED) return st;
   }
+#endif
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, true);
 }
 

@@ -531,7 +531,7 @@ static int linear_small_impl(const float* x, int x_rows, const float* W, const f
     if (K <= LS_KC) {  // one staged chunk: walk several column groups per workgroup, keep >= 4 workgroups per CU
       const long long groups = static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups;
       iters = groups >= 2048 ? 4 : 1;  // measured (tools/gemv_bench.py, 38 D x D): 78 us at 1, 73 at 4, slower at 3 / 8 / 16
-      static const char* const force_iters = getenv("LDC_LINEAR_SMALL_ITERS");  // measurement aid, read once
+      static const char* const force_iters = LDC_AB_GETENV("LDC_LINEAR_SMALL_ITERS");  // measurement aid, read once
       if (force_iters && atoi(force_iters) > 0) iters = atoi(force_iters);
     }
     dim3 grid(ldc_cdiv(ldc_cdiv(N, 4 * LS_CPW_MAX), iters), row_groups);

@@ -67,6 +67,54 @@ __global__ void dpm_step_kernel(const float* __restrict__ sample, const float* _
   prev[i] = r;
 }
 
+// diffusers DDIMScheduler.step / DDPMScheduler.step (the scheduler classes the reference pipeline names, pipelines/pipeline_AR.py:19-21,
+// 100-102) as ONE fused fp32 kernel per solver step; every product, sum and quotient rounds where the schedulers' elementwise torch
+// ops round (no contraction: this file is built with -ffp-contract=off), the scalar coefficients come from the host's fp32 0-dim
+// tensor arithmetic.  pred: 0 epsilon, 1 sample, 2 v_prediction.
+//   x0   = (s - sb F) / sa | F | sa s - sb F           [clamped to +-clip when clip > 0]
+//   DDIM: eps = F | (s - sa x0) / sb | sa F + sb s     (recomputed from the clamped x0 when reclip);  prev = sap x0 + cdir eps [+ sd noise]
+//   DDPM: prev = c0 x0 + c1 s [+ sd noise]
+struct DdStepArgs {
+  const float* sample;
+  const float* F;
+  const float* noise;  // nullptr: no noise term
+  float* x0;
+  float* prev;
+  float sa, sb;        // alpha_prod_t ** 0.5, beta_prod_t ** 0.5
+  float c0, c1;        // DDIM: alpha_prod_t_prev ** 0.5, direction coefficient; DDPM: pred_original_sample_coeff, current_sample_coeff
+  float sd;            // noise scale
+  float clip;          // <= 0: no clamp
+  int pred, ddpm, reclip;
+};
+
+__global__ void dd_step_kernel(DdStepArgs p, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = p.sample[i], f = p.F[i];
+  float x0, eps;
+  if (p.pred == 0) {
+    x0 = (s - p.sb * f) / p.sa;
+    eps = f;
+  } else if (p.pred == 1) {
+    x0 = f;
+    eps = (s - p.sa * x0) / p.sb;
+  } else {
+    x0 = p.sa * s - p.sb * f;
+    eps = p.sa * f + p.sb * s;
+  }
+  if (p.clip > 0.f) x0 = fminf(fmaxf(x0, -p.clip), p.clip);
+  float r;
+  if (p.ddpm) {
+    r = p.c0 * x0 + p.c1 * s;
+  } else {
+    if (p.reclip) eps = (s - p.sa * x0) / p.sb;
+    r = p.c0 * x0 + p.c1 * eps;
+  }
+  if (p.noise) r = r + p.sd * p.noise[i];
+  p.x0[i] = x0;
+  p.prev[i] = r;
+}
+
 __global__ void scale_f32_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long long n) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) y[i] = x[i] * s;
@@ -135,6 +183,28 @@ extern "C" int ldc_dpm_step(const float* sample, const float* F, const float* m1
   if (order != 1 && order != 2) return LDC_ERR_UNSUPPORTED;
   if (order == 2 && m1 == nullptr) return LDC_ERR_ARG;
   LDC_LAUNCH_1D(dpm_step_kernel, n, sample, F, m1, x0, prev, c_skip, c_out, a, b, inv_r0, order);
+}
+static int dd_step(const float* sample, const float* F, const float* noise, float* x0, float* prev, float sa, float sb, float c0, float c1,
+                   float sd, float clip, int pred, int ddpm, int reclip, long long n, void* stream) {
+  LDC_CHECK_PTR(sample);
+  LDC_CHECK_PTR(F);
+  LDC_CHECK_PTR(x0);
+  LDC_CHECK_PTR(prev);
+  if (pred < 0 || pred > 2) return LDC_ERR_UNSUPPORTED;
+  DdStepArgs a{sample, F, noise, x0, prev, sa, sb, c0, c1, sd, clip, pred, ddpm, reclip};
+  LDC_LAUNCH_1D(dd_step_kernel, n, a);
+}
+extern "C" int ldc_ddim_step(const float* sample, const float* F, const float* noise, float* x0, float* prev, float sqrt_alpha_t,
+                             float sqrt_beta_t, float sqrt_alpha_prev, float dir_coef, float std_dev, float clip_range,
+                             int prediction_type, int use_clipped_model_output, long long n, void* stream) {
+  return dd_step(sample, F, noise, x0, prev, sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, std_dev, clip_range, prediction_type, 0,
+                 use_clipped_model_output, n, stream);
+}
+extern "C" int ldc_ddpm_step(const float* sample, const float* F, const float* noise, float* x0, float* prev, float sqrt_alpha_t,
+                             float sqrt_beta_t, float x0_coef, float sample_coef, float std_dev, float clip_range, int prediction_type,
+                             long long n, void* stream) {
+  return dd_step(sample, F, noise, x0, prev, sqrt_alpha_t, sqrt_beta_t, x0_coef, sample_coef, std_dev, clip_range, prediction_type, 1, 0, n,
+                 stream);
 }
 extern "C" int ldc_scale_f32(const float* x, float s, float* y, long long n, void* stream) {
   LDC_CHECK_PTR(x);

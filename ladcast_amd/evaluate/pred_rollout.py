@@ -89,6 +89,8 @@ def run_rollout(
     noise_level: float = 0,
     device: Optional[torch.device] = None,
     batch_size: Optional[int] = None,
+    ic_noise_seed: int = 0,
+    latent_hw: Optional[Sequence[int]] = None,
     **roll_out_kwargs,
 ) -> List[torch.Tensor]:
     """One ``roll_out_serial`` call per initial time with the reference CLI's fixed arguments (``encdec_model_type="ae"``,
@@ -100,8 +102,11 @@ def run_rollout(
     gather: the collective itself moves the per-rank blocks in pieces of at most 256 MiB (``distributed.GATHER_CHUNK_BYTES``); the
     assembled batch - ``batch_size x ens`` items - lives on ``device`` in latent mode (12 MB per member at 240 h) and on the HOST in
     decoded mode (``save_as_latent=False``: 0.8 GB per member at 240 h; 8 initial times x 20 members = 130 GB, never on a GPU).
-    ``noise_level > 0`` perturbs each initial time's IC once, from a generator seeded by the initial time (``ic_noise_seed``, default
-    0), so the result does not depend on the number of ranks."""
+    ``noise_level > 0`` perturbs each initial time's IC once, from a CPU generator seeded with ``ic_noise_seed + YYYYMMDDHH`` of the
+    initial time, so the result does not depend on the number of ranks.  NOTE the default ``ic_noise_seed = 0``: unlike the
+    reference (process RNG stream), two runs over the same initial time draw the SAME IC perturbation unless the caller varies
+    the seed.  ``latent_hw``: the latent grid ``(h, w)``; default: the static field's grid over the autoencoder's compression
+    ratio.  Known up front, it makes the latent-mode exchange the single all_gather of north_star (no shape agreement round)."""
     if total_lead_time_hour % step_size_hour:
         raise ValueError("total_lead_time_hour must be divisible by step_size_hour")  # pipelines/utils.py:305-306
     import torch.distributed as dist
@@ -111,6 +116,9 @@ def run_rollout(
     if batch_size is None:
         batch_size = dist.get_world_size() if active else 1
     init_times = list(init_times)
+    if latent_hw is None and static_conditioning_tensor is not None and hasattr(encdec_model, "spatial_compression_ratio"):
+        r_ = int(encdec_model.spatial_compression_ratio)
+        latent_hw = tuple(int(v) // r_ for v in static_conditioning_tensor.shape[-2:])
     results = []
     for b0 in range(0, len(init_times), batch_size):
         batch = init_times[b0 : b0 + batch_size]
@@ -120,7 +128,7 @@ def run_rollout(
             encdec_model=encdec_model, encdec_model_type="ae", static_tensor4encdec=static_conditioning_tensor, latent_transform="normalize",
             latent_transform_args=latent_transform_args, total_lead_time_hour=total_lead_time_hour, step_size_hour=step_size_hour,
             sampler_type=sampler_type, input_seq_len=input_seq_len, return_tensor=True, return_latent=save_as_latent, noise_level=noise_level,
-            **roll_out_kwargs,
+            ic_noise_seed=ic_noise_seed, latent_hw=latent_hw, **roll_out_kwargs,
         )  # (len(batch), ens, C, 1 + steps, h, w)
         if output is not None and save_as_latent and rank == 0:
             save_latent_npy(full, batch, output)

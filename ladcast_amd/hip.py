@@ -21,8 +21,9 @@ LIB_PATH = os.environ.get("LDC_LIB_PATH") or os.path.join(_HERE, "libladcast_hip
 ACT_NONE, ACT_SILU, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per row, the input row = its sinusoidal embedding
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
+GEMM_F32_REGSTAGE = 8  # exact-fp32 problems: stay on the register-staged stream-K kernel (include/ladcast_hip.h)
 ATTN_OUT_SPLIT, ATTN_BF16_1TERM, ATTN_OUT_BF16 = 1, 2, 4
-ABI_VERSION = 2  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
+ABI_VERSION = 3  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
 FMT_F32, FMT_SPLIT, FMT_BF16 = 0, 1, 2  # activation formats of the producers' `out_split` arguments (True == FMT_SPLIT)
 
 
@@ -82,7 +83,6 @@ def _load():
         "ldc_gate_residual_layernorm": (I, [P, P, P, P, I, I, I, I, L, I, L, I, I, L, P, P, F, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
-        "ldc_sphere_conv_nhwc_bf16x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
         "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
@@ -110,6 +110,8 @@ def _load():
         "ldc_edm_heun": (I, [P, P, P, P, D, D, D, D, L, P]),
         "ldc_f64_to_f32": (I, [P, P, L, P]),
         "ldc_dpm_step": (I, [P, P, P, P, P, F, F, F, F, F, I, L, P]),
+        "ldc_ddim_step": (I, [P, P, P, P, P, F, F, F, F, F, F, I, I, L, P]),
+        "ldc_ddpm_step": (I, [P, P, P, P, P, F, F, F, F, F, F, I, L, P]),
         "ldc_scale_f32": (I, [P, F, P, L, P]),
         "ldc_axpby_f32": (I, [P, F, P, F, P, L, P]),
         "ldc_sphere_conv_nhwc": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
@@ -192,7 +194,8 @@ def _grouped_workspace(device):
 
 def gemm_problem(A, W, C, *, M, N, K, batch=1, lda=None, ldw=None, ldc=None, a_bs=0, c_bs=0, bias=None, gate=None, gate_bs=0, R=None,
                  ldr=0, r_bs=0, act=ACT_NONE, flags=0):
-    """one entry of a grouped launch (same argument meaning as `gemm`); flags: GEMM_A_SPLIT | GEMM_C_SPLIT (bf16x3 only)"""
+    """one entry of a grouped launch (same argument meaning as `gemm`); flags: GEMM_A_SPLIT | GEMM_C_SPLIT (bf16x3 only); GEMM_F32_REGSTAGE
+    (exact fp32 only): the register-staged kernel instead of the ring kernel"""
     _dev(A, W, C, bias, gate, R)
     d = GemmDesc(M, N, K, batch, lda if lda is not None else K, ldw if ldw is not None else K, ldc if ldc is not None else N, ldr,
                  a_bs, c_bs, r_bs, gate_bs, act, flags, 0)
@@ -319,6 +322,7 @@ def qkv_epilogue(wq=None, wk=None, rope=None, *, eps=1e-7, heads, rope_row0=0, q
 
 
 ERR_UNSUPPORTED = -3  # LDC_ERR_UNSUPPORTED
+_DEFAULT_QSCALE = ctypes.c_float(0.08838834764831845 * 1.4426950408889634).value  # log2(e) / sqrt(128) as the library rounds it
 
 
 def gemm_grouped_qkv(problems, epilogues, force_fallback=False):
@@ -345,6 +349,9 @@ def gemm_grouped_qkv(problems, epilogues, force_fallback=False):
         if e is None:
             continue
         q, (wq, wk, rope) = e
+        if q.qscale not in (0.0, _DEFAULT_QSCALE):  # ldc_attn_qkv_prepare_split applies the default scale only: never two answers for one call
+            raise RuntimeError("ldc_gemm_grouped_bf16x3_qkv: shape not served by the fused kernel, and the plain-GEMM + ldc_attn_qkv_prepare_split "
+                               f"route applies the default q scale log2(e)/sqrt(128), not qscale={q.qscale!r}")
         d, C = p.d, keep[2]
         D, S = q.heads * 128, d.M
         if d.N != 3 * D:
@@ -485,6 +492,18 @@ def dpm_step(sample, F, m1, x0, prev, c_skip, c_out, a, b, inv_r0, order):
            "ldc_dpm_step")
 
 
+def ddim_step(sample, F, noise, x0, prev, sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, std_dev, clip_range, prediction_type, reclip):
+    _dev(sample, F, noise, x0, prev)
+    _check(lib.ldc_ddim_step(_p(sample), _p(F), _p(noise), _p(x0), _p(prev), sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, dir_coef, std_dev,
+                             clip_range, prediction_type, int(bool(reclip)), sample.numel(), _stream()), "ldc_ddim_step")
+
+
+def ddpm_step(sample, F, noise, x0, prev, sqrt_alpha_t, sqrt_beta_t, x0_coef, sample_coef, std_dev, clip_range, prediction_type):
+    _dev(sample, F, noise, x0, prev)
+    _check(lib.ldc_ddpm_step(_p(sample), _p(F), _p(noise), _p(x0), _p(prev), sqrt_alpha_t, sqrt_beta_t, x0_coef, sample_coef, std_dev, clip_range,
+                             prediction_type, sample.numel(), _stream()), "ldc_ddpm_step")
+
+
 def scale_f32(x, s, y):
     _dev(x, y)
     _check(lib.ldc_scale_f32(_p(x), s, _p(y), x.numel(), _stream()), "ldc_scale_f32")
@@ -512,8 +531,14 @@ def conv_cin_padded(cin, cpk=32):
 
 
 def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE):
-    """Wp: pack_weight_bf16x2 of the [cout, k*k*conv_cin_padded(cin)] tap-major weight (zeros behind cin)"""
+    """A/B BUILD ONLY (`make -C ladcast_amd/csrc ab`, LDC_LIB_PATH=ladcast_amd/libladcast_hip_ab.so; tools/conv_bench.py): round 1's conv entry
+    point with fp32 rows in and the split in the loop - it left the shipped ABI in version 3.  Wp: pack_weight_bf16x2 of the
+    [cout, k*k*conv_cin_padded(cin)] tap-major weight (zeros behind cin)"""
     _dev(X, Wp, Y, bias, R)
+    if not hasattr(lib, "ldc_sphere_conv_nhwc_bf16x3"):
+        raise RuntimeError("ldc_sphere_conv_nhwc_bf16x3 exists in the A/B build only (make ab; LDC_LIB_PATH=.../libladcast_hip_ab.so)")
+    I_, P_, L_ = c_int, c_void_p, c_longlong
+    lib.ldc_sphere_conv_nhwc_bf16x3.restype, lib.ldc_sphere_conv_nhwc_bf16x3.argtypes = I_, [P_] * 5 + [I_] * 10 + [P_, L_, P_]
     ws = _grouped_workspace(X.device)
     _check(lib.ldc_sphere_conv_nhwc_bf16x3(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx if ldx is not None else cin, cout,
                                            ldy if ldy is not None else cout, ldr, ksize, act, _p(ws), ws.numel() * 4, _stream()),
@@ -522,7 +547,7 @@ def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None,
 
 def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE, in_fmt=FMT_SPLIT,
                            out_fmt=FMT_F32):
-    """X: operand rows (FMT_SPLIT: Wp as sphere_conv_nhwc_bf16x3 | FMT_BF16: Wp = pack_weight_bf16 of the taps padded to 64 * 2^j channels;
+    """X: operand rows (FMT_SPLIT: Wp = pack_weight_bf16x2 of the [cout, k*k*conv_cin_padded(cin)] tap-major weight, zeros behind cin | FMT_BF16: Wp = pack_weight_bf16 of the taps padded to 64 * 2^j channels;
     ldx % 8 == 0); Y fp32 rows or (out_fmt = in_fmt) operand rows"""
     _dev(X, Wp, Y, bias, R)
     ws = _grouped_workspace(X.device)

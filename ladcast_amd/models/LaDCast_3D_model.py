@@ -699,6 +699,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         as in `forward`."""
         if self._plan is None:
             self._build_plan()
+        if hidden_states.dtype != torch.float32 or not hidden_states.is_cuda or not hidden_states.is_contiguous():
+            raise TypeError("forward_launch_only takes a contiguous fp32 device tensor (use forward() for anything else)")
         if conditioning is not None:
             return self._main_device(hidden_states, conditioning[0], conditioning[1])
         return self._forward_device(hidden_states, timestep.reshape(-1), conditioning_tensors, te)
@@ -720,6 +722,10 @@ class LaDCastTransformer3DModel(ModelMixin):
             self._build_plan()
         dev = self.device
         timesteps = timesteps.to(device=dev, dtype=torch.float32).reshape(-1)
+        # the same cast `forward` applies: the kernels read raw fp32 device pointers (an fp64 / bf16 / host tensor must never reach them)
+        conditioning_tensors = conditioning_tensors.to(device=dev, dtype=torch.float32)
+        if conditioning_tensors.dim() != 5:
+            raise ValueError("conditioning_tensors must be (B, C, T_in, h, w)")
         N, B = timesteps.shape[0], conditioning_tensors.shape[0]
         shape = tuple(conditioning_tensors.shape)
         per = max(1, self.COND_MAX_ROWS // B)  # noise levels per pass
@@ -739,6 +745,37 @@ class LaDCastTransformer3DModel(ModelMixin):
             ctx[n0 * B : (n0 + n) * B].copy_(pk.ctx)
             mods[n0 * B : (n0 + n) * B].copy_(pk.mods)
         return SimpleNamespace(ctx=ctx, mods=mods, shape=shape, levels=N)
+
+    @staticmethod
+    def _launchers(plan):
+        """What `_conditioning_device` and `_main_device` launch their GEMMs with, for the plan's precision mode:
+        (AS, CS, fmt, G, run, run1, run_qkv).  Split-bf16 / bf16 modes: activations that only feed GEMMs (LayerNorm outputs, attention
+        outputs, MLP hidden states) are written ONCE in the operand format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT /
+        _C_SPLIT) - same buffers, strides and column offsets as in fp32 mode.  AS / CS: descriptor flags "A is / C is written in the
+        operand format"; fmt: what the producers of GEMM operands write - fp32, split-bf16 groups (bf16x3), plain bf16 rows (bf16: a
+        row's K values in the first 2 K bytes of its fp32 row; only COLUMN offsets differ, 2 bytes per column instead of 4)."""
+        split, packed = plan.split, plan.packed
+        AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
+        CS = hip.GEMM_C_SPLIT if split else 0
+        fmt = hip.FMT_BF16 if plan.one_term else hip.FMT_SPLIT if split else hip.FMT_F32
+
+        def G(A, W, C, **kw):  # weight in the format of the active precision mode
+            return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
+
+        def run(problems):
+            hip.gemm_grouped(problems, split_bf16=split)
+
+        def run1(A, W, C, **kw):
+            hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
+
+        def run_qkv(problems, epis):
+            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
+            if split:
+                hip.gemm_grouped_qkv(problems, epis)
+            else:
+                hip.gemm_grouped(problems, split_bf16=split)
+
+        return AS, CS, fmt, G, run, run1, run_qkv
 
     def _forward_device(self, hidden_states, timestep, conditioning_tensors, te):
         """one forward = its conditioning path (batch = the call's members) + the sample-dependent part"""
@@ -769,32 +806,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         SD = S * D
         h_c, nh_c = ws.h, ws.nh
         split = plan.split
-        packed = plan.packed
 
-        # split-bf16 mode: activations that only feed GEMMs (LayerNorm outputs, attention outputs, MLP hidden states)
-        # are written ONCE in the split format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT / _C_SPLIT); the
-        # buffers, strides and column offsets are the same as in fp32 mode
-        AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
-        CS = hip.GEMM_C_SPLIT if split else 0
-        # what the producers of GEMM operands write: fp32, split-bf16 groups (bf16x3), plain bf16 rows (bf16: a row's K values in the
-        # first 2 K bytes of its fp32 row - same buffers and strides; only COLUMN offsets differ, 2 bytes per column instead of 4)
-        fmt = hip.FMT_BF16 if plan.one_term else hip.FMT_SPLIT if split else hip.FMT_F32
-
-        def G(A, W, C, **kw):  # weight in the format of the active precision mode
-            return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
-
-        def run(problems):
-            hip.gemm_grouped(problems, split_bf16=split)
-
-        def run1(A, W, C, **kw):
-            hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
-
-        def run_qkv(problems, epis):
-            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
-            if split:
-                hip.gemm_grouped_qkv(problems, epis)
-            else:
-                hip.gemm_grouped(problems, split_bf16=split)
+        AS, CS, fmt, G, run, run1, run_qkv = self._launchers(plan)
 
         # 1b. context patch embed (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59
         if split:
@@ -892,32 +905,8 @@ class LaDCastTransformer3DModel(ModelMixin):
         NM = plan.mod_w.shape[0]
         mods = pack.mods[idx * B : (idx + 1) * B]
         split = plan.split
-        packed = plan.packed
 
-        # split-bf16 mode: activations that only feed GEMMs (LayerNorm outputs, attention outputs, MLP hidden states)
-        # are written ONCE in the split format by their producer (ladcast_hip.h LDC_GEMM_A_SPLIT / _C_SPLIT); the
-        # buffers, strides and column offsets are the same as in fp32 mode
-        AS = (hip.GEMM_A_SPLIT | (hip.GEMM_BF16_1TERM if plan.one_term else 0)) if split else 0
-        CS = hip.GEMM_C_SPLIT if split else 0
-        # what the producers of GEMM operands write: fp32, split-bf16 groups (bf16x3), plain bf16 rows (bf16: a row's K values in the
-        # first 2 K bytes of its fp32 row - same buffers and strides; only COLUMN offsets differ, 2 bytes per column instead of 4)
-        fmt = hip.FMT_BF16 if plan.one_term else hip.FMT_SPLIT if split else hip.FMT_F32
-
-        def G(A, W, C, **kw):  # weight in the format of the active precision mode
-            return hip.gemm_problem(A, packed[id(W)] if split else W, C, **kw)
-
-        def run(problems):
-            hip.gemm_grouped(problems, split_bf16=split)
-
-        def run1(A, W, C, **kw):
-            hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
-
-        def run_qkv(problems, epis):
-            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
-            if split:
-                hip.gemm_grouped_qkv(problems, epis)
-            else:
-                hip.gemm_grouped(problems, split_bf16=split)
+        AS, CS, fmt, G, run, run1, run_qkv = self._launchers(plan)
 
         # 1a. sample patch embed (k=1 Conv3d == per-token Linear), models/embeddings.py:52-59; the refined context of this noise level
         # becomes the conditioning rows of the joint token buffer (the dual blocks update them in place)

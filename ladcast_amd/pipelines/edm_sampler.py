@@ -52,7 +52,7 @@ def edm_AR_sampler(
     t_steps = noise_scheduler.sigmas  # (N+1,) fp32 on the host
     # (N,) fed to the model as (1,) views; a captured chunk holds its own device copy, so the upload happens on the paths that need it
     c_noise_host = noise_scheduler.precondition_noise(t_steps[:-1])
-    known = known_latents.to(device)
+    known = known_latents.to(device=device, dtype=torch.float32)  # the model's kernels read fp32 (its forward() casts; the launch-only entry does not)
     if known.shape[0] != batch_size:
         known = known.expand(batch_size, *known.shape[1:])
     known = known.contiguous()

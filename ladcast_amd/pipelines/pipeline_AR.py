@@ -60,11 +60,15 @@ class AutoRegressive2DPipeline:
         dev = self._execution_device
         shape = (batch_size, self.ar_model.config.out_channels, return_seq_len, *known_latents.shape[-2:])
         image = randn_tensor(shape, generator=generator, device=dev, dtype=self.ar_model.dtype).contiguous()
-        known_latents = known_latents.to(dev)  # the reference discards this result (Q13); we keep it
+        known_latents = known_latents.to(device=dev, dtype=torch.float32)  # the reference discards this result (Q13); we keep it (fp32: what the kernels read)
         if not do_edm_style:
             raise NotImplementedError("Only EDM style is supported for now")
         net, sch = self.ar_model, self.scheduler
-        if getattr(net, "use_hip_graph", False) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs") and getattr(sch, "launch_only", False):
+        # a scheduler whose `step` is host scalars + kernel launches (`launch_only`) lets the WHOLE loop be captured; step kwargs that make it
+        # draw noise (DDIM's eta > 0, any generator) put the loop back on eager launches
+        kw_ = self.scheduler_step_kwargs
+        graphable = getattr(sch, "launch_only", False) and hasattr(sch, "graph_signature") and not kw_.get("eta") and kw_.get("generator") is None and kw_.get("variance_noise") is None
+        if getattr(net, "use_hip_graph", False) and hasattr(net, "forward_launch_only") and hasattr(net, "_graphs") and graphable:
             image = self._graph_loop(net, sch, image, known_latents.contiguous(), timestamps, num_inference_steps, batch_size, dev)
             if not return_dict:
                 return (image,)
@@ -80,7 +84,9 @@ class AutoRegressive2DPipeline:
             if not do_edm_style:
                 raise NotImplementedError("Only EDM style is supported for now")
             x_in = self.scheduler.scale_model_input(image, t)
+            t_host = t
             t = t.expand(batch_size).to(dev)
+            t.host_value = t_host  # schedulers that index by timestep (DDIM / DDPM) read it here instead of stalling on a device read-back
             ckw = {} if pack is None else {"conditioning": (pack, i)}
             model_output = self.ar_model(x_in, t, known_latents, time_elapsed=timestamps, return_dict=False, **ckw)[0]
             image = self.scheduler.step(model_output, t, image, **self.scheduler_step_kwargs, return_dict=False)[0]
@@ -92,13 +98,12 @@ class AutoRegressive2DPipeline:
         """hipGraph of the whole scheduler loop (N forwards + N scheduler steps), as edm_AR_sampler does for its chunk: with this
         build's scheduler every coefficient is a host scalar known before the first launch, so the loop is launches only.  Same
         kernels and arguments as the eager loop (bit-identical samples); afterwards the scheduler object is left in the state
-        the eager loop leaves it in (step index N, last two x0 predictions)."""
+        the eager loop leaves it in (`graph_state` / `set_graph_state`: EDM - step index N and the last two x0 predictions; DDIM - none).
+        The scheduler describes itself to the graph cache through `graph_signature()` (its config and schedule)."""
         sch.set_timesteps(num_inference_steps)
         te = net.time_elapsed_embedding(timestamps)
-        c = sch.config
-        key = (tuple(image.shape), tuple(known.shape), num_inference_steps, tuple(float(v) for v in sch.sigmas.tolist()),
-               (c.solver_order, c.prediction_type, c.final_sigmas_type, c.euler_at_final, c.lower_order_final, c.sigma_data),
-               tuple(sorted(self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity(),
+        key = (tuple(image.shape), tuple(known.shape), num_inference_steps, sch.graph_signature(),
+               tuple(sorted((k, str(v)) for k, v in self.scheduler_step_kwargs.items())), None if te is None else (te.data_ptr(), tuple(te.shape)), str(dev), net.plan_identity(),
                bool(getattr(net, "batch_conditioning", False)))
         key = ("pipeline_loop",) + key
         cache = net._graphs  # the model's graph store: dropped with the packed weights (load_state_dict, .to(), precision switch)
@@ -121,7 +126,8 @@ class AutoRegressive2DPipeline:
             st_img, st_known = torch.empty_like(image), torch.empty_like(known)
             st_img.copy_(image)
             st_known.copy_(known)
-            tsteps = [t.to(dev).expand(batch_size).contiguous() for t in sch.timesteps]  # what the eager loop feeds the model
+            # what the eager loop feeds the model, in the fp32 its forward() casts to (DDIM / DDPM timesteps are int64; the launch-only entry reads raw fp32)
+            tsteps = [t.to(device=dev, dtype=torch.float32).expand(batch_size).contiguous() for t in sch.timesteps]
             side = net.capture_stream() if hasattr(net, "capture_stream") else torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):  # warm-up on the capture stream (per-stream workspaces)
@@ -131,11 +137,11 @@ class AutoRegressive2DPipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 st_out = loop(st_img, st_known, tsteps)
-            ent = (graph, st_img, st_known, st_out, tsteps, side, list(sch.model_outputs), sch.lower_order_nums, sch._step_index, ts_dev)  # ts_dev: read by the graph
+            ent = (graph, st_img, st_known, st_out, tsteps, side, sch.graph_state(), ts_dev)  # ts_dev: read by the graph
             cache[key] = ent
         graph, st_img, st_known, st_out = ent[:4]
         st_img.copy_(image)
         st_known.copy_(known)
         graph.replay()
-        sch.model_outputs, sch.lower_order_nums, sch._step_index = list(ent[6]), ent[7], ent[8]
+        sch.set_graph_state(ent[6])
         return st_out.clone()

@@ -199,6 +199,18 @@ class EDMDPMSolverMultistepScheduler:
     def __len__(self):
         return self.config.num_train_timesteps
 
+    # what a captured sampling loop needs to know about this object (pipelines/pipeline_AR.py::_graph_loop)
+    def graph_signature(self):
+        c = self.config
+        return ("EDMDPMSolverMultistepScheduler", tuple(float(v) for v in self.sigmas.tolist()),
+                (c.solver_order, c.prediction_type, c.final_sigmas_type, c.euler_at_final, c.lower_order_final, c.sigma_data))
+
+    def graph_state(self):
+        return (list(self.model_outputs), self.lower_order_nums, self._step_index)
+
+    def set_graph_state(self, state):
+        self.model_outputs, self.lower_order_nums, self._step_index = list(state[0]), state[1], state[2]
+
 
 def _host_scalar(sigma):
     if isinstance(sigma, torch.Tensor):

@@ -208,3 +208,188 @@ class EDMDPMSolverMultistepScheduler:
         while sigma.dim() < original_samples.dim():
             sigma = sigma.unsqueeze(-1)
         return original_samples + noise * sigma
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# DDIMScheduler / DDPMScheduler (diffusers v0.32.1): the scheduler classes the reference's pipeline loop is documented against
+# (``pipelines/pipeline_AR.py:19-21``; the loop itself, :85-102, only calls set_timesteps / timesteps / scale_model_input / step).
+# PARITY UNPINNED like the class above (third-party source absent); restated op by op - every whole-tensor expression below is the
+# one diffusers evaluates, in its order, with fp32 0-dim CPU tensors as coefficients.  Independent derivations:
+# ``tests/test_oracle_independent_leaves.py`` (DDIM on exact epsilon lands on the closed-form marginal; the DDPM posterior mean /
+# variance vs Ho et al. eq. 6-7 in fp64).  Not restated: dynamic thresholding, learned variances, custom timestep lists.
+# ---------------------------------------------------------------------------------------------------------------------------
+import math  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+def _oracle_randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers.utils.torch_utils.randn_tensor: drawn on the generator's device (CPU here), a list draws (1, ...) per generator"""
+    if isinstance(generator, list) and len(generator) == 1:
+        generator = generator[0]
+    if isinstance(generator, list):
+        one = (1,) + tuple(shape[1:])
+        return torch.cat([torch.randn(one, generator=g, dtype=dtype) for g in generator], dim=0)
+    return torch.randn(tuple(shape), generator=generator, dtype=dtype)
+
+
+class _DDBase:
+    order = 1
+
+    def _betas(self, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, rescale_betas_zero_snr):
+        if trained_betas is not None:
+            betas = torch.tensor(trained_betas, dtype=torch.float32)
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start**0.5, beta_end**0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "squaredcos_cap_v2":
+            bar = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2  # noqa: E731
+            betas = torch.tensor([min(1 - bar((i + 1) / num_train_timesteps) / bar(i / num_train_timesteps), 0.999) for i in range(num_train_timesteps)],
+                                 dtype=torch.float32)
+        else:
+            raise NotImplementedError(beta_schedule)
+        if rescale_betas_zero_snr:
+            raise NotImplementedError("rescale_betas_zero_snr is not restated")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def _spacing(self, n):
+        c = self.config
+        if c.timestep_spacing == "linspace":
+            return np.linspace(0, c.num_train_timesteps - 1, n).round()[::-1].copy().astype(np.int64)
+        if c.timestep_spacing == "leading":
+            return (np.arange(0, n) * (c.num_train_timesteps // n)).round()[::-1].copy().astype(np.int64) + c.steps_offset
+        if c.timestep_spacing == "trailing":
+            return np.round(np.arange(c.num_train_timesteps, 0, -c.num_train_timesteps / n)).astype(np.int64) - 1
+        raise ValueError(c.timestep_spacing)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _x0_eps(self, model_output, sample, alpha_prod_t, beta_prod_t):
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            return (sample - beta_prod_t ** (0.5) * model_output) / alpha_prod_t ** (0.5), model_output
+        if pt == "sample":
+            return model_output, (sample - alpha_prod_t ** (0.5) * model_output) / beta_prod_t ** (0.5)
+        if pt == "v_prediction":
+            return ((alpha_prod_t**0.5) * sample - (beta_prod_t**0.5) * model_output,
+                    (alpha_prod_t**0.5) * model_output + (beta_prod_t**0.5) * sample)
+        raise ValueError(pt)
+
+    @staticmethod
+    def _t(timestep):
+        if isinstance(timestep, torch.Tensor):
+            timestep = timestep.reshape(-1)[0].item()
+        return int(timestep)
+
+
+class DDIMScheduler(_DDBase):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                 clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon", thresholding=False,
+                 dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0, timestep_spacing="leading",
+                 rescale_betas_zero_snr=False):
+        assert not thresholding
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        self._betas(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, rescale_betas_zero_snr)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = torch.from_numpy(self._spacing(num_inference_steps))
+
+    def _get_variance(self, timestep, prev_timestep):
+        alpha_prod_t = self.alphas_cumprod[timestep]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        return ((1 - alpha_prod_t_prev) / (1 - alpha_prod_t)) * (1 - alpha_prod_t / alpha_prod_t_prev)
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None, variance_noise=None, return_dict=True):
+        timestep = self._t(timestep)
+        prev_timestep = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        alpha_prod_t = self.alphas_cumprod[timestep]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        beta_prod_t = 1 - alpha_prod_t
+        pred_original_sample, pred_epsilon = self._x0_eps(model_output, sample, alpha_prod_t, beta_prod_t)
+        if self.config.clip_sample:
+            pred_original_sample = pred_original_sample.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        variance = self._get_variance(timestep, prev_timestep)
+        std_dev_t = eta * variance ** (0.5)
+        if use_clipped_model_output:
+            pred_epsilon = (sample - alpha_prod_t ** (0.5) * pred_original_sample) / beta_prod_t ** (0.5)
+        pred_sample_direction = (1 - alpha_prod_t_prev - std_dev_t**2) ** (0.5) * pred_epsilon
+        prev_sample = alpha_prod_t_prev ** (0.5) * pred_original_sample + pred_sample_direction
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = _oracle_randn_tensor(model_output.shape, generator=generator, dtype=model_output.dtype)
+            prev_sample = prev_sample + std_dev_t * variance_noise
+        if not return_dict:
+            return (prev_sample, pred_original_sample)
+        return SimpleNamespace(prev_sample=prev_sample, pred_original_sample=pred_original_sample)
+
+
+class DDPMScheduler(_DDBase):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                 variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", thresholding=False,
+                 dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0, timestep_spacing="leading", steps_offset=0,
+                 rescale_betas_zero_snr=False):
+        assert not thresholding
+        self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
+        self._betas(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, rescale_betas_zero_snr)
+        self.one = torch.tensor(1.0)
+        self.variance_type = variance_type
+
+    def set_timesteps(self, num_inference_steps=None, device=None):
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = torch.from_numpy(self._spacing(num_inference_steps))
+
+    def previous_timestep(self, timestep):
+        if self.num_inference_steps:
+            index = (self.timesteps == timestep).nonzero(as_tuple=True)[0][0]
+            return torch.tensor(-1) if index == self.timesteps.shape[0] - 1 else self.timesteps[index + 1]
+        return timestep - 1
+
+    def _get_variance(self, t):
+        prev_t = self.previous_timestep(t)
+        alpha_prod_t = self.alphas_cumprod[t]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        current_beta_t = 1 - alpha_prod_t / alpha_prod_t_prev
+        variance = torch.clamp((1 - alpha_prod_t_prev) / (1 - alpha_prod_t) * current_beta_t, min=1e-20)
+        if self.variance_type == "fixed_small_log":
+            variance = torch.exp(0.5 * torch.log(variance))
+        elif self.variance_type == "fixed_large":
+            variance = current_beta_t
+        elif self.variance_type == "fixed_large_log":
+            variance = torch.log(current_beta_t)
+        return variance
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        t = self._t(timestep)
+        prev_t = self.previous_timestep(t)
+        alpha_prod_t = self.alphas_cumprod[t]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        beta_prod_t = 1 - alpha_prod_t
+        beta_prod_t_prev = 1 - alpha_prod_t_prev
+        current_alpha_t = alpha_prod_t / alpha_prod_t_prev
+        current_beta_t = 1 - current_alpha_t
+        pred_original_sample, _ = self._x0_eps(model_output, sample, alpha_prod_t, beta_prod_t)
+        if self.config.clip_sample:
+            pred_original_sample = pred_original_sample.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        pred_original_sample_coeff = (alpha_prod_t_prev ** (0.5) * current_beta_t) / beta_prod_t
+        current_sample_coeff = current_alpha_t ** (0.5) * beta_prod_t_prev / beta_prod_t
+        pred_prev_sample = pred_original_sample_coeff * pred_original_sample + current_sample_coeff * sample
+        variance = 0
+        if t > 0:
+            variance_noise = _oracle_randn_tensor(model_output.shape, generator=generator, dtype=model_output.dtype)
+            if self.variance_type == "fixed_small_log":
+                variance = self._get_variance(t) * variance_noise
+            else:
+                variance = (self._get_variance(t) ** 0.5) * variance_noise
+        pred_prev_sample = pred_prev_sample + variance
+        if not return_dict:
+            return (pred_prev_sample, pred_original_sample)
+        return SimpleNamespace(prev_sample=pred_prev_sample, pred_original_sample=pred_original_sample)

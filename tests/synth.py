@@ -40,6 +40,38 @@ def make_ar(cfg, seed=1234):
     return randomize_norms(LaDCastTransformer3DModel.from_config(cfg)).eval()
 
 
+def stress_ar_(model, q_gain=4.0, k_gain=3.0, outliers=8, outlier_scale=50.0, ada_scale=8.0, seed=77):
+    """Stand-in for the statistics of TRAINED weights nobody has offline - in place, on an oracle model:
+    * q / k RMSNorm gains x `q_gain` / x `k_gain`: score std ~ q_gain * k_gain = 12, |logit| up to ~50 over 2250 keys -> peaked softmax
+      (default init: logits ~N(0, 1), a diffuse softmax that hides score errors);
+    * `outliers` output channels of the two patch embeds (weights and bias) x `outlier_scale`: a few channels that dominate every
+      token's LayerNorm statistics, as the massive-activation channels of trained transformers do;
+    * every AdaLN modulation Linear (dual / single blocks, output head, refiner gates) x `ada_scale`: gates, shifts and scales O(1)
+      instead of ~0.3.
+    Returns the model (same object)."""
+    g = torch.Generator().manual_seed(seed)
+    D = model.x_embedder.proj.weight.shape[0]
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            leaf = name.rsplit(".", 2)
+            if name.endswith((".norm_q.weight", ".norm_added_q.weight")):
+                p.mul_(q_gain)
+            elif name.endswith((".norm_k.weight", ".norm_added_k.weight")):
+                p.mul_(k_gain)
+            elif len(leaf) == 3 and leaf[1] == "linear" and leaf[0].split(".")[-1] in ("norm1", "norm1_context", "norm", "norm_out"):
+                p.mul_(ada_scale)  # AdaLayerNormZero / -ZeroSingle / -Continuous / HunyuanVideoAdaNorm modulation Linears
+        for emb in (model.x_embedder, model.context_embedder):
+            idx = torch.randperm(D, generator=g)[:outliers]
+            emb.proj.weight[idx] *= outlier_scale
+            emb.proj.bias[idx] *= outlier_scale
+    return model
+
+
+def make_ar_stress(cfg, seed=1234, **kw):
+    """`make_ar` + `stress_ar_`: seeded default-init weights pushed to trained-model statistics"""
+    return stress_ar_(make_ar(cfg, seed), **kw)
+
+
 def make_dcae(cfg, seed=1234):
     torch.manual_seed(seed)
     return randomize_norms(AutoencoderDC.from_config(cfg)).eval()

@@ -215,3 +215,71 @@ def test_ic_noise_is_partition_invariant_and_gather_is_chunked(tmp_path):
     # chunked gather: 14 items of (5, 3) over 2 ranks in collectives of two rows
     want = torch.cat([torch.arange(7 * 5 * 3, dtype=torch.float32).reshape(7, 5, 3) + 1000 * r for r in range(2)]).reshape(2, 7, 5, 3)
     assert torch.equal(c0, want) and torch.equal(c1, want)
+
+
+# -- single all_gather in latent mode; return_ensemble_mean under sharding -----------------------------------------
+def _fake_decoded_rollout(ensemble_size, member_ids, pred_timestamp, return_ensemble_mean=False, **kw):
+    """decoded-mode contract: slot 0 = the IC field (the same for every member), slots 1.. differ per member; honours
+    return_ensemble_mean the way roll_out_serial does (one row holding the fp32 mean over the members, pipelines/utils.py:296-300,641)"""
+    g = torch.Generator().manual_seed(1000 * pred_timestamp[0])
+    ic = torch.randn(2, 3, 4, generator=g)
+    rows = []
+    for k in member_ids:
+        x = torch.randn(2, 4, 3, 4, generator=torch.Generator().manual_seed(77 * pred_timestamp[0] + k))
+        x[:, 0] = ic
+        rows.append(x)
+    out = torch.stack(rows)[None]
+    if return_ensemble_mean:
+        m = out.mean(dim=1, keepdim=True)
+        m[:, 0, :, 0] = ic
+        return m
+    return out
+
+
+def _worker_mean_and_single_gather(rank, world, port, result_path):
+    from datetime import datetime
+
+    from ladcast_amd.pipelines import roll_out_serial
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mean = roll_out_sharded(_fake_decoded_rollout, ensemble_size=5, pred_timestamp=[1, 2, 3], return_ensemble_mean=True)
+    # latent mode through the PRODUCT's roll_out_serial: the item shape is known on every rank -> exactly one collective, an all_gather
+    # (1 initial time x 1 member on 2 ranks: rank 0 has no work and must still take part with the right shape)
+    calls = []
+    orig_ag, orig_ar = dist.all_gather, dist.all_reduce
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), orig_ag(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), orig_ar(*a, **k))[1]
+    try:
+        kw = dict(_real_rollout_kwargs(), noise_level=0)
+        one = roll_out_sharded(roll_out_serial, ensemble_size=1, pred_timestamp=[datetime(2018, 1, 1, 0)], **kw)
+        three = roll_out_sharded(roll_out_serial, ensemble_size=3, pred_timestamp=[datetime(2018, 1, 1, 0)], **kw)
+    finally:
+        dist.all_gather, dist.all_reduce = orig_ag, orig_ar
+    torch.save((mean, one, three, calls), f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ensemble_mean_and_single_all_gather(tmp_path):
+    from datetime import datetime
+
+    from ladcast_amd.pipelines import roll_out_serial
+    from ladcast_amd.pipelines.distributed import latent_item_shape
+
+    path = str(tmp_path / "res")
+    mp.spawn(_worker_mean_and_single_gather, args=(2, _free_port(), path), nprocs=2, join=True)
+    (m0, one0, three0, calls0), (m1, one1, three1, calls1) = torch.load(path + ".0"), torch.load(path + ".1")
+    want = torch.cat([_fake_decoded_rollout(5, list(range(5)), [t], return_ensemble_mean=True) for t in (1, 2, 3)], dim=0)
+    assert m0.shape == want.shape == (3, 1, 2, 4, 3, 4)
+    assert torch.allclose(m0, want, rtol=0, atol=1e-6) and torch.equal(m0, m1)  # same fp32 mean of the same members
+    assert torch.equal(m0[:, 0, :, 0], want[:, 0, :, 0])  # slot 0 (the IC) copied, not averaged
+    assert calls0 == ["all_gather", "all_gather"] and calls1 == calls0  # ONE collective per sharded call, no shape-agreement round
+    kw = dict(_real_rollout_kwargs(), noise_level=0)
+    assert latent_item_shape(dict(kw, pipeline=kw["pipeline"])) == (84, 4, 15, 30)
+    s1 = roll_out_serial(pred_timestamp=[datetime(2018, 1, 1, 0)], ensemble_size=1, **kw)
+    s3 = roll_out_serial(pred_timestamp=[datetime(2018, 1, 1, 0)], ensemble_size=3, **kw)
+    assert torch.equal(one0, s1) and torch.equal(one1, s1) and torch.equal(three0, s3) and torch.equal(three1, s3)
+    with __import__("pytest").raises(ValueError):
+        roll_out_sharded(_fake_decoded_rollout, ensemble_size=2, pred_timestamp=[1], return_ensemble_mean=True, return_latent=True)

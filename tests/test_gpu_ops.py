@@ -276,9 +276,10 @@ def test_gemm_fp32_streamk_inlaunch_reduction_is_deterministic_and_rearmed(hip):
         assert int(ws.view(torch.int32)[: (1 << 20) // 4].abs().sum().item()) == 0
 
 
-def test_gemm_fp32_ring_kernel_vs_register_staged_kernel(hip, monkeypatch):
+def test_gemm_fp32_ring_kernel_vs_register_staged_kernel(hip):
     """round 3: exact-fp32 problems with K % 32 == 0, contiguous weights and 16-byte rows run on the LDS-DMA ring kernel (fp32 operand
-    rows, v_mfma_f32_16x16x4_f32); LDC_F32_RING=0 (read per call) keeps them on the register-staged stream-K kernel.  Both against
+    rows, v_mfma_f32_16x16x4_f32); the descriptor flag LDC_GEMM_F32_REGSTAGE keeps them on the register-staged stream-K kernel (round 4:
+    a caller's choice in the ABI - the shipped library reads no environment variable any more).  Both against
     fp64 and against each other: ragged M / N, batches, every epilogue term, C as a strided slab, in-place residual."""
     cases = [(2250, 1536, 1536, 1, 0), (300, 260, 128, 2, 2), (4500, 4608, 1536, 1, 1), (77, 96, 6144, 1, 3), (1800, 84, 1536, 2, 0),
              (9000, 6144, 1536, 1, 2)]
@@ -292,16 +293,16 @@ def test_gemm_fp32_ring_kernel_vs_register_staged_kernel(hip, monkeypatch):
         want[:, :, 8 : 8 + N] += v * gate[:, None, :].double()
         got = {}
         for ring in ("1", "0"):
-            monkeypatch.setenv("LDC_F32_RING", ring)
             d_buf = dev(buf)
             Cv = d_buf[:, :, 8:]
             hip.gemm_grouped([hip.gemm_problem(dev(A), dev(W), Cv, M=M, N=N, K=K, batch=B, a_bs=M * K, ldc=LDC, c_bs=M * LDC, bias=dev(b),
-                                               gate=dev(gate), gate_bs=N, R=Cv, ldr=LDC, r_bs=M * LDC, act=act)])
+                                               gate=dev(gate), gate_bs=N, R=Cv, ldr=LDC, r_bs=M * LDC, act=act,
+                                               flags=0 if ring == "1" else hip.GEMM_F32_REGSTAGE)])
             got[ring] = d_buf.cpu()
             assert rel(d_buf, want) < 2e-6, (M, N, K, ring)
             assert torch.equal(got[ring][:, :, :8], buf[:, :, :8]) and torch.equal(got[ring][:, :, 8 + N :], buf[:, :, 8 + N :])
         assert rel(got["1"], got["0"]) < 1e-6
-    monkeypatch.delenv("LDC_F32_RING")
+        assert not torch.equal(got["1"], got["0"]) or M * N < 50000  # two kernels, two summation orders: the flag does select the other one
     # grouped: the dual block's two streams in one launch, different row counts; bitwise repeatable
     A, W0, W1 = dev(rnd(2250, 1536, seed=1)), dev(rnd(6144, 1536, seed=2) / 39.0), dev(rnd(6144, 1536, seed=3) / 39.0)
     outs = []

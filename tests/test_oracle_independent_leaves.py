@@ -8,6 +8,7 @@ What still has no independent check is listed in ``oracle/__init__.py``.
 import math
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -250,3 +251,90 @@ def test_randn_tensor_member_seeding_contract():
     for j, k in enumerate((7, 8, 9)):
         solo = torch.randn((1,) + shape[1:], generator=torch.Generator().manual_seed(k))
         assert torch.equal(full[j : j + 1], solo)
+
+
+# -- DDIM / DDPM (oracle/scheduler.py; diffusers 0.32.1 restated) against the papers' closed forms, evaluated another way ---------------
+def test_ddim_on_the_exact_epsilon_walks_the_closed_form_marginal():
+    """Song et al. (DDIM) eq. 12 with sigma = 0: if the network returns the TRUE noise of x_t = sqrt(a_t) x0 + sqrt(1 - a_t) eps, every
+    step lands on x_prev = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps with the same (x0, eps), and the last step (a_prev = 1) returns x0.
+    The expected values come from the fp64 cumulative product of the betas alone, not from the scheduler's own tables."""
+    from oracle.scheduler import DDIMScheduler
+
+    for pred in ("epsilon", "sample", "v_prediction"):
+        s = DDIMScheduler(clip_sample=False, prediction_type=pred)
+        s.set_timesteps(20)
+        assert s.timesteps.tolist() == list(range(950, -1, -50))  # "leading": multiples of T // n, descending
+        abar = torch.cumprod(1.0 - torch.linspace(1e-4, 2e-2, 1000, dtype=torch.float64), 0)
+        g = torch.Generator().manual_seed(0)
+        x0, eps = torch.randn(4, 6, generator=g), torch.randn(4, 6, generator=g)
+        t0 = int(s.timesteps[0])
+        x = (abar[t0].sqrt() * x0 + (1 - abar[t0]).sqrt() * eps).float()
+        for t in s.timesteps.tolist():
+            a = abar[t]
+            out = {"epsilon": eps, "sample": x0, "v_prediction": (a.sqrt() * eps - (1 - a).sqrt() * x0).float()}[pred]
+            x = s.step(out, t, x).prev_sample
+            ap = abar[t - 50] if t >= 50 else torch.tensor(1.0, dtype=torch.float64)
+            want = ap.sqrt() * x0 + (1 - ap).sqrt() * eps
+            assert (x - want).abs().max() < 2e-5, (pred, t)
+        assert (x - x0).abs().max() < 2e-5
+
+
+def test_ddpm_posterior_mean_and_variance_match_ho_et_al():
+    """Ho et al. (DDPM) eq. 6-7 on the SPACED schedule: q(x_prev | x_t, x0) = N(mu, beta~) with the step's own alpha_t = abar_t / abar_prev,
+    mu = sqrt(abar_prev) beta_t / (1 - abar_t) x0 + sqrt(alpha_t) (1 - abar_prev) / (1 - abar_t) x_t, beta~ = (1 - abar_prev) / (1 - abar_t) beta_t.
+    The scheduler's deterministic part (a generator whose draw is subtracted back out) and its noise scale against these, in fp64."""
+    from oracle.scheduler import DDPMScheduler
+
+    abar = torch.cumprod(1.0 - torch.linspace(1e-4, 2e-2, 1000, dtype=torch.float64), 0)
+    for vt in ("fixed_small", "fixed_small_log", "fixed_large"):
+        s = DDPMScheduler(clip_sample=False, variance_type=vt)
+        s.set_timesteps(10)
+        g = torch.Generator().manual_seed(1)
+        x0, eps = torch.randn(3, 5, generator=g), torch.randn(3, 5, generator=g)
+        for t in s.timesteps.tolist():
+            tp = t - 100
+            a, ap = abar[t], (abar[tp] if tp >= 0 else torch.tensor(1.0, dtype=torch.float64))
+            xt = (a.sqrt() * x0 + (1 - a).sqrt() * eps).float()
+            got = s.step(eps, t, xt, generator=torch.Generator().manual_seed(9)).prev_sample
+            z = torch.randn(3, 5, generator=torch.Generator().manual_seed(9))
+            alpha_t = a / ap
+            beta_t = 1 - alpha_t
+            mu = ap.sqrt() * beta_t / (1 - a) * x0 + alpha_t.sqrt() * (1 - ap) / (1 - a) * xt.double()
+            var = {"fixed_small": (1 - ap) / (1 - a) * beta_t, "fixed_small_log": (1 - ap) / (1 - a) * beta_t, "fixed_large": beta_t}[vt]
+            want = mu + (var.clamp(min=1e-20).sqrt() * z if t > 0 else 0.0)
+            assert (got - want).abs().max() < 3e-5, (vt, t)
+        assert int(s.previous_timestep(0)) == -1 and int(s.previous_timestep(300)) == 200
+
+
+def test_product_ddim_ddpm_schedules_equal_the_oracles():
+    """host side of the product classes (no kernel): tables, spacing rules, previous-timestep rule, config surface"""
+    from ladcast_amd.schedulers import DDIMScheduler, DDPMScheduler
+    from oracle import scheduler as OS
+
+    for kw in (dict(), dict(beta_schedule="scaled_linear"), dict(beta_schedule="squaredcos_cap_v2"), dict(timestep_spacing="trailing"),
+               dict(timestep_spacing="linspace"), dict(steps_offset=1)):
+        for P, O in ((DDIMScheduler, OS.DDIMScheduler), (DDPMScheduler, OS.DDPMScheduler)):
+            a, b = P(**kw), O(**kw)
+            assert torch.equal(a.betas, b.betas) and torch.equal(a.alphas_cumprod, b.alphas_cumprod) and torch.equal(a.timesteps, b.timesteps)
+            for n in (1, 7, 20, 50):
+                a.set_timesteps(n), b.set_timesteps(n)
+                assert torch.equal(a.timesteps, b.timesteps) and a.num_inference_steps == n
+            assert a.config.num_train_timesteps == 1000 and a.init_noise_sigma == 1.0 and a.order == 1
+    d, od = DDPMScheduler(), OS.DDPMScheduler()
+    d.set_timesteps(20), od.set_timesteps(20)
+    for t in d.timesteps.tolist():
+        assert int(d.previous_timestep(t)) == int(od.previous_timestep(t))
+        assert torch.equal(d._get_variance(t), od._get_variance(t))
+    s = DDIMScheduler()
+    with pytest.raises(ValueError):
+        s.set_timesteps(2000)
+    with pytest.raises(ValueError):
+        s.step(None, 10, None)  # set_timesteps first
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(thresholding=True)
+    with pytest.raises(NotImplementedError):
+        DDPMScheduler(variance_type="learned")
+    assert DDIMScheduler.launch_only and not DDPMScheduler.launch_only
+    sig = s.graph_signature()
+    s.set_timesteps(20)
+    assert s.graph_signature() != sig and hash(s.graph_signature()) is not None

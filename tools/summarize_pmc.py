@@ -16,8 +16,10 @@ for c in vals:
     for f in glob.glob(os.path.join(root, f"pmc_{c}", "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
-                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].strip()
-                name = name.split("::")[-1].split(" ")[-1]
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                if not os.environ.get("PMC_KEEP_TEMPLATE"):  # default: all instantiations of a kernel template under one name
+                    name = name.split("<")[0]
+                name = name.strip().split("::")[-1].split(" ")[-1] if "<" not in name else name.strip()
                 vals[c][name].append(float(r["Counter_Value"]))
 for name in sorted(set(vals["FETCH_SIZE"]) | set(vals["WRITE_SIZE"])):
     fs, wsz = vals["FETCH_SIZE"].get(name, []), vals["WRITE_SIZE"].get(name, [])
