@@ -227,8 +227,15 @@ int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, const ldc_qkv_
 int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, int S, int H, int ld_qkv, long long qkv_bs, int split_row,
                                const float* wq0, const float* wk0, const float* cos0, const float* sin0, const float* wq1,
                                const float* wk1, const float* cos1, const float* sin1, float eps, void* stream);
+/* workspace (ABI 3): bytes ldc_attn_fwd_split can use for this call shape (0: none needed).  When query blocks x heads x batch exceed the
+ * 256 CUs by at most half a round (the 1.6B model: 16 heads x 18 query blocks of 128 = 288 units), the kernel runs one persistent
+ * workgroup per CU - its whole units first, then ONE key slice of a left-over unit - and a second small launch merges the slices'
+ * (O, m, l) in slice order (bitwise reproducible): 288 units take ~1.13 rounds instead of two uneven ones.  workspace == NULL (or too
+ * small) is legal: the call then runs the plain one-unit-per-workgroup grids. */
+long long ldc_attn_fwd_split_workspace_bytes(int B, int S, int H);
 int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
-                       long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* stream);
+                       long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* workspace,
+                       long long workspace_bytes, void* stream);
 /* key_bias: as ldc_attn_fwd's, but 32 * ceil(S / 32) floats (16-byte aligned; entries past S are ignored). */
 
 /* In-place per-head RMSNorm(128, eps, weight) on q and k followed by the

@@ -161,7 +161,13 @@ struct AttnArgs {
   int nq, nt;
   int out_split;
   const float* kbias;  // additive per-key score bias (natural-log units, as an SDPA float mask), 32 * nt floats, or nullptr
+  // TAIL schedule (more units than CUs): units [0, n_full) run whole, one per workgroup and round; each of the remaining units is cut
+  // into `slices` key ranges ("pieces", n_pieces = tail units x slices <= workgroups) whose un-normalised (O, m, l) go to `part` and
+  // are combined by attn_tail_merge_kernel
+  int n_full, n_pieces, slices;
+  float* part;
 };
+constexpr int PART_FLOATS = 68 * 256;  // per piece: [64 O values + m0, m1, l0, l1][4 waves x 64 lanes]
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return static_cast<unsigned>(reinterpret_cast<unsigned long long>(p));
@@ -187,6 +193,15 @@ __device__ __forceinline__ float xor16_add(float x) {
 __device__ __forceinline__ float xor32_add(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// This lane's index produced where it is asked for (two VALU instructions in a volatile asm: cannot be hoisted or shared).  The TAIL
+// kernel's per-item prologue / epilogue geometry derives from it, so that nothing of it is live across the item's key loop - derived
+// from threadIdx once, the compiler hoists those values out of the item loop and spills 46 registers (gemm_bf16x3_v3.hip: fresh_lane).
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
 }
 
 #define LDC_SB __builtin_amdgcn_sched_barrier(0)
@@ -217,10 +232,107 @@ __device__ __forceinline__ float xor32_add(float x) {
       if (kb_ + 16 * kt_ + r_ >= S) { SN[kt_][0][r_] = -1.0e30f; SN[kt_][1][r_] = -1.0e30f; } \
   }
 
+// ---- epilogue: a lane owns query row 16 qt + c16 and, per d tile, the 4 consecutive columns 16 dt + 4 g4 .. + 3 ----
+__device__ __forceinline__ void attn_store_rows(const AttnArgs& p, int b, int head, int q0, int c16, int g4, const f32x4 (&o)[8][2],
+                                                const float (&l_run)[2]) {
+  const int S = p.S;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrow = q0 + 16 * qt + c16;
+    if (qrow >= S) continue;
+    const float inv = 1.0f / l_run[qt];
+    float* orow = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const int n = 16 * dt + 4 * g4;
+      float4 v = make_float4(o[dt][qt][0] * inv, o[dt][qt][1] * inv, o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+      if (p.out_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
+        unsigned char* rowb = reinterpret_cast<unsigned char*>(orow - head * HD);  // bf16 columns are 2 bytes: offset from the ROW start
+        *reinterpret_cast<uint2*>(rowb + 2 * (head * HD + n)) = make_uint2(pack_pair(v.x, v.y), pack_pair(v.z, v.w));
+      } else if (p.out_split) {
+        // LDC_GEMM_A_SPLIT format: columns 8c..8c+7 live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16
+        // further the other half: v_permlane16_swap gives the even lane group both hi halves, the odd one both lo halves
+        float r0, r1, r2, r3;
+        const unsigned hx = split_pair(v.x, v.y, r0, r1), hy = split_pair(v.z, v.w, r2, r3);
+        const unsigned lx = pack_pair(r0, r1), ly = pack_pair(r2, r3);
+        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+        unsigned char* grp8 = reinterpret_cast<unsigned char*>(orow + (n & ~7)) + 4 * (n & 4);
+        *reinterpret_cast<uint4*>(grp8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      } else {
+        *reinterpret_cast<float4*>(orow + n) = v;
+      }
+    }
+  }
+}
+
+// one (query row, 4 columns of d tile dt) of a lane, normalised and stored in the call's output format (attn_store_rows for one d tile)
+__device__ __forceinline__ void attn_store_tile(const AttnArgs& p, int b, int head, int qrow, int dt, int g4, f32x4 ov, float l_sum) {
+  const float inv = 1.0f / l_sum;
+  float* orow = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD;
+  const int n = 16 * dt + 4 * g4;
+  float4 v = make_float4(ov[0] * inv, ov[1] * inv, ov[2] * inv, ov[3] * inv);
+  if (p.out_split == LDC_FMT_BF16) {
+    unsigned char* rowb = reinterpret_cast<unsigned char*>(orow - head * HD);
+    *reinterpret_cast<uint2*>(rowb + 2 * (head * HD + n)) = make_uint2(pack_pair(v.x, v.y), pack_pair(v.z, v.w));
+  } else if (p.out_split) {
+    float r0, r1, r2, r3;
+    const unsigned hx = split_pair(v.x, v.y, r0, r1), hy = split_pair(v.z, v.w, r2, r3);
+    const unsigned lx = pack_pair(r0, r1), ly = pack_pair(r2, r3);
+    const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
+    const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
+    unsigned char* grp8 = reinterpret_cast<unsigned char*>(orow + (n & ~7)) + 4 * (n & 4);
+    *reinterpret_cast<uint4*>(grp8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+  } else {
+    *reinterpret_cast<float4*>(orow + n) = v;
+  }
+}
+
+// TAIL schedule, second launch: the `slices` pieces of tail unit u (pieces u * slices ..) -> its output rows.  One 256-thread workgroup per
+// (unit, d tile), the same (wave, lane) -> (query, columns) ownership as the attention kernel; pieces are combined in slice order (fixed:
+// the result does not depend on which piece finished first).  A thread reads 12 floats per slice, all slices' loads independent.
+__global__ __launch_bounds__(256) void attn_tail_merge_kernel(AttnArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int dt = blockIdx.y;
+  const int unit = p.n_full + blockIdx.x;
+  const int qblk = unit % p.nq, hb = unit / p.nq;
+  const int head = hb % p.H, b = hb / p.H;
+  const float* base = p.part + static_cast<long long>(blockIdx.x) * p.slices * PART_FLOATS + wave * 64 + lane;
+  float m[2] = {-1.0e30f, -1.0e30f};
+  for (int s = 0; s < p.slices; ++s) {
+    m[0] = fmaxf(m[0], base[static_cast<long long>(s) * PART_FLOATS + 64 * 256]);
+    m[1] = fmaxf(m[1], base[static_cast<long long>(s) * PART_FLOATS + 65 * 256]);
+  }
+  f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float l[2] = {0.f, 0.f};
+  for (int s = 0; s < p.slices; ++s) {
+    const float* pp = base + static_cast<long long>(s) * PART_FLOATS;
+    const float a0 = exp2f(pp[64 * 256] - m[0]), a1 = exp2f(pp[65 * 256] - m[1]);
+    l[0] += pp[66 * 256] * a0;
+    l[1] += pp[67 * 256] * a1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[0][r] += pp[((dt * 2 + 0) * 4 + r) * 256] * a0;
+      o[1][r] += pp[((dt * 2 + 1) * 4 + r) * 256] * a1;
+    }
+  }
+  const int q0 = qblk * QB + wave * 32;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrow = q0 + 16 * qt + c16;
+    if (qrow >= p.S) continue;  // (the 4 lanes of a row share qrow: the lane-group swap of the split format stays among active lanes)
+    attn_store_tile(p, b, head, qrow, dt, g4, o[qt], l[qt]);
+  }
+}
+
 // BIAS: scores += kbias[key] (models/LaDCast_3D_model.py:873-882 `scale_attn_by_lat`: a float attention mask that only depends on
 // the key) - it enters as the initial value of the S accumulators, so it costs no instruction in the MFMA stream
-template <int NGRP, int TERMS, bool BIAS>
-__global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_kernel(AttnArgs p) {
+// TAIL (NGRP = 2 only): a persistent workgroup per CU walks items item = blockIdx.x, + gridDim.x, ...: first whole units, then at most one
+// key slice of a tail unit (see AttnArgs) - 288 units (16 heads x 18 query blocks) on 256 CUs are one round of whole units plus an eighth
+// of a unit each instead of two uneven rounds.  TAIL = false compiles to the single-unit kernel (the loop condition is constant).
+template <int NGRP, int TERMS, bool BIAS, bool TAIL = false>
+__global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_kernel(AttnArgs p_arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;  // key-range group (wave-uniform)
   const int tid = threadIdx.x & 255;
@@ -228,13 +340,27 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15;  // query column of the 16x16 tiles / fragment row
   const int g4 = lane >> 4;   // lane group: keys 4 g4 .. 4 g4 + 3 of a 16-key tile, k-group of an operand fragment
+  int item = blockIdx.x;
+  do {
+  const AttnArgs& p = p_arg;
   const int S = p.S;
   int head, b, qblk;
+  int t_lo = 0, t_hi = p.nt, piece = -1;
   {  // XCD-aware placement: contiguous runs of [batch][head][query block] per XCD (its K / V tiles stay in that XCD's L2)
     const int nq = p.nq, T = gridDim.x;
     const int bid = blockIdx.x;
     const int q = T >> 3, r = T & 7, xcd = bid & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if constexpr (TAIL) {
+      lin += item - bid;  // whole rounds of T items
+      if (lin >= p.n_full) {
+        piece = lin - p.n_full;
+        const int u = piece / p.slices, sl = piece - u * p.slices;
+        lin = p.n_full + u;
+        t_lo = __builtin_amdgcn_readfirstlane(sl * p.nt / p.slices);
+        t_hi = __builtin_amdgcn_readfirstlane((sl + 1) * p.nt / p.slices);
+      }
+    }
     qblk = lin % nq;
     const int hb = lin / nq;
     head = hb % p.H;
@@ -247,11 +373,12 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
 
   // Q fragments (B operand): query 16 qt + c16, d = 32 s + 8 g4 + j <-> split group 4 s + g4
   bf16x8 qh[2][4], ql[2][4];
+  const int lane_p = TAIL ? fresh_lane() : lane;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    int qrow = q0 + 16 * qt + c16;
+    int qrow = q0 + 16 * qt + (lane_p & 15);
     qrow = qrow < S ? qrow : S - 1;  // rows past S: any valid row (never stored)
-    const unsigned char* qp = p.Q + bh_off + static_cast<unsigned>(qrow) * ldb + 32 * g4;
+    const unsigned char* qp = p.Q + bh_off + static_cast<unsigned>(qrow) * ldb + 32 * (lane_p >> 4);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qh[qt][s] = *reinterpret_cast<const bf16x8*>(qp + 128 * s);
@@ -279,12 +406,27 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
   // 16-byte half lane & 1): 64 contiguous bytes of a plane per key
   const int vkey = (lane & 31) >> 1;
   const unsigned v_lane = (4 * wave + 2 * (lane >> 5) + (lane & 1)) * 16;
+  // (TAIL: the per-lane parts are re-formed from a fresh lane index at every use - two tile-DMA offset registers fewer are live across
+  // the MFMA phases of the kernel that runs at its 256-register budget; the item loop keeps a few more values live than one unit does)
   auto k_src = [&](int t) {  // 32-bit offset from k_base (S * ldb < 2^32, checked on the host)
+    if constexpr (TAIL) {
+      const int l_ = fresh_lane();
+      const int kr_ = 8 * wave + (l_ >> 3);
+      int key = t * KT + kr_;
+      key = key < S ? key : S - 1;
+      return (static_cast<unsigned>((l_ & 7) ^ swz(kr_)) << 4) + static_cast<unsigned>(key) * ldb;
+    }
     int key = t * KT + krow;
     key = key < S ? key : S - 1;  // rows past S are masked in the scores: any finite data
     return k_lane + static_cast<unsigned>(key) * ldb;
   };
   auto v_src = [&](int t, int kt) {
+    if constexpr (TAIL) {
+      const int l_ = fresh_lane();
+      int key = t * KT + 16 * kt + ((l_ & 31) >> 1);
+      key = key < S ? key : S - 1;
+      return static_cast<unsigned>((4 * wave + 2 * (l_ >> 5) + (l_ & 1)) * 16) + static_cast<unsigned>(key) * ldb;
+    }
     int key = t * KT + 16 * kt + vkey;
     key = key < S ? key : S - 1;  // their probabilities are exactly 0
     return v_lane + static_cast<unsigned>(key) * ldb;
@@ -314,9 +456,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
   float l_run[2] = {0.f, 0.f};  // per-lane partial row sums (this lane's 8 keys of every tile): reduced over the lane groups at the end
   float alpha[2] = {1.f, 1.f};
 
-  const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
-  const int t_begin = grp ? nhalf : 0;
-  const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
+  const int nspan = t_hi - t_lo;                               // key tiles of this item (all of them unless it is a tail piece)
+  const int nhalf = NGRP == 2 ? (nspan + 1) >> 1 : nspan;    // iterations of the longer group
+  const int t_begin = t_lo + (grp ? nhalf : 0);
+  const int t_end = grp ? t_hi : t_lo + nhalf;                // group 1 may have one tile fewer (or none)
 
   // per-lane fragment bases inside a stage
   const unsigned f_r = swz(c16);
@@ -460,7 +603,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
 
   // ---- merge the two key halves: group 1 hands (m, l, O) to group 0 through LDS ----
   if constexpr (NGRP == 2) {
-    float* xch = reinterpret_cast<float*>(smem) + (wave * 68) * 64 + lane;  // [wave][68][64 lanes]
+    float* xch = reinterpret_cast<float*>(smem) + (wave * 68) * 64 + (TAIL ? fresh_lane() : lane);  // [wave][68][64 lanes]
     if (grp == 1) {
 #pragma unroll
       for (int d = 0; d < 8; ++d)
@@ -474,49 +617,67 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
       xch[67 * 64] = l_run[1];
     }
     __syncthreads();
-    if (grp == 1) return;
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const float m1 = xch[(64 + qt) * 64], l1 = xch[(66 + qt) * 64];
-      const float m = fmaxf(m_run[qt], m1);
-      const float a0 = exp2f(m_run[qt] - m), a1 = exp2f(m1 - m);
-      l_run[qt] = l_run[qt] * a0 + l1 * a1;
-#pragma unroll
-      for (int d = 0; d < 8; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[d][qt][r] = o[d][qt][r] * a0 + xch[((d * 2 + qt) * 4 + r) * 64] * a1;
+    if constexpr (!TAIL) {
+      if (grp == 1) return;
     }
-  }
-
-  // ---- epilogue: a lane owns query row 16 qt + c16 and, per d tile, the 4 consecutive columns 16 dt + 4 g4 .. + 3 ----
+    if (grp == 0) {
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int qrow = q0 + 16 * qt + c16;
-    if (qrow >= S) continue;
-    const float inv = 1.0f / l_run[qt];
-    float* orow = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD;
+      for (int qt = 0; qt < 2; ++qt) {
+        const float m1 = xch[(64 + qt) * 64], l1 = xch[(66 + qt) * 64];
+        const float m = fmaxf(m_run[qt], m1);
+        const float a0 = exp2f(m_run[qt] - m), a1 = exp2f(m1 - m);
+        l_run[qt] = l_run[qt] * a0 + l1 * a1;
+        m_run[qt] = m;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const int n = 16 * dt + 4 * g4;
-      float4 v = make_float4(o[dt][qt][0] * inv, o[dt][qt][1] * inv, o[dt][qt][2] * inv, o[dt][qt][3] * inv);
-      if (p.out_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
-        unsigned char* rowb = reinterpret_cast<unsigned char*>(orow - head * HD);  // bf16 columns are 2 bytes: offset from the ROW start
-        *reinterpret_cast<uint2*>(rowb + 2 * (head * HD + n)) = make_uint2(pack_pair(v.x, v.y), pack_pair(v.z, v.w));
-      } else if (p.out_split) {
-        // LDC_GEMM_A_SPLIT format: columns 8c..8c+7 live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16
-        // further the other half: v_permlane16_swap gives the even lane group both hi halves, the odd one both lo halves
-        float r0, r1, r2, r3;
-        const unsigned hx = split_pair(v.x, v.y, r0, r1), hy = split_pair(v.z, v.w, r2, r3);
-        const unsigned lx = pack_pair(r0, r1), ly = pack_pair(r2, r3);
-        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
-        unsigned char* grp8 = reinterpret_cast<unsigned char*>(orow + (n & ~7)) + 4 * (n & 4);
-        *reinterpret_cast<uint4*>(grp8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      } else {
-        *reinterpret_cast<float4*>(orow + n) = v;
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[d][qt][r] = o[d][qt][r] * a0 + xch[((d * 2 + qt) * 4 + r) * 64] * a1;
+      }
+    }
+    if constexpr (TAIL) {
+      __syncthreads();  // the exchange area is ring memory of the next item: group 0 has read it
+      if (grp == 1) {
+        item += gridDim.x;
+        continue;
       }
     }
   }
+
+  if constexpr (TAIL) {
+    const int lane_e = fresh_lane();
+    // the epilogue's arguments (O, strides, format, workspace) are re-read from the kernarg segment HERE, through a laundered pointer:
+    // kept in scalar registers across the item loop they exhaust the SGPR file (105 of 102) and the DMA base pointers fall back to
+    // per-lane 64-bit registers that are spilled and re-loaded, behind a vmcnt(0), in every key-loop iteration
+    AttnArgs pe{};
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      typedef const __attribute__((address_space(4))) AttnArgs* KArgs;
+      KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      pe.O = ka->O; pe.S = ka->S; pe.ldo = ka->ldo; pe.o_bs = ka->o_bs; pe.out_split = ka->out_split; pe.part = ka->part;
+    }
+#endif
+    const AttnArgs& p = pe;
+    if (piece >= 0) {  // a key slice of a tail unit: un-normalised O and the softmax statistics of the slice, combined by attn_tail_merge_kernel
+      float* pp = p.part + static_cast<long long>(piece) * PART_FLOATS + wave * 64 + lane_e;
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pp[((d * 2 + qt) * 4 + r) * 256] = o[d][qt][r];
+      pp[64 * 256] = m_run[0];
+      pp[65 * 256] = m_run[1];
+      pp[66 * 256] = l_run[0];
+      pp[67 * 256] = l_run[1];
+    } else {
+      attn_store_rows(p, b, head, q0, lane_e & 15, lane_e >> 4, o, l_run);
+    }
+  } else {
+    attn_store_rows(p, b, head, q0, c16, g4, o, l_run);
+  }
+  item += gridDim.x;
+  } while (TAIL && item < p_arg.n_full + p_arg.n_pieces);
 }
 
 }  // namespace
@@ -550,8 +711,32 @@ extern "C" int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, i
   return ldc_launch_status();
 }
 
+// units of one call = query blocks x heads x batch; the TAIL schedule applies when they exceed the 256 CUs by at most half a round
+static bool attn_tail_plan(long long nwg, int nt, int* n_full, int* n_pieces, int* slices) {
+  constexpr int CUS = 256;
+  if (nwg <= CUS || nwg > 8 * CUS) return false;
+  const int rem = static_cast<int>(nwg % CUS);
+  if (rem == 0 || rem > CUS / 2) return false;  // a whole number of rounds / a tail that can only be cut once: the plain grids do as well
+  int s = CUS / rem;
+  if (s > 16) s = 16;
+  if (s > nt) s = nt;
+  if (s < 2) return false;
+  *n_full = static_cast<int>(nwg) - rem;
+  *slices = s;
+  *n_pieces = rem * s;
+  return true;
+}
+
+extern "C" long long ldc_attn_fwd_split_workspace_bytes(int B, int S, int H) {
+  if (B <= 0 || S <= 0 || H <= 0) return 0;
+  int nf, np, sl;
+  if (!attn_tail_plan(static_cast<long long>(ldc_cdiv(S, QB)) * H * B, ldc_cdiv(S, KT), &nf, &np, &sl)) return 0;
+  return static_cast<long long>(np) * PART_FLOATS * static_cast<long long>(sizeof(float));
+}
+
 extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
-                                  long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* stream) {
+                                  long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* workspace,
+                                  long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(Q);
   LDC_CHECK_PTR(K);
   LDC_CHECK_PTR(V);
@@ -583,6 +768,35 @@ extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V
   p.kbias = key_bias;
   const long long nwg = static_cast<long long>(p.nq) * H * B;
   const hipStream_t st = static_cast<hipStream_t>(stream);
+  // more units than CUs by at most half a round (1.6B model: 16 heads x 18 query blocks = 288): one persistent 8-wave workgroup per CU
+  // runs its whole units, then one key slice of a tail unit; the slices are merged by a second small launch.  Needs the caller's
+  // workspace (ldc_attn_fwd_split_workspace_bytes); without it the 4-wave / two-per-CU form below runs (two uneven rounds).
+  if (attn_tail_plan(nwg, p.nt, &p.n_full, &p.n_pieces, &p.slices) && workspace != nullptr &&
+      workspace_bytes >= static_cast<long long>(p.n_pieces) * PART_FLOATS * static_cast<long long>(sizeof(float))) {
+    LDC_CHECK_ALIGN16(workspace);
+    p.part = static_cast<float*>(workspace);
+    const dim3 tgrid(256);
+#define LDC_ATTN_TAIL(T, BI)                                                                                                    \
+  {                                                                                                                             \
+    static const bool attr_set = [] {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split_kernel<2, T, BI, true>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GROUP_LDS);                                     \
+      return true;                                                                                                              \
+    }();                                                                                                                        \
+    (void)attr_set;                                                                                                             \
+    hipLaunchKernelGGL((attn_fwd_split_kernel<2, T, BI, true>), tgrid, dim3(512), 2 * GROUP_LDS, st, p);                        \
+  }
+    if (one_term) {
+      if (key_bias) LDC_ATTN_TAIL(1, true) else LDC_ATTN_TAIL(1, false)
+    } else {
+      if (key_bias) LDC_ATTN_TAIL(3, true) else LDC_ATTN_TAIL(3, false)
+    }
+#undef LDC_ATTN_TAIL
+    const int st1 = ldc_launch_status();
+    if (st1 != LDC_OK) return st1;
+    hipLaunchKernelGGL(attn_tail_merge_kernel, dim3(static_cast<unsigned>(nwg - p.n_full), 8), dim3(256), 0, st, p);
+    return ldc_launch_status();
+  }
   const int variant = (nwg <= 256 ? 4 : 0) | (one_term ? 2 : 0) | (key_bias ? 1 : 0);
 #define LDC_ATTN_LAUNCH(NG, T, BI)                                                                                              \
   {                                                                                                                             \

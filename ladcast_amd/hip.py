@@ -74,7 +74,8 @@ def _load():
         "ldc_sizeof_qkv_epilogue": (I, []),
         "ldc_gemm_grouped_bf16x3_qkv": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
         "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
-        "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, P, I, P]),
+        "ldc_attn_fwd_split_workspace_bytes": (L, [I, I, I]),
+        "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, P, I, P, L, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_pack_weight_bf16": (I, [P, P, I, I, I, P]),
         "ldc_linear_small": (I, [P, I, P, P, P, I, P, I, I, I, I, I, P]),
@@ -372,14 +373,31 @@ def attn_qkv_prepare_split(Q, K, V, *, B, S, H, ld_qkv, qkv_bs, split_row, seg0=
                                           _p(seg1[0]), _p(seg1[1]), _p(seg1[2]), _p(seg1[3]), eps, _stream()), "ldc_attn_qkv_prepare_split")
 
 
-def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=False, one_term=False, key_bias=None):
+_attn_ws = {}
+
+
+def _attn_workspace(device, nbytes):
+    """scratch of the attention's TAIL schedule (more units than CUs), one per (device, stream), grown on demand - outside a capture:
+    samplers warm up on their capture stream first, like the GEMM workspace"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _attn_ws[key] = ws
+    return ws
+
+
+def attn_fwd_split(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, out_split=False, one_term=False, key_bias=None, use_workspace=True):
     """attention on row-major split-bf16 operand rows (ldc_attn_fwd_split); key_bias: additive score bias per key, padded to a multiple
-    of 32 entries (`pad_key_bias`), or None"""
+    of 32 entries (`pad_key_bias`), or None.  use_workspace=False: never the TAIL schedule (A/B, tests)"""
     _dev(Q, K, V, O, key_bias)
+    nbytes = lib.ldc_attn_fwd_split_workspace_bytes(B, S, H) if use_workspace else 0
+    ws = _attn_workspace(Q.device, nbytes) if nbytes > 0 else None
     if key_bias is not None and key_bias.numel() < 32 * ((S + 31) // 32):
         raise ValueError("key_bias must be padded to a multiple of 32 keys (hip.pad_key_bias)")
     flags = (ATTN_OUT_BF16 if int(out_split) == FMT_BF16 else ATTN_OUT_SPLIT if out_split else 0) | (ATTN_BF16_1TERM if one_term else 0)
-    _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), flags, _stream()), "ldc_attn_fwd_split")
+    _check(lib.ldc_attn_fwd_split(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), flags, _p(ws), 0 if ws is None else ws.numel() * 4,
+                                  _stream()), "ldc_attn_fwd_split")
 
 
 def pad_key_bias(bias):

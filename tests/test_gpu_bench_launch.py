@@ -52,32 +52,21 @@ def test_bench_rejects_mismatched_world():
 
 def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
     """BASELINE configs[2] in shape on the one GPU of the test box: `--gpus 8 --ensemble-size 16 --lead-steps 4` over gloo, every rank
-    on GPU 0 - two members per rank (rank r owns members r and r + 8), one collective.  The gathered (1, 16, 84, 5, 15, 30) tensor
-    must equal, BIT FOR BIT, what one process computes for the same member pairs (same kernels, same batch shape), i.e. the
-    partition, the padding / trimming of the all_gather and the member order lose nothing; against the one-process run of all 16
-    members as ONE batch it agrees to fp32 rounding only (another stream-K cut: documented in pipelines/distributed.py).  The line
-    carries the per-rank diagnostics a SCALE run is read from."""
+    on GPU 0 - two members per rank (rank r owns members r and r + 8), one collective.  In the exact-fp32 mode the gathered
+    (1, 16, 84, 5, 15, 30) tensor must equal, BIT FOR BIT, what one process computes for the same member pairs (same kernels, same
+    batch shape): the partition, the padding / trimming of the all_gather and the member order lose nothing.  Against the one-process
+    run of all 16 members as ONE batch it agrees to fp32 rounding only (another stream-K cut: documented in pipelines/distributed.py).
+    The line carries the per-rank diagnostics a SCALE run is read from.
+
+    The split-bf16 mode is run the same way but compared with a TOLERANCE: when several PROCESSES share one GPU, workgroups of the
+    4-wave split attention (the form used for more than 256 units, here batch 2) and of the wide AdaLN GEMV from different processes
+    become co-resident on a SIMD, and the GEMV's results then differ at the 1e-3 level from run to run (isolated with a victim /
+    aggressor experiment, profiles/r04_*_gpu_sharing_*.log; neither kernel is affected inside one process - the soak runs are bit
+    exact - and one process per GPU is the production topology).  The dry run still checks the partition logic in that mode."""
     import torch
     from datetime import datetime
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    dump = str(tmp_path / "gathered.pt")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpus", "--ensemble-size", "16", "--lead-steps", "4",
-           "--steps", "1", "--warmup", "0", "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--dump-output", dump]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["members_on_rank"] == [2] * 8
-    pr = line["ranks"]["per_rank"]
-    assert len(pr["ms_per_step"]) == 8 and pr["members"] == [2] * 8 and len(pr["gather_ms_per_step"]) == 8
-    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and all(v > 0 for v in pr["rollout_ms_per_step"])
-    assert abs(line["value"] - 16 * 4 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
-    got = torch.load(dump)
-    assert got.shape == (1, 16, 84, 5, 15, 30) and torch.isfinite(got).all()
-
-    # the same work in ONE process: the eight member pairs one after the other, then all 16 members as one batch
     sys.path.insert(0, ROOT)
     import bench
     from ladcast_amd.models import LaDCastTransformer3DModel
@@ -86,19 +75,43 @@ def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
     from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
 
     torch.manual_seed(1234)
-    model = LaDCastTransformer3DModel.from_config(bench.CONFIGS["375M"]).to("cuda").eval().set_gemm_precision("bf16x3")
+    model = LaDCastTransformer3DModel.from_config(bench.CONFIGS["375M"]).to("cuda").eval()
     model.enable_hip_graph(True)
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).cuda()
     kw = dict(num_inference_steps=20, return_seq_len=4, latent_transform_args={"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5},
               total_lead_time_hour=24, sampler_type="edm", return_latent=True, known_latents_override=ic)
-    want = torch.empty_like(got)
-    for rank in range(8):
-        ids = shard_members(16, rank, 8)
-        assert ids == [rank, rank + 8]
-        want[:, ids] = roll_out_serial(None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=2, member_ids=ids, **kw)
-    assert torch.equal(got, want)
-    whole = roll_out_serial(None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=16, **kw)
-    e = ((whole.double() - got.double()).norm() / got.double().norm()).item()
-    print(f"\n8 ranks x 2 members == one process, pair by pair: bit for bit; vs all 16 members as one batch: rel-L2 {e:.2e}")
-    assert e < 1e-4
+    for mode in ("fp32", "bf16x3"):
+        dump = str(tmp_path / f"gathered_{mode}.pt")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpus", "--ensemble-size", "16", "--lead-steps", "4",
+               "--steps", "1", "--warmup", "0", "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--precision", mode, "--dump-output", dump]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["members_on_rank"] == [2] * 8
+        pr = line["ranks"]["per_rank"]
+        assert len(pr["ms_per_step"]) == 8 and pr["members"] == [2] * 8 and len(pr["gather_ms_per_step"]) == 8
+        assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and all(v > 0 for v in pr["rollout_ms_per_step"])
+        assert abs(line["value"] - 16 * 4 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+        got = torch.load(dump)
+        assert got.shape == (1, 16, 84, 5, 15, 30) and torch.isfinite(got).all()
+        # the same work in ONE process: the eight member pairs one after the other, then all 16 members as one batch
+        model.set_gemm_precision(mode)
+        want = torch.empty_like(got)
+        for rank in range(8):
+            ids = shard_members(16, rank, 8)
+            assert ids == [rank, rank + 8]
+            want[:, ids] = roll_out_serial(None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=2, member_ids=ids, **kw)
+        e_pairs = ((want.double() - got.double()).norm() / want.double().norm()).item()
+        whole = roll_out_serial(None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=16, **kw)
+        e_whole = ((whole.double() - got.double()).norm() / got.double().norm()).item()
+        print(f"\n[{mode}] 8 ranks x 2 members vs one process pair by pair: {'bit for bit' if torch.equal(got, want) else f'rel-L2 {e_pairs:.2e}'}; "
+              f"vs all 16 members as one batch: rel-L2 {e_whole:.2e}")
+        assert torch.equal(got[:, :, :, 0], want[:, :, :, 0])  # slot 0: the IC latent, member order and padding of the gather
+        if mode == "fp32":
+            assert torch.equal(got, want)
+            assert e_whole < 1e-5
+        else:
+            assert e_pairs < 5e-3 and e_whole < 5e-3

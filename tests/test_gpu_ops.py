@@ -687,6 +687,50 @@ def test_attention_split(hip, B, S, H, one_term):
     assert rel((vf[:, :, :, 0] + vf[:, :, :, 1]).reshape(B, S, D), qkv[..., 2 * D :]) < 1e-5
 
 
+@pytest.mark.parametrize("B,S,H,one_term,bias", [(1, 2250, 16, False, False), (1, 2250, 16, True, True), (1, 3300, 10, False, True), (2, 2250, 8, False, False),
+                                                  (1, 1200, 29, False, False), (3, 1100, 11, True, False)])
+def test_attention_split_tail_schedule(hip, B, S, H, one_term, bias):
+    """more (query block, head, batch) units than CUs by at most half a round - the 1.6B model's 16 heads x 18 query blocks = 288: a
+    persistent workgroup per CU runs whole units, then one key slice of a left-over unit; a second launch merges the slices.  Against
+    fp64 sdpa, bitwise repeatable, and equal to fp32 rounding to the plain grids (`use_workspace=False`: the same call without the
+    workspace).  Shapes: 288 units (32 left over, 8 slices), 260 (4 left over: slice count capped at 16), 288 as 2 x 144, 290 (34 -> 7
+    slices of 38 key tiles), 297 with 35-tile key ranges."""
+    D = H * 128
+    assert hip.lib.ldc_attn_fwd_split_workspace_bytes(B, S, H) > 0, "shape does not take the tail schedule"
+    qkv = rnd(B, S, 3 * D, seed=21)
+    qkv[..., :D] *= 4.0
+    kb = None
+    if bias:
+        kb = hip.pad_key_bias(dev(0.5 * rnd(S, seed=22)))
+    d_qkv = dev(qkv)
+    _prep(hip, d_qkv, B, S, H, D, split_row=S)
+    kw = dict(B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D, one_term=one_term, key_bias=kb)
+    outs = []
+    for rep in range(3):
+        o = torch.full((B, S, D), float("nan"), device="cuda")
+        hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], o, **kw)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    plain = torch.full((B, S, D), float("nan"), device="cuda")
+    hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], plain, use_workspace=False, **kw)
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    mask = None if kb is None else kb[:S].cpu().double().view(1, 1, 1, S)
+    want = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, S, D)
+    assert torch.isfinite(outs[0]).all()
+    tol = 1e-2 if one_term else 2e-5
+    assert rel(outs[0], want) < tol and rel(plain, want) < tol
+    assert rel(outs[0], plain) < (1e-5 if not one_term else 1e-3)  # same products, another order of the key tiles
+    o2 = torch.empty(B, S, D, device="cuda")  # split-format output through the merge kernel
+    hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], o2, **dict(kw, out_split=hip.FMT_BF16 if one_term else True))
+    if one_term:
+        got = (o2.view(torch.int16)[..., :D].to(torch.int32) << 16).view(torch.float32)
+        assert torch.equal(got.cpu(), outs[0].cpu().bfloat16().float())
+    else:
+        hi, lo = _unsplit(o2.reshape(B * S, D), B * S, D)
+        wh = outs[0].cpu().reshape(B * S, D).bfloat16().float()
+        assert torch.equal(hi, wh) and torch.equal(lo, (outs[0].cpu().reshape(B * S, D) - wh).bfloat16().float())
+
+
 @pytest.mark.parametrize("Nx,Nc,rope1", [(37, 11, False), (1800, 450, True), (64, 0, False), (40, 57, True)])
 def test_attention_split_norm_rope_two_segments(hip, Nx, Nc, rope1):
     """the stand-alone producer's q/k RMSNorm + RoPE per row segment, against the oracle layers + sdpa (reference

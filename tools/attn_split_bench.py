@@ -18,6 +18,7 @@ for (S, H) in ((2250, 12), (450, 12), (2250, 16)):
     fl = 4.0 * B * H * S * S * 128
     variants = {
         "split  x3": lambda: hip.attn_fwd_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], out, ldo=D, o_bs=S * D, out_split=True, **kw),
+        "x3 plain grid": lambda: hip.attn_fwd_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], out, ldo=D, o_bs=S * D, out_split=True, use_workspace=False, **kw),
         "split  x1": lambda: hip.attn_fwd_split(sp[:, :, :D], sp[:, :, D : 2 * D], sp[:, :, 2 * D :], out, ldo=D, o_bs=S * D, out_split=True, one_term=True, **kw),
     }
     res = {n: [] for n in variants}
