@@ -408,6 +408,10 @@ int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, v
  * hold (252: the last group's pad columns are zero in X and in Wp).  ksize 1 / 3 / 5.
  * in_fmt = LDC_FMT_BF16 is the single-term `bf16` mode of the same conv (see LDC_GEMM_BF16_1TERM): X plain bf16 rows (same ldx, in
  * floats), Wp = ldc_pack_weight_bf16 of the [cout][k*k][cin rounded up to 64 * 2^j] tap-major weight, out_fmt LDC_FMT_F32 | LDC_FMT_BF16.
+ * in_fmt = LDC_FMT_F32 (ABI 3) is the EXACT-fp32 conv on the same kernel (v_mfma_f32_16x16x4_f32 on plain fp32 operand rows, the conv
+ * gather unchanged): X plain fp32 rows (ldx % 4 == 0, cin % 4 == 0), Wp the plain fp32 [cout][k*k][cin rounded up to 32 * 2^j]
+ * tap-major weight with zeros behind cin, out_fmt LDC_FMT_F32 - what AutoencoderDC runs in its fp32 mode (ldc_sphere_conv_nhwc, the
+ * tile-per-workgroup kernel, stays for channel counts that are no multiple of 4 and as the second implementation in the tests).
  * Replaces models/sphere_conv.py:62-192 + the nn.Conv2d / nn.Linear 1x1 layers of models/DCAE.py:96-324. */
 int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W,
                                int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int in_fmt, int out_fmt,

@@ -340,19 +340,24 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_split_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15;  // query column of the 16x16 tiles / fragment row
   const int g4 = lane >> 4;   // lane group: keys 4 g4 .. 4 g4 + 3 of a 16-key tile, k-group of an operand fragment
-  int item = blockIdx.x;
+  // XCD-aware placement: contiguous runs of [batch][head][query block] per XCD (its K / V tiles stay in that XCD's L2).  TAIL: the
+  // workgroup's items are lin0, lin0 + T, lin0 + 2 T, ... (T = grid size) in that permuted numbering - whole units below n_full, then
+  // piece lin - n_full; a workgroup takes part in the last round only if its permuted index is a piece that exists
+  int item;
+  {
+    const int T = gridDim.x, bid = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   do {
   const AttnArgs& p = p_arg;
   const int S = p.S;
   int head, b, qblk;
   int t_lo = 0, t_hi = p.nt, piece = -1;
-  {  // XCD-aware placement: contiguous runs of [batch][head][query block] per XCD (its K / V tiles stay in that XCD's L2)
-    const int nq = p.nq, T = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = T >> 3, r = T & 7, xcd = bid & 7;
-    int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  {
+    const int nq = p.nq;
+    int lin = item;
     if constexpr (TAIL) {
-      lin += item - bid;  // whole rounds of T items
       if (lin >= p.n_full) {
         piece = lin - p.n_full;
         const int u = piece / p.slices, sl = piece - u * p.slices;

@@ -1012,6 +1012,13 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       if (gmax < G) G = gmax;
     }
   }
+  if constexpr (TERMS == 0) {  // (the DCAE's fp32 convs too: 8.09 / 8.83 -> 7.73 / 8.41 ms per frame, profiles/r04_l_dcae_unit_ranges_ab.txt; the split modes lose 10 % with it)
+    // exact fp32 (round 4): ALWAYS one unit range per CU, cut wherever U / 256 falls.  The fp32 k-step is matrix-pipe bound (5x the split
+    // kernel's MFMA time per k-step), so the L2 lockstep that made unaligned ranges 40 % slower in the split mode does not matter here and
+    // the chip is not at its power cap: idle CUs cost their full share.  375M in fp32 mode, same box: 111.3 -> 118.5 TFLOP/s per GEMM launch,
+    // 2.82 -> 2.96 member-steps/s (aligned 240 / 248 ranges: 111.6 / 115.0; profiles/r04_k_fp32_unit_ranges.txt)
+    if (U >= 4 * CUS) G = CUS;
+  }
   static const char* const force_g = LDC_AB_GETENV("LDC_BF16X3_G");  // measurement aid (read once): force the number of unit ranges
   if (force_g) {
     const long long g_ = atoll(force_g);
@@ -1112,6 +1119,8 @@ extern "C" int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, con
 // ldc_sphere_conv_nhwc_bf16x3; Y: fp32 rows or (out_fmt = LDC_FMT_SPLIT) split rows for the next conv.
 // in_fmt = LDC_FMT_BF16 (the single-term `bf16` mode): X is plain bf16 rows (same row stride ldx in floats), Wp = ldc_pack_weight_bf16
 // of the [cout][k*k][cin rounded up to 64 * 2^j] weight; Y: fp32 rows or (out_fmt = LDC_FMT_BF16) plain bf16 rows.
+// in_fmt = LDC_FMT_F32 (round 4, the exact-fp32 mode): X is plain fp32 rows (ldx % 4 == 0, cin % 4 == 0), Wp the plain fp32
+// [cout][k*k][cin rounded up to 32 * 2^j] tap-major weight (zeros behind cin), Y fp32 rows - the TERMS = 0 instantiation.
 extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H,
                                           int W, int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int in_fmt,
                                           int out_fmt, void* workspace, long long workspace_bytes, void* stream) {
@@ -1121,9 +1130,13 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return LDC_ERR_ARG;
   if (ksize != 1 && ksize != 3 && ksize != 5) return LDC_ERR_UNSUPPORTED;
   if (ksize > 1 && ((W & 1) || H < 2 || H < ksize / 2 || W / 2 < ksize / 2 || H > 32767 || W > 65535)) return LDC_ERR_UNSUPPORTED;
-  if (in_fmt != LDC_FMT_SPLIT && in_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
+  if (in_fmt != LDC_FMT_SPLIT && in_fmt != LDC_FMT_BF16 && in_fmt != LDC_FMT_F32) return LDC_ERR_UNSUPPORTED;
   if (out_fmt != LDC_FMT_F32 && out_fmt != in_fmt) return LDC_ERR_UNSUPPORTED;
-  if ((ldx & 7) || ldx < ((cin + 7) & ~7) || ldy < cout) return LDC_ERR_ALIGN;
+  if (in_fmt == LDC_FMT_F32) {  // exact fp32 (round 4): plain fp32 pixel rows, 16-byte chunks of 4 channels
+    if ((ldx & 3) || (cin & 3) || ldx < cin || ldy < cout) return LDC_ERR_ALIGN;
+  } else if ((ldx & 7) || ldx < ((cin + 7) & ~7) || ldy < cout) {
+    return LDC_ERR_ALIGN;
+  }
   const long long M = static_cast<long long>(B) * H * W;
   if (M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   const bool one = in_fmt == LDC_FMT_BF16;
@@ -1148,6 +1161,12 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
   q.d.ldr = ldr;
   q.d.act = act;
   q.d.flags = LDC_GEMM_A_SPLIT | (out_fmt != LDC_FMT_F32 ? LDC_GEMM_C_SPLIT : 0) | (one ? LDC_GEMM_BF16_1TERM : 0);
+  if (in_fmt == LDC_FMT_F32) {
+    // the exact-fp32 variant of the ring kernel (TERMS = 0: v_mfma_f32_16x16x4_f32 on plain fp32 operand rows) with the same conv gather;
+    // 128-row tiles only, as for the fp32 GEMMs (a tile is 2.7x the split kernel's MFMA time: balance beats the halved W traffic)
+    q.d.flags = 0;
+    return launch_v3<128, 0, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
+  }
   const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
   // tile height: measured cross-over (tools/conv_bench.py) - 252 -> 252 at 120 x 240 (226 tiles of 256 rows): 101 us at 256 rows, 121 at
   // 128; 504 -> 504 at 60 x 120 (116 tiles): 122 / 111; four frames of it (464): 350 / 437.  LDC_CONV_SMALL_TILES: measurement aid

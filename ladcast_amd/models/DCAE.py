@@ -22,7 +22,8 @@ import torch.nn as nn
 
 from .. import hip
 from .modeling_utils import ModelMixin
-from .sphere_conv import SphereConv2d, ceil4, pack_dense_weight, pack_dense_weight_bf16, pack_dense_weight_bf16x3, pack_depthwise_weight
+from .sphere_conv import (SphereConv2d, ceil4, pack_dense_weight, pack_dense_weight_bf16, pack_dense_weight_bf16x3, pack_dense_weight_f32ring,
+                          pack_depthwise_weight)
 
 
 class EncoderOutput(SimpleNamespace):
@@ -302,28 +303,28 @@ class AutoencoderDC(ModelMixin):
 
     # -- plan: repacked weights (NHWC / tap-major) ------------------------------------------------
     def _build_plan(self):
-        if self.dtype != torch.float32:
-            raise NotImplementedError("this build computes in fp32; cast the model to float32")
+        self._upcast_to_fp32()  # a bf16 / fp16 model loads: parameters are up-cast once, with a warning
         if not next(self.parameters()).is_cuda:
             raise RuntimeError("AutoencoderDC must live on a HIP device (no CPU fallback)")
         plan = {}
         split = self.gemm_precision != "fp32"
-        pack = pack_dense_weight_bf16 if self.gemm_precision == "bf16" else pack_dense_weight_bf16x3  # operand format of the mode
+        # operand format of the mode; round 4: the exact-fp32 mode runs its dense convs / 1x1 convs / Linears on the same LDS-DMA ring kernel
+        # (fp32 operand rows, fp32 matrix instruction) - every weight is the tap-major matrix with the taps padded to 32 * 2^j channels
+        pack = {"bf16": pack_dense_weight_bf16, "bf16x3": pack_dense_weight_bf16x3, "fp32": pack_dense_weight_f32ring}[self.gemm_precision]
         for mod in self.modules():
             if isinstance(mod, SphereConv2d):
                 if mod.groups == 1:
                     k3 = mod.kernel_size[0] == 3
-                    plan[id(mod)] = pack(mod.weight) if (split and k3) else pack_dense_weight(mod.weight)
+                    plan[id(mod)] = pack(mod.weight) if k3 else pack_dense_weight(mod.weight)
                 else:
                     plan[id(mod)] = pack_depthwise_weight(mod.weight)
             elif isinstance(mod, nn.Conv2d):  # 1x1 convs
                 w = mod.weight.reshape(mod.weight.shape[0], -1).contiguous()
-                plan[id(mod)] = pack(w[:, :, None, None]) if (split and mod.groups == 1) else w
+                plan[id(mod)] = pack(w[:, :, None, None]) if mod.groups == 1 else w
             elif isinstance(mod, SanaMultiscaleLinearAttention):
                 w = torch.cat([mod.to_q.weight, mod.to_k.weight, mod.to_v.weight], dim=0).contiguous()
-                plan[id(mod)] = pack(w[:, :, None, None]) if split else w
-                if split:
-                    plan[id(mod.to_out)] = pack(mod.to_out.weight[:, :, None, None])
+                plan[id(mod)] = pack(w[:, :, None, None])
+                plan[id(mod.to_out)] = pack(mod.to_out.weight[:, :, None, None])
         self._plan = plan
         self._plan_gen += 1
 
@@ -359,8 +360,8 @@ class AutoencoderDC(ModelMixin):
                                        out_fmt=self._fmt if out_split else hip.FMT_F32)
             return y
         y = torch.empty(B * H * W, cout, device=x32.device, dtype=torch.float32)
-        hip.sphere_conv_nhwc(x32, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=x32.shape[1], cout=cout, bias=conv.bias, R=R,
-                             ldr=cout if R is not None else 0, ksize=3, act=act)
+        hip.sphere_conv_nhwc_split(x32, self._plan[id(conv)], y, B=B, H=H, W=W, cin=cin_p, ldx=x32.shape[1], cout=cout, ldy=cout, bias=conv.bias, R=R,
+                                   ldr=cout if R is not None else 0, ksize=3, act=act, in_fmt=hip.FMT_F32, out_fmt=hip.FMT_F32)
         return y
 
     def _mm(self, x, key, w_fp32, y, B, H, W, N, K, ldc=None, bias=None, act=hip.ACT_NONE):
@@ -370,8 +371,9 @@ class AutoencoderDC(ModelMixin):
         if self._split:
             hip.sphere_conv_nhwc_split(xs, self._plan[key], y, B=B, H=H, W=W, cin=K, ldx=xs.shape[1], cout=N, ldy=ldc, bias=bias, ksize=1,
                                        act=act, in_fmt=self._fmt)
-        else:
-            hip.gemm(x32, w_fp32, y, M=B * H * W, N=N, K=K, ldc=ldc, bias=bias, act=act)
+        else:  # exact fp32: the same conv entry with ksize 1 on fp32 rows (K need not be a multiple of 32: the taps are padded with zeros)
+            hip.sphere_conv_nhwc_split(x32, self._plan[key], y, B=B, H=H, W=W, cin=K, ldx=x32.shape[1], cout=N, ldy=ldc if ldc is not None else N,
+                                       bias=bias, ksize=1, act=act, in_fmt=hip.FMT_F32, out_fmt=hip.FMT_F32)
 
     def _norm(self, u, norm, resid, M, C, act=hip.ACT_NONE, want32=True):
         """RMSNorm rows (+ residual, activation) -> stream tensor"""

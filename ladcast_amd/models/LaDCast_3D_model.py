@@ -425,8 +425,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         )
 
     def _build_plan(self):
-        if self.dtype != torch.float32:
-            raise NotImplementedError("this build computes in fp32 (exact-fp32 MFMA); cast the model to float32")
+        self._upcast_to_fp32()  # a bf16 / fp16 model loads: parameters are up-cast once, with a warning
         if not next(self.parameters()).is_cuda:
             raise RuntimeError("LaDCastTransformer3DModel must live on a HIP device (no CPU fallback)")
         plan = SimpleNamespace(attn={})

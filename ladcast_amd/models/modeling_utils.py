@@ -142,6 +142,21 @@ class ModelMixin(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    def _upcast_to_fp32(self):
+        """A model cast to bf16 / fp16 (`.to(torch.bfloat16)`, `from_pretrained(torch_dtype=torch.bfloat16)` - how the reference's mixed
+        precision checkpoints are often held) keeps working: the kernels read fp32 parameter storage, so the parameters are up-cast
+        once, with a warning; the arithmetic mode is chosen with `set_gemm_precision`, not with the parameter dtype."""
+        import warnings
+
+        dt = self.dtype
+        if dt == torch.float32:
+            return
+        if dt not in (torch.bfloat16, torch.float16, torch.float64):
+            raise NotImplementedError(f"parameters of dtype {dt} are not supported")
+        warnings.warn(f"{type(self).__name__}: parameters are {dt}; up-casting them to float32 (the HIP kernels read fp32 parameter storage; "
+                      "use set_gemm_precision('bf16') for reduced-precision arithmetic)", stacklevel=3)
+        self.to(torch.float32)
+
     @classmethod
     def _ctor_keys(cls):
         return [k for k in inspect.signature(cls.__init__).parameters if k not in ("self", "args", "kwargs")]

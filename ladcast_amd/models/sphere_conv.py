@@ -36,6 +36,16 @@ def pack_dense_weight_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return hip.pack_weight_bf16x2(out.reshape(co, k * k * cpp))
 
 
+def pack_dense_weight_f32ring(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, k, k] -> plain fp32 tap-major [Cout, k*k*Cin_pp], Cin_pp = 32 * 2^j >= Cin with zeros behind Cin: the weight of
+    ldc_sphere_conv_nhwc_split(in_fmt = LDC_FMT_F32), the exact-fp32 conv on the LDS-DMA ring kernel (round 4)."""
+    co, ci, k, _ = w.shape
+    cpp = hip.conv_cin_padded(ci)
+    out = torch.zeros(co, k * k, cpp, device=w.device, dtype=torch.float32)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, k * k, ci)
+    return out.reshape(co, k * k * cpp).contiguous()
+
+
 def pack_dense_weight_bf16(w: torch.Tensor) -> torch.Tensor:
     """[Cout, Cin, k, k] -> plain bf16 weight of the tap-major [Cout, k*k*Cin_pp] matrix, Cin_pp = 64 * 2^j >= Cin with zeros behind
     Cin (ldc_sphere_conv_nhwc_split, in_fmt = LDC_FMT_BF16: the single-term `bf16` mode)."""

@@ -79,12 +79,15 @@ def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
     model.enable_hip_graph(True)
     pipe = AutoRegressive2DPipeline(model, EDMDPMSolverMultistepScheduler())
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).cuda()
-    kw = dict(num_inference_steps=20, return_seq_len=4, latent_transform_args={"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5},
+    kw = dict(num_inference_steps=3, return_seq_len=4, latent_transform_args={"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5},
               total_lead_time_hour=24, sampler_type="edm", return_latent=True, known_latents_override=ic)
-    for mode in ("fp32", "bf16x3"):
+    # (the bf16x3 leg costs another ~100 s of process start-up on a box where eight ranks share one GPU: run it with LDC_TEST_8RANK_BF16X3=1;
+    # measured in profiles/r04_j_gpu_tests.log: pair by pair 9.8e-6, as one batch 9.8e-6)
+    for mode in ("fp32", "bf16x3") if os.environ.get("LDC_TEST_8RANK_BF16X3") else ("fp32",):
         dump = str(tmp_path / f"gathered_{mode}.pt")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpus", "--ensemble-size", "16", "--lead-steps", "4",
-               "--steps", "1", "--warmup", "0", "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--precision", mode, "--dump-output", dump]
+               "--steps", "1", "--warmup", "0", "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--precision", mode, "--dump-output", dump,
+               "--solver-steps", "3"]  # 5 forwards per chunk: eight ranks share ONE GPU here, the literal 20 steps cost minutes of suite time
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

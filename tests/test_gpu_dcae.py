@@ -288,7 +288,9 @@ def test_bulk_encoder_matches_frame_by_frame_oracle():
     got = encode_latents(g, frames, static_conditioning_tensor=st, batch_size=2)
     assert got.device.type == "cpu" and got.shape == want.shape and rel_l2(got, want) < 2e-5
     got2 = encode_latents(g, lambda i: frames[i], total_samples=5, static_conditioning_tensor=st, batch_size=4)
-    assert torch.equal(got, got2)  # the batch split does not change a frame's result
+    # the batch split changes a frame's result at fp32 rounding level only (round 4: the fp32 convs run on the stream-K ring kernel, whose
+    # unit-range cut - i.e. the order in which a split tile's k-ranges are added - depends on the number of frames in the launch)
+    assert rel_l2(got2, got) < 1e-6
     with pytest.raises(ValueError):
         encode_latents(g, lambda i: frames[i], static_conditioning_tensor=st)
 

@@ -72,8 +72,8 @@ def test_ddpm_step_is_bit_exact(variance_type, pred):
             xa, xb = ra.prev_sample, rb.prev_sample
         assert int(b.timesteps[-1]) == 0 or kw.get("timestep_spacing") == "trailing"
         # one generator for the whole batch (diffusers' other randn_tensor rule)
-        ra = a.step(f.cuda(), 500 if kw.get("timestep_spacing") != "trailing" else int(b.timesteps[3]), x.cuda(), generator=torch.Generator().manual_seed(3))
-        rb = b.step(f, 500 if kw.get("timestep_spacing") != "trailing" else int(b.timesteps[3]), x, generator=torch.Generator().manual_seed(3))
+        ra = a.step(f.cuda(), int(b.timesteps[3]), x.cuda(), generator=torch.Generator().manual_seed(3))
+        rb = b.step(f, int(b.timesteps[3]), x, generator=torch.Generator().manual_seed(3))
         assert torch.equal(ra.prev_sample.cpu(), rb.prev_sample)
 
 

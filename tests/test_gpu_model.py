@@ -628,3 +628,41 @@ def test_batched_conditioning_equals_per_evaluation_conditioning(tiny_pair):
         g.COND_MAX_ROWS = 96
         g.batch_conditioning = True
         g.set_gemm_precision("fp32")
+
+
+def test_model_cast_to_bf16_is_upcast_with_a_warning(tiny_pair):
+    """a model held in bf16 / fp16 (`.to(torch.bfloat16)`) used to raise at the first forward; now its parameters are
+    up-cast to fp32 once, with a warning, and the forward equals the one of the same (rounded) weights held in fp32 - bit for bit."""
+    import warnings
+
+    from ladcast_amd.models import AutoencoderDC
+    from tests.synth import make_dcae, tiny_dcae_config
+
+    from ladcast_amd.models import LaDCastTransformer3DModel
+
+    o, _ = tiny_pair
+    cfg = tiny_ar_config(heads=2, layers=1, single=1, refiner=1)
+    m = LaDCastTransformer3DModel.from_config(cfg)
+    m.load_state_dict(o.state_dict(), strict=True)
+    m = m.to("cuda").eval().to(torch.bfloat16)
+    assert m.dtype == torch.bfloat16
+    ref = LaDCastTransformer3DModel.from_config(cfg)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()}, strict=True)  # the rounded weights, held in fp32
+    ref = ref.to("cuda").eval()
+    x = torch.randn(1, 84, 2, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+    known, ts, t = synth_known(1).cuda(), torch.tensor([2018010100]).cuda(), torch.tensor([0.3]).cuda()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m(x, t, known, time_elapsed=ts).sample
+    assert any("up-casting" in str(i.message) for i in w) and m.dtype == torch.float32
+    assert torch.equal(got, ref(x, t, known, time_elapsed=ts).sample)
+    cfg = tiny_dcae_config()
+    od = make_dcae(cfg)
+    ae = AutoencoderDC.from_config(cfg)
+    ae.load_state_dict(od.state_dict(), strict=True)
+    ae = ae.cuda().eval().half()
+    f, st = torch.randn(1, 8, 48, 64).cuda(), torch.randn(1, 5, 48, 64).cuda()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        z = ae.encode(f, static_conditioning_tensor=st).latent
+    assert any("up-casting" in str(i.message) for i in w) and ae.dtype == torch.float32 and torch.isfinite(z).all()

@@ -719,7 +719,7 @@ def test_attention_split_tail_schedule(hip, B, S, H, one_term, bias):
     assert torch.isfinite(outs[0]).all()
     tol = 1e-2 if one_term else 2e-5
     assert rel(outs[0], want) < tol and rel(plain, want) < tol
-    assert rel(outs[0], plain) < (1e-5 if not one_term else 1e-3)  # same products, another order of the key tiles
+    assert rel(outs[0], plain) < (1e-5 if not one_term else 5e-3)  # same products, another order of the key tiles (bf16 P: another rounding point)
     o2 = torch.empty(B, S, D, device="cuda")  # split-format output through the merge kernel
     hip.attn_fwd_split(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], o2, **dict(kw, out_split=hip.FMT_BF16 if one_term else True))
     if one_term:

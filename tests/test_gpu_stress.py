@@ -61,8 +61,9 @@ def test_full_375m_forward_with_trained_model_statistics():
             g.set_gemm_precision(mode)
             got = g(x.cuda(), torch.tensor([t]).cuda(), known.cuda(), time_elapsed=ts.cuda()).sample
             e = rel_l2(got.cpu(), want)
-            print(f"  [{mode}] rel-L2 vs the fp32 oracle {e:.2e}  (stated {tolerance(mode, 'forward'):g})")
-            assert e < tolerance(mode, "forward"), (mode, t, e)
+            tol = tolerance(mode, "forward_trained_statistics" if mode == "bf16" else "forward")  # fp32 / bf16x3: the default-weights entries, unchanged
+            print(f"  [{mode}] rel-L2 vs the fp32 oracle {e:.2e}  (stated {tol:g})")
+            assert e < tol, (mode, t, e)
     g.set_gemm_precision("fp32")
 
 
