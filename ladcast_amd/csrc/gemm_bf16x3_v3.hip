@@ -1097,6 +1097,10 @@ int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* wor
   }
   // 128-row tiles only: a tile is 2.7x the split kernel's MFMA time, so balance matters more than the halved W traffic per FLOP of
   // the 256-row tile (375M model in fp32 mode, same box: 113.6 TFLOP/s against 111.0 with 256 rows forced; profiles/r03_j_*)
+#ifdef LDC_AB_BUILD
+  static const char* const force_bm = getenv("LDC_F32_RING_BM");  // A/B build only: 256-row tiles for the exact-fp32 GEMMs
+  if (force_bm && atoi(force_bm) == 256) return launch_v3<256, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
+#endif
   return launch_v3<128, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
 }
 
