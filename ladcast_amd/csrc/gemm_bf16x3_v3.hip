@@ -863,9 +863,11 @@ struct ConvParams {
   int H, W, cin, ks, kshift;
 };
 
+constexpr int LDC_SPLIT_GROUP = -100;  // internal: "launch this group's problems one by one" (gemm_v3_dispatch)
+
 template <int BM, int TERMS, bool CONV = false>
 int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace, long long workspace_bytes,
-              void* stream, const ConvParams* cp = nullptr) {
+              void* stream, const ConvParams* cp = nullptr, bool may_split_group = false) {
   constexpr int SLOT_FLOATS = BM * BN;
   constexpr int STAGE_B = (BM + BN) * ROW_B;
   constexpr int CUS = 256;  // one workgroup per CU
@@ -1000,6 +1002,11 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
           break;
         }
     }
+    // Round 4: a GROUP whose tile count has no k-aligned cut onto >= 160 workgroups (1.6B dual blocks: (15 + 4) x 16 = 304 tiles of
+    // k-depth 2^j - every aligned grid is a multiple of 19 that divides 304 s: 152) used to take the unaligned ranges below, which cost
+    // the split modes 40 % (out / down projection of the 1.6B dual block: 205 / 213 TFLOP/s).  Its problems one by one cut well
+    // (pred: 240 tiles = 240 workgroups; cond: 64 tiles x 4 k-pieces = 256): the dispatcher launches them separately.
+    if (may_split_group && TERMS != 0 && n > 1 && best < 160 && few == 0) return LDC_SPLIT_GROUP;
     if (best >= 160) {
       G = best;
     } else if (few > 0) {
@@ -1072,11 +1079,24 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
   bool small = tiles256 < (force_thr ? atoll(force_thr) : 400);  // measured cross-over on the 375M model launches (tools/gemm_sustained.py, both heights forced)
   static const char* const force_bm = LDC_AB_GETENV("LDC_BF16X3_BM");  // measurement aid, read once
   if (force_bm) small = (atoi(force_bm) == 128);
-  if (problems[0].d.flags & LDC_GEMM_BF16_1TERM)
-    return small ? launch_v3<128, 1>(problems, epi, n, workspace, workspace_bytes, stream)
-                 : launch_v3<256, 1>(problems, epi, n, workspace, workspace_bytes, stream);
-  return small ? launch_v3<128, 3>(problems, epi, n, workspace, workspace_bytes, stream)
-               : launch_v3<256, 3>(problems, epi, n, workspace, workspace_bytes, stream);
+  const bool one = (problems[0].d.flags & LDC_GEMM_BF16_1TERM) != 0;
+  auto launch = [&](const ldc_gemm_problem* pr, const ldc_qkv_epilogue* ep, int cnt, bool sm, bool may_split) {
+    if (one)
+      return sm ? launch_v3<128, 1>(pr, ep, cnt, workspace, workspace_bytes, stream, nullptr, may_split)
+                : launch_v3<256, 1>(pr, ep, cnt, workspace, workspace_bytes, stream, nullptr, may_split);
+    return sm ? launch_v3<128, 3>(pr, ep, cnt, workspace, workspace_bytes, stream, nullptr, may_split)
+              : launch_v3<256, 3>(pr, ep, cnt, workspace, workspace_bytes, stream, nullptr, may_split);
+  };
+  const int st = launch(problems, epi, n, small, true);
+  if (st != LDC_SPLIT_GROUP) return st;
+  for (int i = 0; i < n; ++i) {  // the group has no good aligned cut: its problems one after the other (independent; same stream)
+    const ldc_gemm_desc& d = problems[i].d;
+    bool sm = static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN) < (force_thr ? atoll(force_thr) : 400);
+    if (force_bm) sm = (atoi(force_bm) == 128);
+    const int sti = launch(problems + i, epi ? epi + i : nullptr, 1, sm, false);
+    if (sti != LDC_OK) return sti;
+  }
+  return LDC_OK;
 }
 
 // exact-fp32 grouped GEMM on the ring kernel (TERMS = 0); LDC_ERR_UNSUPPORTED -> the caller (ldc_gemm_grouped, gemm_streamk.hip) runs
