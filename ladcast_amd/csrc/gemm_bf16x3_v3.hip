@@ -23,6 +23,7 @@
 // tile +4 of the same stage | column tile 4 | barrier(kt+1) | A fragments of kt+1 | column tiles 5-7, reloading with tiles
 // 0-3 of kt+1 (the barrier's lgkmcnt(0) then waits for reads that were issued a whole column tile earlier).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -1040,6 +1041,14 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   }
   LDC_CHECK_ALIGN16(workspace);
   if (U >= (1LL << 31)) return LDC_ERR_UNSUPPORTED;  // 32-bit unit arithmetic in the kernel
+#ifdef LDC_AB_BUILD
+  {  // A/B build only: LDC_GEMM_DEBUG_G=1 prints every launch's cut (n problems, tiles, k-depth, tile rows, unit ranges, units per range)
+    static const bool dbg = getenv("LDC_GEMM_DEBUG_G") != nullptr;
+    if (dbg)
+      fprintf(stderr, "ldc_gemm cut: terms %d conv %d n %d tiles %lld kt0 %d BM %d G %lld U %lld %s\n", TERMS, int(CONV), n, tiles, a.pr[0].kt, BM, G, U,
+              (U % G == 0 && (U / G) % a.pr[0].kt == 0) ? "whole tiles" : (U % G == 0 ? "equal ranges" : "UNALIGNED"));
+  }
+#endif
   a.G = static_cast<int>(G);
   a.U = U;
   a.upg = static_cast<unsigned>(U / G);
