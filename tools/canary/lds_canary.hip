@@ -12,6 +12,30 @@
 // would show up here
 __global__ void canary(unsigned* report, int words, int spin, unsigned tag, const unsigned* gbuf, int gwords, int mode) {
   extern __shared__ unsigned lds[];
+  if (mode == 2) {
+    // cross-lane canary: ds_bpermute_b32 (what __shfl_xor compiles to: the LDS unit's crossbar, no LDS memory) in a loop; every lane
+    // checks that it received its partner's value.  The victim of the GPU-sharing effect (linear_small_kernel<4>) reduces with it.
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned bad = 0, first = 0xffffffffu, val = 0;
+    unsigned x = (blockIdx.x * 2654435761u) ^ ((threadIdx.x >> 6) * 40503u) ^ tag;  // wave-uniform
+    for (int s = 0; s < spin; ++s) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned mine = x ^ (lane * 0x9E3779B1u) ^ (unsigned)(s * 64 + o);
+        const unsigned want = x ^ ((lane ^ (unsigned)o) * 0x9E3779B1u) ^ (unsigned)(s * 64 + o);  // x is wave-uniform below
+        const unsigned got = (unsigned)__shfl_xor((int)mine, o, 64);
+        if (got != want) { ++bad; if ((unsigned)s < first) { first = s; val = got ^ want; } }
+      }
+    }
+    if (bad) {
+      atomicAdd(&report[0], bad);
+      atomicAdd(&report[1], 1u);
+      atomicMin(&report[2], first);
+      report[3] = val;
+      atomicMax(&report[4], first);
+    }
+    return;
+  }
   if (mode == 1) {
     unsigned bad = 0, first = 0xffffffffu, val = 0;
     unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
@@ -79,7 +103,7 @@ int main(int argc, char** argv) {
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
     unsigned init[5] = {0, 0, 0xffffffffu, 0, 0};
     hipMemcpy(rep, init, sizeof(init), hipMemcpyHostToDevice);
-    for (int k = 0; k < 50; ++k) hipLaunchKernelGGL(canary, dim3(1024), dim3(256), mode == 1 ? 0 : kib * 1024, 0, rep, words, spin, (unsigned)(launches + k) * 2654435761u, gbuf, gwords, mode);
+    for (int k = 0; k < 50; ++k) hipLaunchKernelGGL(canary, dim3(1024), dim3(256), mode != 0 ? 0 : kib * 1024, 0, rep, words, spin, (unsigned)(launches + k) * 2654435761u, gbuf, gwords, mode);
     hipDeviceSynchronize();
     unsigned out[5];
     hipMemcpy(out, rep, sizeof(out), hipMemcpyDeviceToHost);
@@ -88,7 +112,7 @@ int main(int argc, char** argv) {
     bad_wgs += out[1];
     if (out[1]) { if (out[2] < lo) lo = out[2]; if (out[4] > hi) hi = out[4]; sample = out[3]; }
   }
-  printf("%s canary (spin %d): %d KiB per workgroup, %llu launches x 1024 workgroups: %llu corrupted words in %llu workgroups", mode == 1 ? "global-load" : "lds", spin, kib, launches, bad_words, bad_wgs);
+  printf("%s canary (spin %d): %d KiB per workgroup, %llu launches x 1024 workgroups: %llu corrupted words in %llu workgroups", mode == 2 ? "ds_bpermute (cross-lane)" : mode == 1 ? "global-load" : "lds", spin, kib, launches, bad_words, bad_wgs);
   if (bad_wgs) printf("; first corrupted word index in [%u, %u], a corrupted value 0x%08x", lo, hi, sample);
   printf("\n");
   return 0;
