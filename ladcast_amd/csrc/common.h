@@ -122,34 +122,11 @@ __device__ __forceinline__ int ldc_sphere_src_pixel(int h, int w, int ky, int kx
 #endif
 
 // wave64 butterfly reductions
-#if defined(LDC_WAVE_SUM_DPP)
-// The same xor butterfly (32, 16, 8, 4, 2, 1: same additions in the same order, same bits) without ds_bpermute_b32: v_permlane32/16_swap
-// for the two widest steps, DPP row rotations under bank masks / quad permutes for the rest.  No LDS-unit instruction at all.
-__device__ __forceinline__ float ldc_dpp_xor(float v, int o) {
-  const int x = __float_as_int(v);
-  int t;
-  if (o == 8) t = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);  // row_ror:8 == lane ^ 8 inside a row of 16
-  else if (o == 4) { t = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xa, false); t = __builtin_amdgcn_update_dpp(t, x, 0x12c, 0xf, 0x5, false); }
-  else if (o == 2) t = __builtin_amdgcn_update_dpp(0, x, 0x4e, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
-  else t = __builtin_amdgcn_update_dpp(0, x, 0xb1, 0xf, 0xf, false);              // quad_perm [1,0,3,2]
-  return __int_as_float(t);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-  { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-  v += ldc_dpp_xor(v, 8);
-  v += ldc_dpp_xor(v, 4);
-  v += ldc_dpp_xor(v, 2);
-  v += ldc_dpp_xor(v, 1);
-  return v;
-}
-#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -254,6 +254,20 @@ __device__ __forceinline__ float modulate_nocontract(float v, float scale, float
 
 // FULL = false compiles the timestep-sinusoid input and the modulation epilogue out: the wide (LS_CPW_MAX) instantiation that streams
 // the 38 D x D AdaLN matrix sits at 125 VGPRs = 4 waves per SIMD, and nine more registers would cost it a wave (76 -> 126 us measured)
+// GPU shared between PROCESSES (gfx950, measured: profiles/r04_z_gpu_sharing_first_read.log): when a wave of this kernel sits on a SIMD
+// next to waves of ANOTHER process's 4-wave split attention, the FIRST VALU read of the two upper dwords of each 64-bit half of the
+// 128-bit LDS read below (x.y, x.w) can return 0 in lanes 48..63 - whatever the wait before it (s_waitcnt lgkmcnt(0) plus 32 idle
+// cycles changes nothing), while the second read is right.  One v_mov of those two registers before their use takes that first read;
+// reading x.x / x.z instead does not help (control).  Two instructions per staged float4, no measurable cost (73.1 / 77.5 us before
+// and after, tools/gemv_bench.py), bit-identical results; one process per GPU never showed the effect.  -DLDC_LS_NO_FIRST_READ in the
+// A/B build compiles it out (tools/canary/victim_pattern.py reproduces the wrong words with it).
+__device__ __forceinline__ void ls_first_read(float4& v) {
+#if !(defined(LDC_AB_BUILD) && defined(LDC_LS_NO_FIRST_READ))
+  float t0, t1;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(t0), "=&v"(t1), "+v"(v.y), "+v"(v.w));
+#endif
+}
+
 template <int LS_CPW, bool FULL = true>
 __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const float* __restrict__ add,
@@ -316,8 +330,7 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
         __syncthreads();
       }
       if (n0 < N) {
-#pragma unroll 2
-        for (int c = lane; c < nv4; c += 64) {
+        for (int c = lane; c < nv4; c += 64) {  // (not unrolled: the asm in ls_first_read is convergent and the trip count is per lane)
           float4 w[LS_CPW];
 #pragma unroll
           for (int j = 0; j < LS_CPW; ++j) {  // weights are streamed once: non-temporal
@@ -328,7 +341,8 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
 #pragma unroll
           for (int i = 0; i < LS_ROWS; ++i) {
             if (i < rows_here) {
-              const float4 xv = reinterpret_cast<const float4*>(xs + i * kc)[c];
+              float4 xv = reinterpret_cast<const float4*>(xs + i * kc)[c];
+              ls_first_read(xv);
 #pragma unroll
               for (int j = 0; j < LS_CPW; ++j) acc[j][i] += (w[j].x * xv.x + w[j].y * xv.y) + (w[j].z * xv.z + w[j].w * xv.w);
             }

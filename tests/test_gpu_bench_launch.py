@@ -52,17 +52,15 @@ def test_bench_rejects_mismatched_world():
 
 def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
     """BASELINE configs[2] in shape on the one GPU of the test box: `--gpus 8 --ensemble-size 16 --lead-steps 4` over gloo, every rank
-    on GPU 0 - two members per rank (rank r owns members r and r + 8), one collective.  In the exact-fp32 mode the gathered
-    (1, 16, 84, 5, 15, 30) tensor must equal, BIT FOR BIT, what one process computes for the same member pairs (same kernels, same
-    batch shape): the partition, the padding / trimming of the all_gather and the member order lose nothing.  Against the one-process
-    run of all 16 members as ONE batch it agrees to fp32 rounding only (another stream-K cut: documented in pipelines/distributed.py).
-    The line carries the per-rank diagnostics a SCALE run is read from.
+    on GPU 0 - two members per rank (rank r owns members r and r + 8), one collective.  The gathered (1, 16, 84, 5, 15, 30) tensor must
+    equal, BIT FOR BIT, what one process computes for the same member pairs (same kernels, same batch shape): the partition, the
+    padding / trimming of the all_gather and the member order lose nothing.  Against the one-process run of all 16 members as ONE batch
+    it agrees to rounding only (another stream-K cut: documented in pipelines/distributed.py).  The line carries the per-rank
+    diagnostics a SCALE run is read from.
 
-    The split-bf16 mode is run the same way but compared with a TOLERANCE: when several PROCESSES share one GPU, workgroups of the
-    4-wave split attention (the form used for more than 256 units, here batch 2) and of the wide AdaLN GEMV from different processes
-    become co-resident on a SIMD, and the GEMV's results then differ at the 1e-3 level from run to run (isolated with a victim /
-    aggressor experiment, profiles/r04_*_gpu_sharing_*.log; neither kernel is affected inside one process - the soak runs are bit
-    exact - and one process per GPU is the production topology).  The dry run still checks the partition logic in that mode."""
+    Both arithmetic modes (75 s for the two at 3 solver steps, profiles/r04_z_gpu_sharing_first_read.log).  Eight PROCESSES on
+    one GPU is also the configuration that exposed the first-read effect the wide AdaLN GEMV now guards against (csrc/rowops.hip
+    ls_first_read): before that guard this comparison differed at the 1e-3 level from run to run in the split-bf16 mode."""
     import torch
     from datetime import datetime
 
@@ -81,9 +79,7 @@ def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
     ic = (0.5 * torch.randn(84, 1, 15, 30, generator=torch.Generator().manual_seed(2))).cuda()
     kw = dict(num_inference_steps=3, return_seq_len=4, latent_transform_args={"mean": [0.0] * 84, "std": [1.0] * 84, "target_std": 0.5},
               total_lead_time_hour=24, sampler_type="edm", return_latent=True, known_latents_override=ic)
-    # (the bf16x3 leg costs another ~100 s of process start-up on a box where eight ranks share one GPU: run it with LDC_TEST_8RANK_BF16X3=1;
-    # measured in profiles/r04_j_gpu_tests.log: pair by pair 9.8e-6, as one batch 9.8e-6)
-    for mode in ("fp32", "bf16x3") if os.environ.get("LDC_TEST_8RANK_BF16X3") else ("fp32",):
+    for mode in ("bf16x3", "fp32"):
         dump = str(tmp_path / f"gathered_{mode}.pt")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpus", "--ensemble-size", "16", "--lead-steps", "4",
                "--steps", "1", "--warmup", "0", "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--precision", mode, "--dump-output", dump,
@@ -113,8 +109,5 @@ def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
         print(f"\n[{mode}] 8 ranks x 2 members vs one process pair by pair: {'bit for bit' if torch.equal(got, want) else f'rel-L2 {e_pairs:.2e}'}; "
               f"vs all 16 members as one batch: rel-L2 {e_whole:.2e}")
         assert torch.equal(got[:, :, :, 0], want[:, :, :, 0])  # slot 0: the IC latent, member order and padding of the gather
-        if mode == "fp32":
-            assert torch.equal(got, want)
-            assert e_whole < 1e-5
-        else:
-            assert e_pairs < 5e-3 and e_whole < 5e-3
+        assert torch.equal(got, want)
+        assert e_whole < (1e-5 if mode == "fp32" else 1e-4)

@@ -66,6 +66,9 @@ env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "L
 workers = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", op, str(seconds + 6)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for _ in range(N - 1)]
 time.sleep(5)  # let the workers build their inputs
 print(f"== canary next to {N - 1} x [{op}]", flush=True)
-subprocess.run(["/tmp/lds_canary", str(seconds), kib, spin, cmode])
+if cmode.startswith("stream"):  # tools/canary/stream_canary.hip: the GEMV's streaming loads, checked word by word ("stream" | "stream_plain")
+    subprocess.run(["/tmp/stream_canary", str(seconds), "0" if cmode.endswith("plain") else "1"])
+else:
+    subprocess.run(["/tmp/lds_canary", str(seconds), kib, spin, cmode])
 for w in workers:
     w.wait()
