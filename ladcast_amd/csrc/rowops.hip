@@ -254,13 +254,14 @@ __device__ __forceinline__ float modulate_nocontract(float v, float scale, float
 
 // FULL = false compiles the timestep-sinusoid input and the modulation epilogue out: the wide (LS_CPW_MAX) instantiation that streams
 // the 38 D x D AdaLN matrix sits at 125 VGPRs = 4 waves per SIMD, and nine more registers would cost it a wave (76 -> 126 us measured)
-// GPU shared between PROCESSES (gfx950, measured: profiles/r04_z_gpu_sharing_first_read.log): when a wave of this kernel sits on a SIMD
-// next to waves of ANOTHER process's 4-wave split attention, the FIRST VALU read of the two upper dwords of each 64-bit half of the
-// 128-bit LDS read below (x.y, x.w) can return 0 in lanes 48..63 - whatever the wait before it (s_waitcnt lgkmcnt(0) plus 32 idle
-// cycles changes nothing), while the second read is right.  One v_mov of those two registers before their use takes that first read;
-// reading x.x / x.z instead does not help (control).  Two instructions per staged float4, no measurable cost (73.1 / 77.5 us before
-// and after, tools/gemv_bench.py), bit-identical results; one process per GPU never showed the effect.  -DLDC_LS_NO_FIRST_READ in the
-// A/B build compiles it out (tools/canary/victim_pattern.py reproduces the wrong words with it).
+// Kernels running at the same time (gfx950, measured: profiles/r04_z_gpu_sharing_first_read.log): when a wave of this
+// kernel shares a SIMD with a wave that streams MFMAs - another process's 4-wave split attention, or any MFMA kernel on a second stream -
+// the FIRST VALU read of the two upper dwords of each 64-bit half of the 128-bit LDS read below (x.y, x.w) can return 0 in lanes 48..63,
+// whatever the wait before it (s_waitcnt lgkmcnt(0) plus 32 idle cycles changes nothing), while the second read is right.  One v_mov of
+// those two registers before their use takes that first read; reading x.x / x.z instead does not help (control).  Two instructions per
+// staged float4, no measurable cost (73.3 / 78.0 -> 72.5 / 77.2 us, tools/gemv_bench.py), bit-identical results; one process on one stream
+// never runs two kernels at once and never showed the effect.  -DLDC_LS_NO_FIRST_READ in the A/B build compiles the guard out
+// (tools/canary/victim_pattern.py reproduces the wrong words with it).
 __device__ __forceinline__ void ls_first_read(float4& v) {
 #if !(defined(LDC_AB_BUILD) && defined(LDC_LS_NO_FIRST_READ))
   float t0, t1;

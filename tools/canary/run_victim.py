@@ -9,7 +9,6 @@ seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
 victim = sys.argv[4] if len(sys.argv) > 4 else "gemv"
 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
 runner = os.path.join(ROOT, "tools", "canary", "run_canary.py")
-workers = [subprocess.Popen([sys.executable, runner, "worker", op, str(seconds + 8)], env={**env, "VICTIM_VA_PAD_MB": "0"}, cwd=ROOT) for _ in range(N - 1)]
 sys.path.insert(0, ROOT)
 import torch
 import ladcast_amd.hip as hip
@@ -28,6 +27,10 @@ def run_victim(y):
         hip.linear_small(x, W, y[:, :1536], rows=2, N=1536, K=1536, bias=b, act_in=hip.ACT_SILU)
     elif victim == "torch_mv":
         torch.matmul(x, W.t(), out=y)
+    elif victim == "torch_layernorm":
+        y.view(-1)[: xl.numel()].copy_(torch.nn.functional.layer_norm(xl, (1536,)).view(-1))
+    elif victim == "torch_softmax":
+        y.view(-1)[: xl.numel()].copy_(torch.softmax(xl, dim=-1).view(-1))
     elif victim == "torch_elementwise":
         torch.mul(W[:2, :].repeat(1, 38), 1.0009765625, out=y)
     elif victim == "ln":
@@ -35,11 +38,15 @@ def run_victim(y):
                           y_bs=2250 * 1536, scale=sc[:, 1536:], shift=sc, mod_bs=3072, mode=0, eps=1e-6)
 
 
-shape = (2, 2250 * 1536) if victim == "ln" else (2, 58368)
+shape = (2, 2250 * 1536) if victim in ("ln", "torch_layernorm", "torch_softmax") else (2, 58368)
 ref = torch.zeros(shape, device="cuda")
 run_victim(ref)
-torch.cuda.synchronize()
-time.sleep(5)
+torch.cuda.synchronize()  # the reference result is computed on an idle GPU, the aggressors start after it
+if op.startswith("synth"):  # tools/canary/synthetic_aggressor.hip (mode = the digit), built to /tmp/synth_aggr
+    workers = [subprocess.Popen(["/tmp/synth_aggr", op[5:], str(seconds + 8)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for _ in range(N - 1)]
+else:
+    workers = [subprocess.Popen([sys.executable, runner, "worker", op, str(seconds + 8)], env={**env, "VICTIM_VA_PAD_MB": "0"}, cwd=ROOT) for _ in range(N - 1)]
+time.sleep(8)
 calls = bad = words = 0
 worst = 0.0
 t_end = time.time() + seconds

@@ -2,7 +2,7 @@
 columns x K = 1536) runs on ANALYTIC inputs next to N - 1 processes looping the 4-wave split attention, so that every wrong word can be
 read: with x = 1, W = 1 every output is exactly 1536 (integers: no rounding, any order), and a wrong value says how many terms were
 lost or doubled; with W[n][k] = (k == n mod K) the output is x[n mod K] - which element of the staged x was read.
-usage: python tools/canary/victim_pattern.py [N] [seconds] [ones|pick]      (A/B library: LDC_LINEAR_SMALL_ITERS=1 walks one column group)"""
+usage: python tools/canary/victim_pattern.py [N] [seconds] [ones|pick|coded|coded2] [aggressor: attn_b2 | ... | synth0..synth6]      (A/B library: LDC_LINEAR_SMALL_ITERS=1 walks one column group)"""
 import collections, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -48,7 +48,17 @@ if os.environ.get("AGGRESSOR_LIB_PATH"):  # the aggressors load another build of
     env["LDC_LIB_PATH"] = os.environ["AGGRESSOR_LIB_PATH"]
     print("aggressors load", env["LDC_LIB_PATH"])
 runner = os.path.join(ROOT, "tools", "canary", "run_canary.py")
-workers = [subprocess.Popen([sys.executable, runner, "worker", aggressor, str(seconds + 8)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for _ in range(N - 1)]
+local = None
+if aggressor.startswith("local"):  # the synthetic aggressor on a second stream of THIS process (/tmp/libsynth.so): co-residency without a second process
+    import ctypes
+    local = ctypes.CDLL("/tmp/libsynth.so")
+    local.synth_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    side = torch.cuda.Stream()
+    workers = []
+elif aggressor.startswith("synth"):  # tools/canary/synthetic_aggressor.hip, mode = the digit: one instruction class in the attention's footprint
+    workers = [subprocess.Popen(["/tmp/synth_aggr", aggressor[5:], str(seconds + 8)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for _ in range(N - 1)]
+else:
+    workers = [subprocess.Popen([sys.executable, runner, "worker", aggressor, str(seconds + 8)], env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for _ in range(N - 1)]
 time.sleep(8)
 calls = bad = 0
 vals = collections.Counter()
@@ -64,6 +74,8 @@ while time.time() < t_end:
     ys = []
     for _ in range(16):
         y = torch.zeros(2, NC, device="cuda")
+        if local is not None:  # ~1 ms of aggressor on the side stream (256 workgroups: one per CU), the victim lands in the middle of it
+            local.synth_launch(int(aggressor[5:]), 2000, 256, ctypes.c_void_p(side.cuda_stream))
         hip.linear_small(x, W, y, rows=2, N=NC, K=K)
         ys.append(y)
     torch.cuda.synchronize()
