@@ -247,3 +247,14 @@ def test_attention_processor_surface_is_honest():
     with pytest.raises(NotImplementedError):
         attn.processor = Foreign()
     attn.processor = SanaMultiscaleAttnProcessor2_0()
+
+
+def test_gemv_first_read_guard_is_in_the_shipped_kernels():
+    """the AdaLN GEMV reads x.y / x.w once before their use (csrc/rowops.hip ls_first_read) - without it the kernel loses
+    products when it shares a SIMD with an MFMA-streaming wave (measured: profiles/r04_z_gpu_sharing_first_read.log).  The guard may only be
+    compiled out in the A/B build; the 8-rank GPU test is what checks its effect."""
+    src = open(os.path.join(ROOT, "ladcast_amd", "csrc", "rowops.hip")).read()
+    assert "ls_first_read(xv);" in src
+    assert "#if !(defined(LDC_AB_BUILD) && defined(LDC_LS_NO_FIRST_READ))" in src
+    mk = open(os.path.join(ROOT, "ladcast_amd", "csrc", "Makefile")).read()
+    assert "LDC_LS_NO_FIRST_READ" not in mk
