@@ -142,20 +142,25 @@ int ldc_pack_weight_bf16(const float* W, void* out, int N, int K, int ldw, void*
  * HBM-bound weight streaming; replaces the timestep / text / AdaLN projection
  * Linears on (B, D) vectors: diffusers TimestepEmbedding, PixArtAlphaTextProjection,
  * AdaLayerNormZero/-Single/-Continuous .linear and HunyuanVideoAdaNorm.linear
- * (models/LaDCast_3D_model.py:224-238,362-364,441,524-529,673-678,1044). */
+ * (models/LaDCast_3D_model.py:224-238,362-364,441,524-529,673-678,1044).
+ * Two kernels, chosen from (rows, N, K) only: up to 8 rows, or N < 4096, or K % 64 != 0 -> the VALU kernel (W streamed once per 8 rows);
+ * more rows on a wide output (the AdaLN modulation of a sampler chunk's conditioning batch: 20 rows per member x 38 D) -> exact-fp32
+ * products on v_mfma_f32_16x16x4_f32 (W streamed once per 32 rows).  Same formula, different summation order (fp32 rounding); inside either
+ * kernel a row's result does not depend on the other rows of the launch. */
 int ldc_linear_small(const float* x, int x_rows, const float* W, const float* bias,
                      const float* add, int add_rows, float* y, int rows, int N, int K,
                      int act_in, int act_out, void* stream);
 
 /* ldc_linear_small followed by y = y * (1 + mod[r % mod_rows][n]) + mod[r % mod_rows][N + n] (mod: [mod_rows][2 N]): the
  * time-elapsed modulation of the conditioning embedding, temb * (1 + scale) + shift (models/LaDCast_3D_model.py:958-969), as the
- * epilogue of the text embedder's second Linear; bit-identical to ldc_linear_small + ldc_temb_modulate. */
+ * epilogue of the text embedder's second Linear; always the VALU kernel: bit-identical to ldc_linear_small + ldc_temb_modulate where that
+ * takes the VALU kernel too (see above). */
 int ldc_linear_small_mod(const float* x, int x_rows, const float* W, const float* bias, const float* add, int add_rows,
                          const float* mod, int mod_rows, float* y, int rows, int N, int K, int act_in, int act_out,
                          void* stream);
 
-/* Up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears (same formula, same per-output arithmetic as
- * ldc_linear_small: results are bit-identical) in ONE launch: the two MLPs of
+/* Up to LDC_LINEAR_SMALL_MAX_GROUPED independent small linears (same formula, the per-output arithmetic of
+ * ldc_linear_small's VALU kernel: results are bit-identical to single launches that take that kernel) in ONE launch: the two MLPs of
  * CombinedTimestepTextProjEmbeddings (timestep_embedder / text_embedder, used twice per forward:
  * models/LaDCast_3D_model.py:362-364,953-969) have independent first and second layers.  No problem's y may be
  * another problem's x / add / y (LDC_ERR_ARG). */

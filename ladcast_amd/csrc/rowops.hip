@@ -374,6 +374,99 @@ __device__ __forceinline__ void linear_small_body(const float* __restrict__ x, i
   }
 }
 
+// ---- the same product for MORE rows than one workgroup of the kernel above holds (9 .. : the conditioning batch of a sampler chunk is 20 rows
+// per member) on the fp32 matrix cores.  The VALU kernel streams W once per 8 rows and is VALU-bound there (20 rows x 58 368 x 1 536: 385 us,
+// 0.9 TB/s); here a wave owns 16 output columns and all rows of its row group (RT tiles of 16), W goes HBM -> registers exactly in the
+// B-operand layout of v_mfma_f32_16x16x4_f32 (lane = (column, k quarter): one 16-byte load = four k-steps), x is staged per K chunk in LDS
+// (row stride KC + 4 floats: the 16 rows of an A read fall on different banks) - exact fp32 products, fp32 accumulation.
+constexpr int LM_KC = 512;          // K chunk staged in LDS
+constexpr int LM_LD = LM_KC + 4;    // its row stride in floats
+typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
+template <int RT, int U>
+__device__ __forceinline__ void lm_steps(const lm_f32x4* __restrict__ wp, const float* __restrict__ xa, lm_f32x4 (&acc)[RT]) {
+  lm_f32x4 w[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + 4 * u);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float4 a = *reinterpret_cast<const float4*>(xa + rt * 16 * LM_LD + 16 * u);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[u].x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[u].y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[u].z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[u].w, acc[rt], 0, 0, 0);
+    }
+}
+
+template <int RT, int IT>  // RT row tiles of 16 per workgroup, IT column groups of 64 per workgroup (the staged x is reused IT times)
+__global__ __launch_bounds__(256) void linear_rows_mfma_kernel(const float* __restrict__ x, int x_rows, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, const float* __restrict__ add, int add_rows,
+                                                               float* __restrict__ y, int rows, int N, int K, int act_in, int act_out) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [16 RT][LM_LD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int r_base = blockIdx.y * 16 * RT;
+  const int rows_here = rows - r_base < 16 * RT ? rows - r_base : 16 * RT;
+  lm_f32x4 acc[IT][RT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[it][rt] = lm_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += LM_KC) {
+    const int kn = K - k0 < LM_KC ? K - k0 : LM_KC;  // multiple of 64
+    const int nv4 = kn >> 2;
+    if (k0) __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * RT * nv4; idx += 256) {
+      const int i = idx / nv4, c = idx - i * nv4;
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the last one multiply zeros
+      if (i < rows_here) {
+        xv = reinterpret_cast<const float4*>(x + static_cast<long long>((r_base + i) % x_rows) * K + k0)[c];
+        if (act_in != LDC_ACT_NONE) {
+          xv.x = ldc_apply_act(xv.x, act_in);
+          xv.y = ldc_apply_act(xv.y, act_in);
+          xv.z = ldc_apply_act(xv.z, act_in);
+          xv.w = ldc_apply_act(xv.w, act_in);
+        }
+      }
+      reinterpret_cast<float4*>(xs + i * LM_LD)[c] = xv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int n0 = ((blockIdx.x * IT + it) * 4 + wave) * 16;
+      if (n0 < N) {  // wave-uniform
+        const int n = n0 + col < N ? n0 + col : N - 1;  // clamped: columns past N are computed and dropped
+        const lm_f32x4* wp = reinterpret_cast<const lm_f32x4*>(W + static_cast<long long>(n) * K + k0) + kq;
+        const float* xa = xs + col * LM_LD + 4 * kq;
+        const int ns = kn >> 4;  // 16 k per step: one 16-byte load of W per lane, RT 16-byte LDS reads, 4 RT MFMAs
+        int s0 = 0;
+        for (; s0 + 8 <= ns; s0 += 8) lm_steps<RT, 8>(wp + 4 * s0, xa + 16 * s0, acc[it]);  // eight loads in flight per lane
+        if (s0 < ns) lm_steps<RT, 4>(wp + 4 * s0, xa + 16 * s0, acc[it]);                   // (ns is a multiple of 4)
+      }
+    }
+  }
+  // accumulator layout: lane (col, kq) holds rows 16 rt + 4 kq + i (i = 0..3) of output column n0 + col
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int n = ((blockIdx.x * IT + it) * 4 + wave) * 16 + col;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 16 * rt + 4 * kq + i;
+        if (rl >= rows_here) continue;
+        const int r = r_base + rl;
+        float v = acc[it][rt][i] + bv;
+        v = ldc_apply_act(v, act_out);
+        if (add) v += add[static_cast<long long>(r % add_rows) * N + n];
+        y[static_cast<long long>(r) * N + n] = v;
+      }
+  }
+}
+
 template <int LS_CPW>
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, int x_rows,
                                                            const float* __restrict__ W, const float* __restrict__ bias,
@@ -539,8 +632,52 @@ static int linear_small_impl(const float* x, int x_rows, const float* W, const f
     return true;
   }();
   (void)attr_set;
+  const bool plain = mod == nullptr && act_in != LDC_ACT_IN_TIMESTEP_SINCOS;  // the wide instantiations have neither feature
+  if (plain && rows > LS_ROWS && N >= 4096 && (K & 63) == 0) {  // more rows than one workgroup of the VALU kernel holds: fp32 matrix cores
+    const int rt = rows <= 16 ? 1 : 2;
+    const int col_groups = ldc_cdiv(N, 64);
+    // column groups per workgroup (they share the staged x): the count that needs the fewest rounds of resident workgroups (LDS: 2 per CU at
+    // RT = 2, 4 at RT = 1) x groups per workgroup; ties go to the larger count (x is staged less often: 20 x 58 368 x 1 536 takes 120.9 us
+    // at 1, 104.6 at 2, 140.5 at 3, 155.0 at 4)
+    const int row_groups_lm = ldc_cdiv(rows, 16 * rt);
+    const long long slots = (rt == 2 ? 2 : 4) * 256LL;
+    int iters = 1;
+    long long best_cost = -1;
+    for (int c = 1; c <= 4; ++c) {
+      const long long wgs = static_cast<long long>(ldc_cdiv(col_groups, c)) * row_groups_lm;
+      const long long cost = ((wgs + slots - 1) / slots) * c;
+      if (best_cost < 0 || cost <= best_cost) { best_cost = cost; iters = c; }
+    }
+    static const char* const force_lm_iters = LDC_AB_GETENV("LDC_LINEAR_MFMA_ITERS");  // measurement aid, read once
+    if (force_lm_iters && atoi(force_lm_iters) >= 1 && atoi(force_lm_iters) <= 4) iters = atoi(force_lm_iters);
+    dim3 grid(ldc_cdiv(col_groups, iters), row_groups_lm);
+    const int lm_lds = 16 * rt * LM_LD * static_cast<int>(sizeof(float));
+    static const bool lm_attr_set = [] {  // once per process; thread-safe (C++11 static initialisation)
+      const int b1 = 16 * LM_LD * static_cast<int>(sizeof(float)), b2 = 2 * b1;
+      const auto set = [](auto kern, int bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+      set(linear_rows_mfma_kernel<1, 1>, b1); set(linear_rows_mfma_kernel<1, 2>, b1); set(linear_rows_mfma_kernel<1, 3>, b1); set(linear_rows_mfma_kernel<1, 4>, b1);
+      set(linear_rows_mfma_kernel<2, 1>, b2); set(linear_rows_mfma_kernel<2, 2>, b2); set(linear_rows_mfma_kernel<2, 3>, b2); set(linear_rows_mfma_kernel<2, 4>, b2);
+      return true;
+    }();
+    (void)lm_attr_set;
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, grid, dim3(256), lm_lds, static_cast<hipStream_t>(stream), x, x_rows, W, bias, add, add_rows, y, rows, N, K,
+                         act_in, act_out);
+    };
+    if (rt == 1) {
+      if (iters == 4) launch(linear_rows_mfma_kernel<1, 4>);
+      else if (iters == 3) launch(linear_rows_mfma_kernel<1, 3>);
+      else if (iters == 2) launch(linear_rows_mfma_kernel<1, 2>);
+      else launch(linear_rows_mfma_kernel<1, 1>);
+    } else {
+      if (iters == 4) launch(linear_rows_mfma_kernel<2, 4>);
+      else if (iters == 3) launch(linear_rows_mfma_kernel<2, 3>);
+      else if (iters == 2) launch(linear_rows_mfma_kernel<2, 2>);
+      else launch(linear_rows_mfma_kernel<2, 1>);
+    }
+    return ldc_launch_status();
+  }
   const int row_groups = ldc_cdiv(rows, LS_ROWS);
-  const bool plain = mod == nullptr && act_in != LDC_ACT_IN_TIMESTEP_SINCOS;  // the wide instantiation has neither feature
   if (plain && static_cast<long long>(ldc_cdiv(N, 4 * LS_CPW_MAX)) * row_groups >= 1024) {  // >= 4 workgroups per CU
     int iters = 1;
     if (K <= LS_KC) {  // one staged chunk: walk several column groups per workgroup, keep >= 4 workgroups per CU

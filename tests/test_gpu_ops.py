@@ -470,6 +470,31 @@ def test_linear_small(hip, rows, x_rows, add_rows):
     assert rel(y, want) < 1e-6
 
 
+@pytest.mark.parametrize("rows,x_rows,add_rows,N,K", [(20, 20, 20, 58368, 1536), (9, 9, 1, 4100, 256), (16, 1, 16, 4096, 1536), (17, 17, 17, 4111, 64),
+                                                    (32, 32, 4, 6000, 576), (40, 40, 40, 5000, 1536), (70, 7, 70, 4097, 512)])
+def test_linear_small_many_rows_on_the_matrix_cores(hip, rows, x_rows, add_rows, N, K):
+    """more than 8 rows and a wide output (the AdaLN modulation of a sampler chunk's conditioning batch: 20 rows per member x 38 D) go to
+    linear_rows_mfma_kernel - exact fp32 products on v_mfma_f32_16x16x4_f32: every epilogue option of the plain path, ragged column tails,
+    1 / 2 row tiles per workgroup, several row groups, K chunks (K > 512) and a partial last chunk; each row's result is independent of the
+    rows it shares a launch with (bit for bit against a launch of the first 9 rows)"""
+    x, W, b, add = rnd(x_rows, K, seed=1), rnd(N, K, seed=2) / K**0.5, rnd(N, seed=3), rnd(add_rows, N, seed=4)
+    y = torch.empty(rows, N, device="cuda")
+    hip.linear_small(dev(x), dev(W), y, rows=rows, N=N, K=K, x_rows=x_rows, bias=dev(b), add=dev(add), add_rows=add_rows, act_in=1, act_out=1)
+    xi = F.silu(x.double())[torch.arange(rows) % x_rows]
+    want = F.silu(xi @ W.double().T + b.double()) + add.double()[torch.arange(rows) % add_rows]
+    assert rel(y, want) < 1e-6
+    y2 = torch.empty(rows, N, device="cuda")
+    hip.linear_small(dev(x), dev(W), y2, rows=rows, N=N, K=K, x_rows=x_rows)  # no bias / activation / addend
+    assert rel(y2, x.double()[torch.arange(rows) % x_rows] @ W.double().T) < 1e-6
+    y9 = torch.empty(9, N, device="cuda")
+    hip.linear_small(dev(x), dev(W), y9, rows=9, N=N, K=K, x_rows=x_rows, bias=dev(b), add=dev(add), add_rows=add_rows, act_in=1, act_out=1)
+    assert torch.equal(y9, y[:9])
+    # the 8-row VALU kernel computes the same rows to fp32 rounding (other summation order)
+    y8 = torch.empty(8, N, device="cuda")
+    hip.linear_small(dev(x), dev(W), y8, rows=8, N=N, K=K, x_rows=x_rows, bias=dev(b), add=dev(add), add_rows=add_rows, act_in=1, act_out=1)
+    assert rel(y8, y[:8]) < 1e-6
+
+
 def test_linear_small_grouped_is_bitwise_the_single_launches(hip):
     """three independent small linears of different K / rows / activations in one launch == three launches, bit for bit;
     a problem that reads another's output is refused (the problems of one launch run concurrently)"""
