@@ -1,6 +1,8 @@
 // experiment: one C++ process (no Python, no torch), the victim = ldc_linear_small of a library build given on the command line, the aggressor =
 // synth_launch of /tmp/libsynth.so (tools/canary/synthetic_aggressor.hip built -shared), two streams
-//   hipcc tools/canary/first_read_repro_dl.cpp -o /tmp/repro_dl -ldl && /tmp/repro_dl ladcast_amd/libladcast_hip_ab_nofirstread.so [mode]
+//   hipcc tools/canary/first_read_repro_dl.cpp -o /tmp/repro_dl -ldl && /tmp/repro_dl <victim library> [mode] [aggressor library]
+//   tools/canary/build_code_object_variants.sh builds the victim (guard compiled out) and the aggressor as two libraries, as one library of two
+//   translation units, and as one library of ONE translation unit (one code object)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <chrono>
@@ -11,7 +13,7 @@ typedef int (*ls_fn)(const float*, int, const float*, const float*, const float*
 typedef int (*synth_fn)(int, int, int, void*);
 int main(int argc, char** argv) {
   void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
-  void* syn = dlopen("/tmp/libsynth.so", RTLD_NOW | RTLD_LOCAL);
+  void* syn = dlopen(argc > 3 ? argv[3] : "/tmp/libsynth.so", RTLD_NOW | RTLD_LOCAL);  // (the same path as argv[1]: both kernels from one library)
   if (!lib || !syn) { printf("dlopen failed: %s\n", dlerror()); return 1; }
   ls_fn ls = (ls_fn)dlsym(lib, "ldc_linear_small");
   synth_fn synth = (synth_fn)dlsym(syn, "synth_launch");
@@ -43,6 +45,6 @@ int main(int argc, char** argv) {
     }
     (void)hipDeviceSynchronize();
   }
-  printf("%s next to synthetic aggressor mode %d, one C++ process: %llu of %llu launches wrong, %llu wrong outputs\n", argv[1], mode, bad_l, launches, bad_w);
+  printf("%s next to synthetic aggressor mode %d from %s, one C++ process: %llu of %llu launches wrong, %llu wrong outputs\n", argv[1], mode, argc > 3 ? argv[3] : "/tmp/libsynth.so", bad_l, launches, bad_w);
   return 0;
 }
