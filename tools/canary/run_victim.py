@@ -17,12 +17,15 @@ pad = torch.empty(pad_mb << 20, dtype=torch.uint8, device="cuda") if pad_mb else
 g = torch.Generator().manual_seed(1)
 x, W, b = torch.randn(2, 1536, generator=g).cuda(), (torch.randn(58368, 1536, generator=g) / 39).cuda(), torch.randn(58368, generator=g).cuda()
 xl = torch.randn(2, 2250, 1536, generator=g).cuda()
+x20 = torch.randn(20, 1536, generator=g).cuda()
 sc = (0.1 * torch.randn(2, 3072, generator=g)).cuda()
 
 
 def run_victim(y):
     if victim == "gemv":
         hip.linear_small(x, W, y, rows=2, N=58368, K=1536, bias=b, act_in=hip.ACT_SILU)
+    elif victim == "gemv_rows20":  # 20 rows: linear_rows_mfma_kernel (x from LDS straight into MFMA operands)
+        hip.linear_small(x20, W, y, rows=20, N=58368, K=1536, bias=b, act_in=hip.ACT_SILU)
     elif victim == "gemv_narrow":  # the one-column-per-wave instantiation
         hip.linear_small(x, W, y[:, :1536], rows=2, N=1536, K=1536, bias=b, act_in=hip.ACT_SILU)
     elif victim == "torch_mv":
@@ -38,7 +41,7 @@ def run_victim(y):
                           y_bs=2250 * 1536, scale=sc[:, 1536:], shift=sc, mod_bs=3072, mode=0, eps=1e-6)
 
 
-shape = (2, 2250 * 1536) if victim in ("ln", "torch_layernorm", "torch_softmax") else (2, 58368)
+shape = (2, 2250 * 1536) if victim in ("ln", "torch_layernorm", "torch_softmax") else (20, 58368) if victim == "gemv_rows20" else (2, 58368)
 ref = torch.zeros(shape, device="cuda")
 run_victim(ref)
 torch.cuda.synchronize()  # the reference result is computed on an idle GPU, the aggressors start after it
