@@ -197,3 +197,47 @@ def test_1_6b_heun_step_truncated_chunk():
         e1, e2 = rel_l2(got[:, :, :, 1:5], want[:, :, :, 1:5]), rel_l2(got[:, :, :, 5:7], want[:, :, :, 5:7])
         print(f"\n1.6B, 6 lead steps = chunk + truncated chunk, 5 forwards each (oracle {tc:.0f} s) [{mode}]: rel-L2 {e1:.2e} / {e2:.2e}")
         assert e1 < TOL and e2 < TOL, (mode, e1, e2)
+
+
+def test_375m_two_members_three_chained_full_size_chunks():
+    """BASELINE configs[2] in shape AT FULL WIDTH (the 375M at B = 2 was one forward, the multi-chunk chain ran at tiny
+    width): the 375M model, 2 members, 12 lead steps = three chained R = 4 chunks - every chunk starts from the previous chunk's last frame of
+    its member - at 3 solver steps per chunk (5 forwards each; the 39-forward chunk is test_full_375m_chunk_matches_oracle), both modes, per
+    chunk against the CPU oracle.  The conditioning batch of a chunk is 3 noise levels x 2 members here."""
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    o = make_ar(dict(CONFIG_375M))
+    g = to_hip(o, dict(CONFIG_375M))
+    targs = {"mean": [0.1] * 84, "std": [1.3] * 84, "target_std": 0.5}
+    ic = synth_known(1)[0] * 2.6 + 0.1
+
+    class FakeAE:
+        device = torch.device("cpu")
+        config = type("c", (), dict(latent_channels=84, out_channels=89, static_channels=5))
+
+        def encode(self, x, static_conditioning_tensor=None):
+            return type("o", (), dict(latent=ic.permute(1, 0, 2, 3)))
+
+    t0 = [datetime(2018, 1, 1, 0)]
+    kw = dict(ensemble_size=2, num_inference_steps=3, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=72, sampler_type="edm",
+              return_latent=True)
+    tc = time.perf_counter()
+    want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), t0, OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
+                              static_tensor4encdec=torch.zeros(5, 120, 240), **kw)
+    tc = time.perf_counter() - tc
+    del o
+    assert want.shape == (1, 2, 84, 13, 15, 30) and not torch.isnan(want).any()
+    assert rel_l2(want[:, 0], want[:, 1]) > 1e-2  # the two members really differ (their own noise)
+    d01, d12 = rel_l2(want[:, :, :, 1:5], want[:, :, :, 5:9]), rel_l2(want[:, :, :, 5:9], want[:, :, :, 9:13])
+    print(f"\nchunk-to-chunk change of the oracle's frames: {d01:.2e} {d12:.2e}")
+    assert d01 > 1e-3 and d12 > 1e-3  # ... and so do consecutive chunks
+    for mode in ("fp32", "bf16x3"):
+        g.set_gemm_precision(mode).enable_hip_graph(True)
+        got = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **kw)
+        g.enable_hip_graph(False)
+        assert got.shape == want.shape and not torch.isnan(got).any()
+        per_chunk = [rel_l2(got[:, :, :, 1 + 4 * c : 5 + 4 * c], want[:, :, :, 1 + 4 * c : 5 + 4 * c]) for c in range(3)]
+        print(f"\n375M, 2 members x 12 lead steps = 3 chained chunks, 5 forwards each (oracle {tc:.0f} s) [{mode}] per-chunk rel-L2: {_fmt(per_chunk)}")
+        assert max(per_chunk) < TOL, (mode, per_chunk)
+    g.set_gemm_precision("fp32")
