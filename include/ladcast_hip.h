@@ -238,6 +238,9 @@ int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, int S, int H
  * (O, m, l) in slice order (bitwise reproducible): 288 units take ~1.13 rounds instead of two uneven ones.  workspace == NULL (or too
  * small) is legal: the call then runs the plain one-unit-per-workgroup grids. */
 long long ldc_attn_fwd_split_workspace_bytes(int B, int S, int H);
+/* upper bound of the above over every call shape (17.8 MB): allocate this once per stream when launches are captured into hipGraphs -
+ * a workspace that is replaced by a larger one later leaves the captured launches writing through a dangling pointer */
+long long ldc_attn_fwd_split_workspace_max_bytes(void);
 int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
                        long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* workspace,
                        long long workspace_bytes, void* stream);

@@ -739,6 +739,12 @@ extern "C" long long ldc_attn_fwd_split_workspace_bytes(int B, int S, int H) {
   return static_cast<long long>(np) * PART_FLOATS * static_cast<long long>(sizeof(float));
 }
 
+// the most any call shape can ask for (attn_tail_plan: rem <= 128 left-over units x floor(256 / rem) slices <= 256 pieces): what a caller
+// that captures launches into graphs allocates ONCE, so that no later shape ever makes it replace a pointer a captured launch holds
+extern "C" long long ldc_attn_fwd_split_workspace_max_bytes(void) {
+  return 256LL * PART_FLOATS * static_cast<long long>(sizeof(float));
+}
+
 extern "C" int ldc_attn_fwd_split(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
                                   long long qkv_bs, int ldo, long long o_bs, const float* key_bias, int flags, void* workspace,
                                   long long workspace_bytes, void* stream) {

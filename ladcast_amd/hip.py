@@ -75,6 +75,7 @@ def _load():
         "ldc_gemm_grouped_bf16x3_qkv": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
         "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
         "ldc_attn_fwd_split_workspace_bytes": (L, [I, I, I]),
+        "ldc_attn_fwd_split_workspace_max_bytes": (L, []),
         "ldc_attn_fwd_split": (I, [P, P, P, P, I, I, I, I, L, I, L, P, I, P, L, P]),
         "ldc_pack_weight_bf16x2": (I, [P, P, I, I, I, P]),
         "ldc_pack_weight_bf16": (I, [P, P, I, I, I, P]),
@@ -377,13 +378,20 @@ _attn_ws = {}
 
 
 def _attn_workspace(device, nbytes):
-    """scratch of the attention's TAIL schedule (more units than CUs), one per (device, stream), grown on demand - outside a capture:
-    samplers warm up on their capture stream first, like the GEMM workspace"""
+    """scratch of the attention's TAIL schedule (more units than CUs), one per (device, stream), allocated ONCE at the largest size any call
+    shape can ask for (ldc_attn_fwd_split_workspace_max_bytes, 17.8 MB) and never replaced: its pointer is baked into every hipGraph
+    captured on that stream, and graphs of several batch sizes stay alive side by side (a regrown workspace would leave the older graphs
+    writing their partials into freed memory).  A first call inside a capture would take the block from the graph's private pool and
+    publish it to eager callers: refused - samplers warm up on their capture stream first, like the GEMM workspace."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _attn_ws.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attn_fwd_split: the first call on a stream must be made outside a graph capture (run one warm-up forward)")
+        ws = torch.empty((lib.ldc_attn_fwd_split_workspace_max_bytes() + 3) // 4, device=device, dtype=torch.float32)
         _attn_ws[key] = ws
+    if ws.numel() * 4 < nbytes:
+        raise RuntimeError(f"attn_fwd_split: call shape asks for {nbytes} workspace bytes, more than ldc_attn_fwd_split_workspace_max_bytes")
     return ws
 
 

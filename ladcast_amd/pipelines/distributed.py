@@ -120,10 +120,13 @@ def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, 
         raise ValueError("local block does not hold this rank's work items")
     if device is None:
         device = local.device if local is not None else torch.device("cpu")
+    bad_local = False
     if item_shape is not None:
+        # a rank whose items do not have the announced shape must not raise HERE: the ranks without work (or with the right shape) would
+        # already be inside the all_gather and wait for it until the collective times out.  It joins every collective with a zero block
+        # and a status word behind the payload; every rank reads all status words and every rank raises the same error afterwards.
         item = tuple(int(v) for v in item_shape)
-        if mine and tuple(local.shape[1:]) != item:
-            raise ValueError(f"local items have shape {tuple(local.shape[1:])}, the caller announced {item}")
+        bad_local = bool(mine) and tuple(local.shape[1:]) != item
     else:
         meta = torch.zeros(8, dtype=torch.int64, device=device)  # item ndim + dims (<= 7), agreed by MAX over ranks
         if mine:
@@ -141,18 +144,28 @@ def gather_work(local: Optional[torch.Tensor], n_init: int, ensemble_size: int, 
         n_el *= v
     rows = max(1, int(max_bytes // max(4 * n_el, 1)))  # rows of the padded block per collective
     out = torch.empty((n_init * ensemble_size,) + item, dtype=torch.float32, device=out_device)
+    bad_ranks: List[int] = []
     for r0 in range(0, cmax, rows):
         n = min(rows, cmax - r0)
-        x = torch.zeros((n,) + item, dtype=torch.float32, device=device)
+        x = torch.zeros(n * n_el + 1, dtype=torch.float32, device=device)  # [n padded items | status word: 1 = "my items have another shape"]
         have = min(max(mine - r0, 0), n)
-        if have:
-            x[:have] = local[r0 : r0 + have].to(device)
+        if bad_local:
+            x[-1] = 1.0
+        elif have:
+            x[: have * n_el] = local[r0 : r0 + have].to(device).reshape(-1)
         bufs = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(bufs, x, group=group)
+        if r0 == 0:
+            bad_ranks = [r for r, v in enumerate(torch.stack([bf[-1] for bf in bufs]).tolist()) if v != 0.0]  # one read-back
+        if bad_ranks:
+            continue  # stay in step with the other ranks' collectives, copy nothing
         for r in range(world):
             cnt = min(max(b[r + 1] - b[r] - r0, 0), n)
             if cnt:
-                out[b[r] + r0 : b[r] + r0 + cnt] = bufs[r][:cnt].to(out_device)
+                out[b[r] + r0 : b[r] + r0 + cnt] = bufs[r][: cnt * n_el].reshape((cnt,) + item).to(out_device)
+    if bad_ranks:
+        mine_txt = f" (here: {tuple(local.shape[1:])})" if bad_local else ""
+        raise ValueError(f"items on rank(s) {bad_ranks} do not have the announced item shape {item}{mine_txt}")
     return out.reshape(n_init, ensemble_size, *item)
 
 

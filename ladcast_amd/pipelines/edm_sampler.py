@@ -47,7 +47,7 @@ def edm_AR_sampler(
         device = torch.device(device)
 
     shape = (batch_size, net.config.out_channels, return_seq_len, *known_latents.shape[-2:])
-    latents = randn_tensor(shape, generator=generator, device=device, dtype=net.dtype).contiguous()
+    latents = randn_tensor(shape, generator=generator, device=device, dtype=torch.float32).contiguous()  # fp32 whatever net.dtype says: see pipeline_AR.py
     noise_scheduler.set_timesteps(num_inference_steps, device=device)
     t_steps = noise_scheduler.sigmas  # (N+1,) fp32 on the host
     # (N,) fed to the model as (1,) views; a captured chunk holds its own device copy, so the upload happens on the paths that need it

@@ -59,7 +59,10 @@ class AutoRegressive2DPipeline:
         assert known_latents is not None, "known_latents must be provided"
         dev = self._execution_device
         shape = (batch_size, self.ar_model.config.out_channels, return_seq_len, *known_latents.shape[-2:])
-        image = randn_tensor(shape, generator=generator, device=dev, dtype=self.ar_model.dtype).contiguous()
+        # the initial noise is drawn in fp32 whatever dtype the caller cast the model to (pipeline_AR.py:77-82 asks for ar_model.dtype): the
+        # kernels read fp32 samples, the parameters of a bf16 / fp16 model are up-cast when its plan is built (`_upcast_to_fp32`), and an fp32
+        # draw is the stream the fp32 run of the same seeds sees
+        image = randn_tensor(shape, generator=generator, device=dev, dtype=torch.float32).contiguous()
         known_latents = known_latents.to(device=dev, dtype=torch.float32)  # the reference discards this result (Q13); we keep it (fp32: what the kernels read)
         if not do_edm_style:
             raise NotImplementedError("Only EDM style is supported for now")

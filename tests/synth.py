@@ -133,3 +133,23 @@ class oracle_threads:
 
     def __exit__(self, *a):
         torch.set_num_threads(self.old)
+
+
+class ToyNet:
+    """elementwise stand-in for the noise-prediction model (same call signature, `.config.out_channels`, `.dtype`,
+    `.device`): no matrix product and no transcendental, so the sampler outputs are reproducible bit for bit on any CPU"""
+
+    def __init__(self, channels, device="cpu"):
+        from types import SimpleNamespace
+
+        self.config = SimpleNamespace(out_channels=channels)
+        self.dtype = torch.float32
+        self.device = torch.device(device)
+
+    def __call__(self, x, t, known, time_elapsed=None, return_dict=True):
+        from types import SimpleNamespace
+
+        t = t.reshape(-1, 1, 1, 1, 1).to(x.dtype)
+        ts = 0.0 if time_elapsed is None else (time_elapsed.reshape(-1, 1, 1, 1, 1) % 100).to(x.dtype) * 0.01
+        y = 0.75 * x - 0.25 * x / (1.0 + x.abs()) + 0.5 * known.mean(dim=2, keepdim=True) + 0.0625 * t + ts  # bounded, IEEE-exact ops only
+        return SimpleNamespace(sample=y) if return_dict else (y,)

@@ -154,7 +154,7 @@ def _real_rollout_kwargs():
     """the PRODUCT's roll_out_serial on the CPU: host loop of the pipeline sampler with an elementwise toy network and a duck-typed
     scheduler (no HIP kernel on this path: latent_transform=None, sampler_type="pipeline", a given IC latent)"""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline
-    from tests.golden.make_golden import ToyNet
+    from tests.synth import ToyNet
     from tests.synth import DuckDDIMScheduler, synth_known
 
     g = torch.Generator().manual_seed(5)
@@ -283,3 +283,31 @@ def test_sharded_ensemble_mean_and_single_all_gather(tmp_path):
     assert torch.equal(one0, s1) and torch.equal(one1, s1) and torch.equal(three0, s3) and torch.equal(three1, s3)
     with __import__("pytest").raises(ValueError):
         roll_out_sharded(_fake_decoded_rollout, ensemble_size=2, pred_timestamp=[1], return_ensemble_mean=True, return_latent=True)
+
+
+def _worker_bad_shape(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    # one item, two ranks: rank 0 has no work, rank 1 owns the item - with a shape other than the announced one
+    local = None if rank == 0 else torch.ones(1, 2, 3)
+    try:
+        gather_work(local, 1, 1, item_shape=(2, 4))
+        msg = "no error"
+    except ValueError as e:
+        msg = str(e)
+    torch.save(msg, f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_announced_shape_mismatch_raises_on_every_rank_instead_of_hanging(tmp_path):
+    """a rank whose items do not have the announced shape used to raise before the all_gather the other ranks were
+    already waiting in (a hang until the collective's timeout).  Now the error travels with the collective and every rank raises."""
+    path = str(tmp_path / "msg")
+    mp.spawn(_worker_bad_shape, args=(2, _free_port(), path), nprocs=2, join=True)
+    m0, m1 = torch.load(path + ".0"), torch.load(path + ".1")
+    assert "rank(s) [1]" in m0 and "announced item shape (2, 4)" in m0
+    assert "rank(s) [1]" in m1 and "(here: (2, 3))" in m1

@@ -656,6 +656,24 @@ def test_model_cast_to_bf16_is_upcast_with_a_warning(tiny_pair):
         got = m(x, t, known, time_elapsed=ts).sample
     assert any("up-casting" in str(i.message) for i in w) and m.dtype == torch.float32
     assert torch.equal(got, ref(x, t, known, time_elapsed=ts).sample)
+    # the samplers drew their initial noise in `net.dtype` BEFORE the first forward had up-cast the model - the first call on a
+    # bf16-cast model raised (or drew a bf16 noise stream).  Both samplers, graph and eager, on a freshly cast model each time.
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+
+    want = {st: ensemble_AR_sampler(AutoRegressive2DPipeline(ref, EDMDPMSolverMultistepScheduler()), 2, 2, 3, known_latents=known, timestamps=ts,
+                                    sampler_type=st, device="cuda") for st in ("edm", "pipeline")}
+    for st in ("edm", "pipeline"):
+        for graph in (True, False):
+            mb = LaDCastTransformer3DModel.from_config(cfg)
+            mb.load_state_dict(o.state_dict(), strict=True)
+            mb = mb.to("cuda").eval().to(torch.bfloat16)
+            mb.use_hip_graph = graph
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = ensemble_AR_sampler(AutoRegressive2DPipeline(mb, EDMDPMSolverMultistepScheduler()), 2, 2, 3, known_latents=known, timestamps=ts,
+                                          sampler_type=st, device="cuda")
+            assert got.dtype == torch.float32 and torch.equal(got, want[st]), (st, graph)
     cfg = tiny_dcae_config()
     od = make_dcae(cfg)
     ae = AutoencoderDC.from_config(cfg)

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.golden.make_golden import ToyNet  # noqa: E402
+from tests.synth import ToyNet  # noqa: E402
 
 
 def _gens(n):

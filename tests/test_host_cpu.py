@@ -183,7 +183,7 @@ def test_pipeline_loop_takes_a_duck_typed_ddim_scheduler():
     bits.  (tests/test_gpu_model.py runs the same scheduler through the HIP model.)"""
     from ladcast_amd.pipelines import AutoRegressive2DPipeline
     from oracle.pipelines import AutoRegressive2DPipeline as OraclePipeline
-    from tests.golden.make_golden import ToyNet
+    from tests.synth import ToyNet
     from tests.synth import DuckDDIMScheduler, synth_known
 
     known, ts = synth_known(2), torch.tensor([2018010106])

@@ -10,7 +10,7 @@ import torch
 from oracle import ar_model as OM
 from oracle import pipelines as OP
 from oracle.scheduler import EDMDPMSolverMultistepScheduler
-from tests.golden.make_golden import ToyNet
+from tests.synth import ToyNet
 
 
 def _gens(n):
