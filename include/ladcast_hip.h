@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 3
+#define LDC_ABI_VERSION 4
 
 #define LDC_OK 0
 #define LDC_ERR_ARG (-1)       /* null pointer / non-positive size */
@@ -424,6 +424,13 @@ int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, v
 int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W,
                                int cin, int ldx, int cout, int ldy, int ldr, int ksize, int act, int in_fmt, int out_fmt,
                                void* workspace, long long workspace_bytes, void* stream);
+/* ABI 4: 3 x 3 convs in the split-bf16 / bf16 formats run a second kernel where the shape fills its tiles (conv_halo.hip): a workgroup
+ * owns a TH x TW pixel tile and DMAs the tile's (TH + 2) x (TW + 2) halo image into LDS once per channel chunk - sphere padding folded
+ * into the source addresses - instead of once per (tap, chunk); same arguments, same arithmetic per output element (k order: chunk-major
+ * instead of tap-major, so results differ from the gathered kernel in the last bits of the fp32 accumulation only).
+ * ldc_sphere_conv_plan tells which kernel a call shape gets: returns 1 and the tile (rows = TH x TW: 128 | 256; width TW) for the
+ * halo-staged kernel, 0 for the gathered one (ksize != 3, fp32 rows, images that would leave most of the tiles' rows empty). */
+int ldc_sphere_conv_plan(int B, int H, int W, int cin, int cout, int ksize, int in_fmt, int* tile_rows, int* tile_w);
 /* Producers of operand rows.  `ys` = operand copy in format `fmt` (LDC_FMT_SPLIT | LDC_FMT_BF16; lds % 8 == 0, >= C rounded up to
  * 8, 32-byte aligned; pad columns zeroed), `y` = fp32 copy (the residual stream / inputs of depthwise convs); either may be NULL,
  * not both. */

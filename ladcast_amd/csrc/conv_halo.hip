@@ -1,0 +1,453 @@
+// Dense 3x3 SphereConv2d (models/sphere_conv.py:62-129,174-192) as an implicit GEMM whose pixel operand is staged ONCE per channel
+// chunk: round 5's replacement for the gathered-row conv of gemm_bf16x3_v3.hip (CONV = true) on the DCAE's large layers.
+//
+// Why (profiles/r05_a_conv_variants.log, r05_a_conv_pmc_summary.txt): in the gathered form every k-step (tap, 32-channel chunk) pulls its
+// own BM x 128 B pixel panel through L2 into LDS - nine DMA'd copies of (nearly) the same pixels per chunk, 48 KB per k-step and CU with
+// the weight tile, 571 MB of fabric traffic per 252 -> 252 full-resolution launch against 60 MB algorithmic.  The same kernel with the
+// DMAs compiled out runs the launch in 78 us instead of 112; ordering the k-steps chunk-major so that L2 serves the re-reads cut the
+// fabric bytes 5.5x and made the launch SLOWER (the per-k-step source arithmetic): what costs is the L2 -> LDS leg itself.
+// Here a workgroup owns a TH x TW pixel tile (BM = TH TW) and one 128-column panel of the output.  For every channel chunk it DMAs the
+// (TH + 2) x (TW + 2) HALO image of the tile once (1.33x the tile for 8 x 32) into one of two LDS buffers, with the sphere padding rule
+// folded into the source addresses (rows past a pole mirror and roll by W / 2, columns wrap), and forms the A fragments of all nine taps
+// from that image: tap (ky, kx) of tile pixel (ty, tx) is halo pixel (ty + ky, tx + kx) - at the two pole rows (tx + 2 - kx) for the
+// kernel row that reaches over the pole, which is the reference's left-right flip of that kernel row.  Weights stream through the 3-stage
+// ring exactly as in the GEMM (k-step = (chunk, tap): byte offset ((tap << kshift) + chunk) * 128 of the packed tap-major row), and the
+// k-step body - fragment window, MFMA order, waits - is gemm_bf16x3_v3.hip's.  Per k-step and wave: 2 weight DMAs + 1 halo DMA (a dump
+// slot when the chunk's pieces are out) instead of 6 / 4.
+// Halo image in LDS: pixel p at byte p * 128; its 16-byte chunk c at slot c ^ f(p), f(p) = ((p >> 1) & 1) | (p & 4).  Found by search
+// (tools/lds_swizzle_search.py): with this f the four 16-lane groups of a ds_read_b128 are conflict-free when lanes 0-15 / 16-31 /
+// 32-47 / 48-63 read k-group 0 / 1 / 2 / 3 of ANY 16 consecutive pixels - every alignment, which the +-1 pixel tap shifts need (the
+// GEMM's swizzle only serves runs that start at a multiple of 16).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+#include "gemm_v3_common.inc"
+
+struct HaloArgs {
+  DevProblem P;  // A = X operand rows, W = packed weight, bias / R / C, d.{M, N, lda, ldc, ldr, act}; cH, cW, cin, kshift, zero16
+  int TW, tw_shift, TH, HP;  // tile (TH x TW pixels, TW a power of two), halo pitch TW + 2
+  int NPX, NP;               // halo pixels (TH + 2) HP, DMA pieces of 8 pixels
+  int hp_magic;              // j / HP == (j * hp_magic) >> 16 for j < 8 NP (checked by the host)
+  int tiles_x, tiles_y, tn;  // pixel tiles per frame, column panels
+  int n_chunks;              // channel chunks of CPK
+  int G;                     // work items = frames * tiles_y * tiles_x * tn = grid size
+};
+
+// tile row r -> output pixel row of Y (0x7fffffff: outside the image)
+struct TileRows {
+  int base, y0, x0, tw_shift, tw_mask, H, W;
+  __device__ __forceinline__ int operator()(int, int r) const {
+    const int y = y0 + (r >> tw_shift), x = x0 + (r & tw_mask);
+    return (y < H && x < W) ? base + y * W + x : 0x7fffffff;
+  }
+};
+
+__device__ __forceinline__ unsigned halo_swz(int p) { return static_cast<unsigned>(((p >> 1) & 1) | (p & 4)); }
+
+template <int BM, int TERMS>
+__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
+  constexpr int CPK = TERMS == 1 ? 2 * BK : BK;  // channels per 128-byte chunk (plain bf16 | split groups)
+  constexpr int RT = BM / 128;
+  constexpr int NACC = RT * 8;
+  constexpr int WB = BN * ROW_B;  // one weight stage: 16 KiB
+  constexpr int TAPS = 9;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const DevProblem& P = a.P;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  int g;
+  {  // XCD-aware placement: an XCD gets a contiguous run of work items - the column panels of one pixel tile and the neighbouring
+     // tiles (shared halo rows) meet in one L2
+    const int bid = blockIdx.x, G = a.G;
+    const int q = G >> 3, r = G & 7, xcd = bid & 7;
+    g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int bn, y0, x0, frame;
+  {
+    const unsigned gu = static_cast<unsigned>(g), tn = static_cast<unsigned>(a.tn);
+    unsigned t = gu / tn;
+    bn = __builtin_amdgcn_readfirstlane(static_cast<int>(gu - t * tn));
+    const unsigned tx_i = t % static_cast<unsigned>(a.tiles_x);
+    t /= static_cast<unsigned>(a.tiles_x);
+    const unsigned ty_i = t % static_cast<unsigned>(a.tiles_y);
+    frame = __builtin_amdgcn_readfirstlane(static_cast<int>(t / static_cast<unsigned>(a.tiles_y)));
+    y0 = __builtin_amdgcn_readfirstlane(static_cast<int>(ty_i) * a.TH);
+    x0 = __builtin_amdgcn_readfirstlane(static_cast<int>(tx_i) * a.TW);
+  }
+  const int H = P.cH, W = P.cW, HP = a.HP;
+  const int fbase = frame * H * W;
+  const unsigned smem_lds = lds_addr(smem);
+  const unsigned abuf_b = static_cast<unsigned>(a.NP) * 1024u;      // one halo buffer
+  const unsigned abuf0 = NSTAGE * WB;                                // LDS offset of halo buffer 0
+  unsigned char* const dump = smem + abuf0 + 2 * abuf_b + wave * 1024;  // per-wave landing zone of the DMAs that carry nothing
+  const int n_k = a.n_chunks * TAPS;
+
+  const int lane = fresh_lane();
+  const int fr = lane & 15, kg = lane >> 4;
+  const int lr = lane >> 3, lp = lane & 7;
+  // W fragment addresses: the GEMM's image (rows aligned to 16, swz)
+  const unsigned f_r = swz(fr);
+  const unsigned w_hi = smem_lds + fr * ROW_B + (((2 * kg) ^ f_r) << 4);
+  const unsigned w_lo = smem_lds + fr * ROW_B + (((2 * kg + 1) ^ f_r) << 4);
+  // this lane's tile pixels: row tile rt of the wave, fragment row fr
+  int p0[RT], pole[RT];  // halo pixel of tap (0, 0); bit 0: the pixel is in the northern pole row (kernel row 0 flips), bit 2: southern (row 2)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int r = 16 * (RT * wave + rt) + fr;
+    const int ty = r >> a.tw_shift, tx = r & (a.TW - 1);
+    p0[rt] = ty * HP + tx;
+    pole[rt] = ((y0 + ty == 0) ? 1 : 0) | ((y0 + ty == H - 1) ? 4 : 0);
+  }
+  // a wave whose rows all lie outside the image issues no MFMA (scalar: the wave's first row is its top-left pixel, TW >= 16)
+  const bool wave_rows = (y0 + ((16 * RT * wave) >> a.tw_shift) < H) && (x0 + ((16 * RT * wave) & (a.TW - 1)) < W);
+  const unsigned kg2 = 2u * static_cast<unsigned>(kg);
+  // fragment address (hi chunk; lo = hi ^ 16) of tap (ky, kx) in the halo buffer at LDS offset ab
+  auto a_addr = [&](int rt, int ky, int kx, unsigned ab) -> unsigned {
+    const int d = 2 - 2 * kx;  // the pole rows read the mirrored tap column: kx -> 2 - kx (branch-free: the k-step body stays one block)
+    const int flip = -((pole[rt] >> ky) & ((ky & 1) ^ 1));  // all ones: this kernel row reaches over this pixel's pole
+    const int p = p0[rt] + ky * HP + kx + (flip & d);
+    return smem_lds + ab + (static_cast<unsigned>(p) << 7) + ((kg2 ^ halo_swz(p)) << 4);
+  };
+
+  // weight DMA sources (k-step 0): instruction i covers panel rows [8 (wave + 8 i), + 8)
+  const long long w_row_bytes = static_cast<long long>(TAPS) * (CPK << P.kshift) * (TERMS == 1 ? 2 : 4);
+  const unsigned char* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (wave + 8 * i) + lr;
+    int gn = bn * BN + r;
+    gn = gn < P.d.N ? gn : P.d.N - 1;
+    w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
+  }
+  auto issue_w = [&](int kt_, int stage, int i) {
+    const bool live = kt_ < n_k;
+    const int kt = live ? kt_ : n_k - 1;
+    const int chunk = kt / TAPS, tap = kt - chunk * TAPS;
+    const long long koff = static_cast<long long>((tap << P.kshift) + chunk) * (BK * 4);
+#ifdef LDC_GEMM_DIAG_NODMA
+    if (kt >= 0) return;
+#endif
+    dma16(w_src[i] + koff, live ? smem + stage * WB + (wave + 8 * i) * 1024 : dump);
+  };
+  // halo piece `slot` of this wave for channel chunk `chunk` (pieces q = wave + 8 slot, 8 pixels each)
+  const unsigned char* const Xb = reinterpret_cast<const unsigned char*>(P.A);
+  const long long row_b = static_cast<long long>(P.d.lda) * 4;
+  auto issue_a = [&](int chunk_, int slot) {
+    const int q = wave + 8 * slot;
+    const bool live = chunk_ < a.n_chunks && q < a.NP;
+    const int chunk = chunk_ < a.n_chunks ? chunk_ : a.n_chunks - 1;
+    int j = 8 * q + lr;
+    j = j < a.NPX ? j : a.NPX - 1;
+    const int hy = (j * a.hp_magic) >> 16, hx = j - hy * HP;
+    int r = y0 - 1 + hy, c = x0 - 1 + hx;
+    {  // rows past a pole mirror and roll by W / 2 (selects, no divergent branch in the main loop)
+      const bool lo = r < 0, hi = r >= H;
+      const int rm = lo ? -1 - r : 2 * H - 1 - r;
+      r = (lo || hi) ? rm : r;
+      c -= (lo || hi) ? (W >> 1) : 0;
+    }
+    r = r < 0 ? 0 : r;  // (rows of a ragged tile far past the pole: never used)
+    c += c < 0 ? W : 0;
+    c -= c >= W ? W : 0;
+    c = c < 0 ? 0 : (c >= W ? W - 1 : c);
+    const int cs = lp ^ static_cast<int>(halo_swz(j));  // the chunk slot this lane fetches lands at slot lp
+    const unsigned char* src = Xb + static_cast<long long>(fbase + r * W + c) * row_b + chunk * (BK * 4) + (cs << 4);
+    // 8-column groups behind cin read zeros (their weights are zero too); a select, not a branch
+    src = (chunk * CPK + 8 * (TERMS == 3 ? (cs >> 1) : cs) >= P.cin) ? P.zero16 : src;
+#ifdef LDC_GEMM_DIAG_NODMA
+    if (chunk >= 0) return;
+#endif
+    dma16(src, live ? smem + abuf0 + (chunk & 1) * abuf_b + q * 1024 : dump);
+  };
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x4v wh0, wl0, wh1, wl1, wh2, wl2, wh3, wl3;  // W fragment window: 4 column tiles
+  i32x4v ah0[RT], al0[RT], ah1[RT], al1[RT];      // A fragments of the current / next k-step
+
+#define LDC_SB __builtin_amdgcn_sched_barrier(0)
+#define LDC_RD_W(WH, WL, SBH, SBL, CT)             \
+  {                                                \
+    LDC_DS_READ(WH, SBH, (CT) * (16 * ROW_B));     \
+    LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));     \
+  }
+  // A fragments of tap (KY, KX) from the halo buffer at LDS offset AB
+#define LDC_RD_A(AH, AL, KY, KX, AB)                                    \
+  {                                                                     \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < RT; ++rt_) {              \
+      const unsigned ad_ = a_addr(rt_, KY, KX, AB);                     \
+      LDC_DS_READ(AH[rt_], ad_, 0);                                     \
+      LDC_DS_READ(AL[rt_], ad_ ^ 16u, 0);                               \
+    }                                                                   \
+  }
+#define LDC_MM(ACC, WF, AF)                                                                                                    \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WF), __builtin_bit_cast(bf16x8, AF), ACC, 0, 0, 0); \
+  LDC_SB;
+#define LDC_CT(CT, WH, WL, AH, AL)                 \
+  if constexpr (WR) {                              \
+    if constexpr (TERMS == 1) {                    \
+      LDC_MM(acc[(CT)], WH, AH[0])                 \
+      if constexpr (RT == 2) {                     \
+        LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])      \
+      }                                            \
+      LDC_MM(acc[(CT)], WL, AL[0])                 \
+      if constexpr (RT == 2) {                     \
+        LDC_MM(acc[8 + (CT)], WL, AL[RT - 1])      \
+      }                                            \
+    } else if constexpr (RT == 2) {                \
+      LDC_MM(acc[(CT)], WH, AL[0])                 \
+      LDC_MM(acc[8 + (CT)], WH, AL[RT - 1])        \
+      LDC_MM(acc[(CT)], WL, AH[0])                 \
+      LDC_MM(acc[8 + (CT)], WL, AH[RT - 1])        \
+      LDC_MM(acc[(CT)], WH, AH[0])                 \
+      LDC_MM(acc[8 + (CT)], WH, AH[RT - 1])        \
+    } else {                                       \
+      LDC_MM(acc[(CT)], WH, AL[0])                 \
+      LDC_MM(acc[(CT)], WL, AH[0])                 \
+      LDC_MM(acc[(CT)], WH, AH[0])                 \
+    }                                              \
+  }
+#define LDC_WAIT(X, Y)                                     \
+  asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(X), "+v"(Y)); \
+  LDC_SB;
+  // one k-step kt = (chunk ch, tap tp): (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt + 1 = (chn, kyn, kxn).
+  // DMAs: before the barrier the second weight piece of k-step kt + 2; behind it the first of kt + 3 (into this k-step's stage, free
+  // once every wave is past the barrier) and halo piece tp of chunk ch + 1 - whose buffer was last read for the fragments of k-step
+  // (ch - 1, tap 8), waited for before the barrier one k-step ago.  vmcnt(3) at the barrier leaves exactly those three in flight.
+#define LDC_KSTEP(AH, AL, AHN, ALN)                                                                                  \
+  {                                                                                                                  \
+    const int st1 = st == NSTAGE - 1 ? 0 : st + 1;                                                                   \
+    const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;                                                                 \
+    const unsigned sb1 = st1 * WB;                                                                                   \
+    const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                             \
+    if constexpr (RT == 2) {                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
+    } else {                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                         \
+    }                                                                                                                \
+    LDC_SB;                                                                                                          \
+    LDC_CT(0, wh0, wl0, AH, AL)                                                                                      \
+    LDC_RD_W(wh0, wl0, wch, wcl, 4)                                                                                  \
+    issue_w(kt + 2, st2, 1);                                                                                         \
+    LDC_WAIT(wh1, wl1)                                                                                               \
+    LDC_CT(1, wh1, wl1, AH, AL)                                                                                      \
+    LDC_RD_W(wh1, wl1, wch, wcl, 5)                                                                                  \
+    LDC_WAIT(wh2, wl2)                                                                                               \
+    LDC_CT(2, wh2, wl2, AH, AL)                                                                                      \
+    LDC_RD_W(wh2, wl2, wch, wcl, 6)                                                                                  \
+    LDC_WAIT(wh3, wl3)                                                                                               \
+    LDC_CT(3, wh3, wl3, AH, AL)                                                                                      \
+    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                                  \
+    LDC_WAIT(wh0, wl0)                                                                                               \
+    LDC_CT(4, wh0, wl0, AH, AL)                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));         \
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    LDC_SB;                                                                                                          \
+    /* next k-step's coordinates (scalar) */                                                                         \
+    const bool wrap_ = tp + 1 == TAPS;                                                                               \
+    const int tpn = wrap_ ? 0 : tp + 1, chn = wrap_ ? ch + 1 : ch;                                                   \
+    const int kyn = tpn >= 6 ? 2 : (tpn >= 3 ? 1 : 0), kxn = tpn - 3 * kyn;                                          \
+    LDC_RD_A(AHN, ALN, kyn, kxn, abuf0 + (chn & 1) * abuf_b)                                                         \
+    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                                  \
+    issue_w(kt + 3, st, 0);                                                                                          \
+    LDC_SB;                                                                                                          \
+    LDC_CT(5, wh1, wl1, AH, AL)                                                                                      \
+    LDC_RD_W(wh1, wl1, wnh, wnl, 1)                                                                                  \
+    issue_a(ch + 1, tp);                                                                                             \
+    LDC_SB;                                                                                                          \
+    LDC_CT(6, wh2, wl2, AH, AL)                                                                                      \
+    LDC_RD_W(wh2, wl2, wnh, wnl, 2)                                                                                  \
+    LDC_SB;                                                                                                          \
+    LDC_CT(7, wh3, wl3, AH, AL)                                                                                      \
+    LDC_RD_W(wh3, wl3, wnh, wnl, 3)                                                                                  \
+    LDC_SB;                                                                                                          \
+    st = st1;                                                                                                        \
+    sb = sb1;                                                                                                        \
+    tp = tpn;                                                                                                        \
+    ch = chn;                                                                                                        \
+  }
+
+  // prologue: the whole halo of chunk 0, the weights of k-steps 0 and 1; then (behind the barrier) the post-barrier DMAs of "k-step -1"
+  constexpr int MAXSLOT = 7;  // pieces per wave and chunk: slot t is issued in tap t and has landed by the barrier of tap t + 2 <= 8
+#pragma unroll
+  for (int s_ = 0; s_ < MAXSLOT; ++s_) issue_a(0, s_);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_w(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) issue_w(1, 1, i);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  LDC_RD_A(ah0, al0, 0, 0, abuf0)
+  LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
+  LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
+  LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
+  LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
+  issue_w(2, 2, 0);
+  issue_a(a.n_chunks, 0);  // (a dump piece: keeps the barrier's vmcnt(3) exact in k-step 0)
+  LDC_SB;
+
+  // the loop in two copies, with and without MFMAs (a wave whose rows all lie outside the image): left to the compiler's loop unswitching the
+  // branch stayed inside the k-step and every join copied the accumulator file (336 v_mov per two k-steps, 206 VGPRs at 128 rows)
+  auto main_loop = [&](auto wr_) {
+    constexpr bool WR = decltype(wr_)::value;
+    unsigned sb = 0;
+    int st = 0, tp = 0, ch = 0;
+    int kt = 0;
+    for (; kt + 1 < n_k; ++kt) {  // pairs of k-steps (the A fragment sets alternate); n_k = 9 chunks is odd for an odd chunk count
+      LDC_KSTEP(ah0, al0, ah1, al1)
+      ++kt;
+      LDC_KSTEP(ah1, al1, ah0, al0)
+    }
+    if (kt < n_k) {
+      LDC_KSTEP(ah0, al0, ah1, al1)
+    }
+  };
+  if (wave_rows) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(ah0[rt]), "+v"(al0[rt]), "+v"(ah1[rt]), "+v"(al1[rt]));
+#undef LDC_KSTEP
+#undef LDC_WAIT
+#undef LDC_CT
+#undef LDC_MM
+#undef LDC_RD_A
+#undef LDC_RD_W
+#undef LDC_SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped DMAs of the last k-steps land in this wave's dump slot: before the LDS goes back
+
+  TileRows rows{fbase, y0, x0, a.tw_shift, a.TW - 1, H, W};
+  tile_epilogue<BM, false, TileRows, false>(P, 0, 0, bn, acc, wave, lane, rows);
+}
+
+template <int BM, int TERMS>
+int launch_halo(const HaloArgs& a, size_t lds, hipStream_t st) {
+  static const bool attr_set = [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<BM, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((conv_halo_kernel<BM, TERMS>), dim3(a.G), dim3(512), lds, st, a);
+  return ldc_launch_status();
+}
+
+}  // namespace
+
+// Tile choice.  Tiles are 256 pixels (TH x TW, TW a power of two >= 16, at most seven halo pieces per wave and chunk) and a launch is whole
+// tiles, one per workgroup, in ceil(tiles / 256) rounds.  Measured against the gathered conv on the DCAE's layer shapes, same box
+// (profiles/r05_c_conv_tile_sweep.log): 252 -> 252 at 120 x 240 (240 tiles) 104 -> 92 us, 504 -> 1008 at 60 x 120 (256 tiles) 187 -> 174,
+// eight frames of every 3 x 3 layer 8 - 14 % less - but 504 -> 504 at 60 x 120 in ONE frame (128 tiles) 106 -> 164: a launch that cannot
+// give most CUs a tile stays on the gathered kernel, which cuts along K over all of them.  (A 128-pixel tile of this kernel was slower
+// than the gathered conv on every shape - the weight stream per FLOP doubles - and is not built.)
+// Among the tile shapes the one with the fewest tiles wins, then the smallest halo.
+static bool halo_plan(int B, int H, int W, int cout, int* bm_out, int* tw_out) {
+  constexpr int bm = 256;
+  const int tn = ldc_cdiv(cout, BN);
+  int best_tw = 0, best_np = 0;
+  long long best_tiles = 0;
+  static const char* const force_tw = LDC_AB_GETENV("LDC_CONV_HALO_TW");  // measurement aids (A/B build only)
+  for (int tw = 16; tw <= bm; tw *= 2) {
+    if (force_tw && atoi(force_tw) != tw) continue;
+    const int th = bm / tw;
+    if (th > H || tw > W) continue;
+    const int np = ldc_cdiv((th + 2) * (tw + 2), 8);
+    if (np > 7 * 8) continue;  // seven pieces per wave and chunk
+    if (static_cast<long long>(NSTAGE) * BN * ROW_B + 2LL * np * 1024 + 8 * 1024 > 160 * 1024) continue;
+    const long long tiles = static_cast<long long>(B) * ldc_cdiv(H, th) * ldc_cdiv(W, tw) * tn;
+    if (best_tw == 0 || tiles < best_tiles || (tiles == best_tiles && np < best_np)) {
+      best_tw = tw;
+      best_np = np;
+      best_tiles = tiles;
+    }
+  }
+  static const char* const min_tiles = LDC_AB_GETENV("LDC_CONV_HALO_MIN_TILES");
+  if (best_tw == 0 || best_tiles < (min_tiles ? atoll(min_tiles) : 192)) return false;
+  // useful share of the rounds: a launch just past a multiple of 256 tiles (257 -> two rounds) is better cut along K
+  const long long rounds = (best_tiles + 255) / 256;
+  if (static_cast<double>(best_tiles) / (256.0 * rounds) < 0.7) return false;
+  *bm_out = bm;
+  *tw_out = best_tw;
+  return true;
+}
+
+// which kernel ldc_sphere_conv_nhwc_split runs for a shape (include/ladcast_hip.h): 1 = the halo-staged kernel, with its tile
+extern "C" int ldc_sphere_conv_plan(int B, int H, int W, int cin, int cout, int ksize, int in_fmt, int* tile_rows, int* tile_w) {
+  (void)cin;
+  int bm = 0, tw = 0;
+  static const char* const halo_sw = LDC_AB_GETENV("LDC_CONV_HALO");
+  const bool halo = ksize == 3 && (in_fmt == LDC_FMT_SPLIT || in_fmt == LDC_FMT_BF16) && B > 0 && H > 0 && W > 0 && cout > 0 &&
+                    !(halo_sw && atoi(halo_sw) == 0) && halo_plan(B, H, W, cout, &bm, &tw);
+  if (tile_rows) *tile_rows = halo ? bm : 0;
+  if (tile_w) *tile_w = halo ? tw : 0;
+  return halo ? 1 : 0;
+}
+
+// Launch.  Returns LDC_ERR_UNSUPPORTED when the halo kernel does not serve the shape (the caller then runs the gathered conv of
+// gemm_bf16x3_v3.hip): exact-fp32 rows, images too small to fill tiles.
+int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W, int cin,
+                           int ldx, int cout, int ldy, int ldr, int act, int in_fmt, int out_fmt, const void* zero16, void* stream) {
+  if (in_fmt != LDC_FMT_SPLIT && in_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
+  const bool one = in_fmt == LDC_FMT_BF16;
+  const int cpk = one ? 2 * BK : BK;
+  const long long M = static_cast<long long>(B) * H * W;
+  if (M * ldx * 4 >= (1LL << 40) || M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  const int tn = ldc_cdiv(cout, BN);
+  int best_bm = 0, best_tw = 0;
+  if (!halo_plan(B, H, W, cout, &best_bm, &best_tw)) return LDC_ERR_UNSUPPORTED;
+  HaloArgs a{};
+  DevProblem& P = a.P;
+  P.A = X;
+  P.W = static_cast<const unsigned char*>(Wp);
+  P.bias = bias;
+  P.R = R;
+  P.C = Y;
+  P.d.M = static_cast<int>(M);
+  P.d.N = cout;
+  P.d.batch = 1;
+  P.d.lda = ldx;
+  P.d.ldc = ldy;
+  P.d.ldr = ldr;
+  P.d.act = act;
+  {
+    auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
+    bool v4 = (cout % 4 == 0) && (ldy % 4 == 0) && al16(Y);
+    if (bias) v4 = v4 && al16(bias);
+    if (R) v4 = v4 && al16(R) && (ldr % 4 == 0);
+    P.vec4 = v4 ? 1 : 0;
+    P.c_split = out_fmt != LDC_FMT_F32 ? (one ? LDC_FMT_BF16 : LDC_FMT_SPLIT) : 0;
+    if (P.c_split && !(v4 && ldy % 8 == 0 && ldy >= ((cout + 7) & ~7) && (reinterpret_cast<unsigned long long>(Y) & 31ull) == 0)) return LDC_ERR_ALIGN;
+  }
+  P.cH = H;
+  P.cW = W;
+  P.cin = cin;
+  P.ks = 3;
+  int ktpt = ldc_cdiv(cin, cpk);
+  while ((1 << P.kshift) < ktpt) ++P.kshift;
+  P.zero16 = static_cast<const unsigned char*>(zero16);
+  a.n_chunks = ktpt;  // chunks behind ceil(cin / cpk) hold only zero weights: not visited (the gathered conv walks all 2^kshift)
+  a.TW = best_tw;
+  a.TH = best_bm / best_tw;
+  while ((1 << a.tw_shift) < a.TW) ++a.tw_shift;
+  a.HP = a.TW + 2;
+  a.NPX = (a.TH + 2) * a.HP;
+  a.NP = ldc_cdiv(a.NPX, 8);
+  a.hp_magic = 65536 / a.HP + 1;
+  for (int j = 0; j < 8 * a.NP; ++j)
+    if (((j * a.hp_magic) >> 16) != j / a.HP) return LDC_ERR_UNSUPPORTED;  // (never for HP >= 18 and j < 512)
+  a.tiles_x = ldc_cdiv(W, a.TW);
+  a.tiles_y = ldc_cdiv(H, a.TH);
+  a.tn = tn;
+  const long long G = static_cast<long long>(B) * a.tiles_y * a.tiles_x * tn;
+  if (G > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
+  a.G = static_cast<int>(G);
+  const size_t lds = static_cast<size_t>(NSTAGE) * BN * ROW_B + 2u * a.NP * 1024u + 8u * 1024u;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  return one ? launch_halo<256, 1>(a, lds, st) : launch_halo<256, 3>(a, lds, st);
+}

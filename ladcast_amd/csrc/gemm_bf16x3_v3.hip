@@ -30,39 +30,7 @@
 
 namespace {
 
-constexpr int BN = 128, BK = 32;
-constexpr int ROW_B = 128;  // bytes per LDS row (both operands)
-constexpr int NSTAGE = 3;
-constexpr int MAXP = LDC_GEMM_MAX_PROBLEMS;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-
-struct DevProblem {
-  const float* A;          // split activations
-  const unsigned char* W;  // packed split weights
-  const float* bias;
-  const float* gate;
-  const float* R;
-  float* C;
-  ldc_gemm_desc d;
-  int tm, tn, kt;
-  int rm;       // tile order: super-rows of rm row tiles, inside a super-row column panel by column panel (launch_v3)
-  long long unit0;
-  long long tile0;
-  int vec4;     // epilogue may use 16-byte accesses
-  int c_split;  // LDC_GEMM_C_SPLIT
-  // QKV projection epilogue (ldc_gemm_grouped_bf16x3_qkv): column tile bn is one head of q (bn < heads), k or v
-  int qkv_heads;  // 0 = ordinary epilogue
-  int rope_row0;
-  const float* qk_w[2];
-  const float* rope_cs;  // [rows][64][2]: (cos, sin) of rotary pair i
-  float eps, qscale;
-  // implicit-GEMM SphereConv2d (CONV instantiations): A row m = output pixel, k-step = (tap, 32-channel chunk)
-  int cH, cW, cin, ks, kshift;     // 2^kshift k-steps per tap
-  const unsigned char* zero16;     // 16 zero bytes: source of the chunks behind cin in a tap's last k-step
-};
+#include "gemm_v3_common.inc"
 
 struct SKArgs {
   DevProblem pr[MAXP];
@@ -88,322 +56,6 @@ __device__ __forceinline__ int find_problem_by_unit(const SKArgs& a, long long u
   for (int k = 1; k < MAXP; ++k)
     if (k < a.np && u >= a.pr[k].unit0) pi = k;
   return pi;
-}
-
-#ifdef LDC_GEMM_DIAG_NOLDS  // diagnostic build: no fragment reads (results are garbage)
-#define LDC_DS_READ(dst, addr, off) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(addr))
-#else
-#define LDC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#endif
-
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return static_cast<unsigned>(reinterpret_cast<unsigned long long>(p));
-}
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
-
-__device__ __forceinline__ float xor16_add(float x) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor32_add(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// This lane's index, produced where it is asked for.  Everything per-lane in the kernel (fragment addresses, DMA row / slot, output
-// row and column) derives from it; derived from threadIdx at the kernel entry those values stay live across the main loop AND the
-// epilogue, the 256-row kernel spills them at entry, and the segment loop then waits for the scratch stores (first touch of the
-// wave's scratch page: ~4 us before the first DMA, measured with the prologue stamps).  Two VALU instructions instead, per use site.
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-
-// Epilogue of the fused QKV projection (models/LaDCast_3D_model.py:92-169,175-190): the 128-column tile is exactly one head, so the
-// tile holds whole head rows - a lane has 32 of a row's 128 values (4 per column tile), the lanes 16 / 32 / 48 further the rest.
-// bias -> RMSNorm(128, eps) * weight -> adjacent-pair rotary embedding (q and k heads; same operation order as
-// qk_rmsnorm_rope_kernel) -> q * qscale -> hi / lo split, written as the operand rows of attn_split.hip: q / k in the
-// LDC_GEMM_A_SPLIT group format, v as [hi x128 | lo x128].  This is what attn_pack_kernel did in a separate pass.
-// The rotary table is the compact form [rows][64][2] = (cos_i, sin_i) per rotary pair (the reference's [rows][128] cos / sin
-// tables repeat every value twice, get_1d_rotary_pos_embed: repeat_interleave(2)).  (A factored table - distinct (cos, sin) rows per
-// axis, ~10 KB, plus a coordinate triple per token - gave the same bits and no gain on the 128-row instance, +24 us on the 256-row
-// one, whose registers the extra address arithmetic does not fit: dropped.)
-// Measured (tools/qkv_epilogue_ab.py, profiles/r02_*_qkv_epilogue_ab.log): +2.5 / +4 / +12 us per launch on the refiner / dual /
-// single-block QKV launches over the plain epilogue, against the 16-22 us pack pass it replaces; a variant that first turns the
-// accumulators into a row-per-lane layout through LDS (contiguous table reads, no cross-lane sums) was 3x worse (+50 us on the
-// 256-row launch: two lanes per row serialise what 4 lanes x 8 column tiles issue in parallel here) and was dropped.
-template <int BM>
-__device__ __forceinline__ void qkv_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
-                                             int lane) {
-  constexpr int RT = BM / 128;
-  lane = fresh_lane();  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
-  const int M = P.d.M;
-  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
-  const int which = bn / P.qkv_heads;  // 0: q, 1: k, 2: v (wave-uniform)
-  const int nl = 4 * (lane >> 4);
-  const float* __restrict__ w = which < 2 ? P.qk_w[which] : nullptr;
-  const float* __restrict__ rope = which < 2 ? P.rope_cs : nullptr;
-  // round 3: every load of the tile's epilogue is issued before the arithmetic that needs it (bias and norm weights of the column
-  // panel here, a row tile's eight rotary vectors at its start) instead of one exposed L2 round trip per column tile and pass
-  float4 bv[8], wv[8];
-  if (P.bias) {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) bv[ct] = *reinterpret_cast<const float4*>(P.bias + bn * BN + nl + 16 * ct);
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) bv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (w) {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) wv[ct] = *reinterpret_cast<const float4*>(w + 16 * ct + nl);
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) wv[ct] = make_float4(1.f, 1.f, 1.f, 1.f);
-  }
-  const float qs = which == 0 ? P.qscale : 1.f;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
-#ifndef LDC_QKV_EPI_HOIST  // experiment (make ... DIAG=-DLDC_QKV_EPI_HOIST): let the second row tile's rotary loads be hoisted over the first's arithmetic
-    asm volatile("" ::: "memory");  // one row tile's loads at a time
-#endif
-    if (m >= M) continue;  // the 4 lanes of a row share m: the cross-lane sums below stay among active lanes
-    // (cos, sin) of this lane's two rotary pairs per column tile: one 16-byte load each, all eight in flight before the row's
-    // sum of squares is formed
-    float4 tv[8];
-    if (rope) {
-      const float* __restrict__ cs = rope + static_cast<long long>(P.rope_row0 + m) * 128 + nl;
-#pragma unroll
-      for (int ct = 0; ct < 8; ++ct) tv[ct] = *reinterpret_cast<const float4*>(cs + 16 * ct);
-    }
-    float r = 1.f;
-    if (w) {  // RMSNorm(128, eps) of the head row (acc + bias, recomputed below: registers are scarce on the 256-row tile)
-      float ss = 0.f;
-#pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
-        const f32x4 av = acc[rt * 8 + ct];
-        const float a0 = av[0] + bv[ct].x, a1 = av[1] + bv[ct].y, a2 = av[2] + bv[ct].z, a3 = av[3] + bv[ct].w;
-        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-      }
-      ss = xor32_add(xor16_add(ss));  // the lanes 16 / 32 / 48 further hold the rest of the head row
-      r = rsqrtf(ss * (1.0f / 128.0f) + P.eps);
-    }
-    unsigned char* row = reinterpret_cast<unsigned char*>(C + static_cast<long long>(m) * P.d.ldc + bn * BN);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const f32x4 av = acc[rt * 8 + ct];
-      float x0 = av[0] + bv[ct].x, x1 = av[1] + bv[ct].y, x2 = av[2] + bv[ct].z, x3 = av[3] + bv[ct].w;
-      if (w) {
-        x0 = x0 * r * wv[ct].x; x1 = x1 * r * wv[ct].y; x2 = x2 * r * wv[ct].z; x3 = x3 * r * wv[ct].w;
-      }
-      if (rope) {
-        const float4 t = tv[ct];
-        const float o0 = x0 * t.x + (-x1) * t.y, o1 = x1 * t.x + x0 * t.y;
-        const float o2 = x2 * t.z + (-x3) * t.w, o3 = x3 * t.z + x2 * t.w;
-        x0 = o0; x1 = o1; x2 = o2; x3 = o3;
-      }
-      if (which == 0) { x0 *= qs; x1 *= qs; x2 *= qs; x3 *= qs; }
-      const int n = 16 * ct + nl;
-      float r0, r1, r2, r3;
-      const unsigned hx = ldc_split_pair(x0, x1, r0, r1), hy = ldc_split_pair(x2, x3, r2, r3);
-      const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
-      // even lane groups end up with the 8 hi values of columns (n & ~7) .. + 7, odd ones with the 8 lo values (tile_epilogue)
-      const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
-      const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
-      unsigned char* dst = which < 2 ? row + 4 * (n & ~7) + 4 * (n & 4)           // group [hi x8 | lo x8]
-                                     : row + 2 * (n & ~7) + ((n & 4) ? 256 : 0);  // planes [hi x128 | lo x128]
-      *reinterpret_cast<uint4*>(dst) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-    }
-  }
-}
-
-// Round 3: the ordinary epilogue in a form whose loads do not wait on each other.  The generic routine below decides everything per
-// column tile at run time (bias / gate / residual present, activation, output format, edge columns): 16 (8) times "load -> wait ->
-// compute -> store" behind wave-uniform branches, i.e. 16 exposed L2 round trips per tile - measured 11-14 us per 256-row GELU tile of
-// which the stores are 2.5 us and the activation 4 us (profiles/r03_b_gemm_epilogue_diagnostics.log).  Here the run-time decisions sit
-// OUTSIDE the unrolled loops: the eight bias and gate vectors of the column panel are fetched first, then a row tile's eight residual
-// vectors together, then arithmetic and stores run without a memory wait in between.  ACT and FMT are compile-time; an absent bias /
-// gate / residual is a register of zeros / ones (x * 1 + 0 is exact).  Same value as the generic routine for every element (the
-// gate / residual step is the same fused multiply-add); used for whole 128-column panels with 16-byte-aligned rows (`vec4`).
-template <int BM, int ACT, int FMT>
-__device__ __forceinline__ void tile_epilogue_fast(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
-                                                   int lane) {
-  constexpr int RT = BM / 128;
-  lane = fresh_lane();  // lane-derived offsets are formed HERE, not hoisted to the kernel entry and spilled across the main loop
-  const int M = P.d.M;
-  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
-  const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
-  const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
-  const int n0 = bn * BN + 4 * (lane >> 4);
-  float4 bv[8], gv[8];
-  if (P.bias) {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) bv[ct] = *reinterpret_cast<const float4*>(P.bias + n0 + 16 * ct);
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) bv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const bool mod = gate != nullptr || R != nullptr;  // wave-uniform
-  if (gate) {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) gv[ct] = *reinterpret_cast<const float4*>(gate + n0 + 16 * ct);
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) gv[ct] = make_float4(1.f, 1.f, 1.f, 1.f);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
-    asm volatile("" ::: "memory");  // one row tile's loads at a time (the second tile's would otherwise be hoisted and spill)
-    if (m >= M) continue;  // the 4 lanes of a row share m: the lane-group swaps below stay among active lanes
-    float* crow = C + static_cast<long long>(m) * P.d.ldc;
-    float4 v[8];
-    if (mod) {
-      float4 rv[8];
-      if (R) {
-        const float* rrow = R + static_cast<long long>(m) * P.d.ldr + n0;
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) rv[ct] = *reinterpret_cast<const float4*>(rrow + 16 * ct);
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) rv[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
-        const f32x4 av = acc[rt * 8 + ct];
-        float4 x = make_float4(ldc_apply_act(av[0] + bv[ct].x, ACT), ldc_apply_act(av[1] + bv[ct].y, ACT), ldc_apply_act(av[2] + bv[ct].z, ACT),
-                               ldc_apply_act(av[3] + bv[ct].w, ACT));
-        v[ct] = make_float4(fmaf(x.x, gv[ct].x, rv[ct].x), fmaf(x.y, gv[ct].y, rv[ct].y), fmaf(x.z, gv[ct].z, rv[ct].z), fmaf(x.w, gv[ct].w, rv[ct].w));
-      }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
-        const f32x4 av = acc[rt * 8 + ct];
-        v[ct] = make_float4(ldc_apply_act(av[0] + bv[ct].x, ACT), ldc_apply_act(av[1] + bv[ct].y, ACT), ldc_apply_act(av[2] + bv[ct].z, ACT),
-                            ldc_apply_act(av[3] + bv[ct].w, ACT));
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const int n = n0 + 16 * ct;
-      if constexpr (FMT == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(crow) + 2 * n) = make_uint2(ldc_pack_pair(v[ct].x, v[ct].y), ldc_pack_pair(v[ct].z, v[ct].w));
-      } else if constexpr (FMT == LDC_FMT_SPLIT) {  // [hi x8 | lo x8] groups: see the generic routine
-        float r0, r1, r2, r3;
-        const unsigned hx = ldc_split_pair(v[ct].x, v[ct].y, r0, r1), hy = ldc_split_pair(v[ct].z, v[ct].w, r2, r3);
-        const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
-        const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);
-        unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
-        *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      } else {
-        *reinterpret_cast<float4*>(crow + n) = v[ct];
-      }
-    }
-  }
-}
-
-template <int BM, int FMT>
-__device__ __forceinline__ void tile_epilogue_fast_act(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
-                                                       int lane) {
-  switch (P.d.act) {  // wave-uniform; one straight-line body per activation
-    case LDC_ACT_SILU: tile_epilogue_fast<BM, LDC_ACT_SILU, FMT>(P, b, bm, bn, acc, wave, lane); break;
-    case LDC_ACT_GELU_TANH: tile_epilogue_fast<BM, LDC_ACT_GELU_TANH, FMT>(P, b, bm, bn, acc, wave, lane); break;
-    case LDC_ACT_RELU: tile_epilogue_fast<BM, LDC_ACT_RELU, FMT>(P, b, bm, bn, acc, wave, lane); break;
-    default: tile_epilogue_fast<BM, LDC_ACT_NONE, FMT>(P, b, bm, bn, acc, wave, lane); break;
-  }
-}
-
-// acc[rt * 8 + ct]: rows 16 (RT wave + rt) + lane % 16, columns 16 ct + 4 (lane / 16) + (0..3)
-template <int BM, bool QKV = true>
-__device__ __forceinline__ void tile_epilogue(const DevProblem& P, int b, int bm, int bn, const f32x4 (&acc)[BM / 16], int wave,
-                                              int lane) {
-  constexpr int RT = BM / 128;
-  if constexpr (QKV) {
-    if (P.qkv_heads) {
-      qkv_epilogue<BM>(P, b, bm, bn, acc, wave, lane);
-      return;
-    }
-  }
-#ifndef LDC_EPI_GENERIC_ONLY  // measurement aid (make ... DIAG=-DLDC_EPI_GENERIC_ONLY): the round-2 epilogue everywhere
-  if (P.vec4 && bn * BN + BN <= P.d.N) {  // a whole column panel, 16-byte accesses
-    if (P.c_split == LDC_FMT_BF16) tile_epilogue_fast_act<BM, LDC_FMT_BF16>(P, b, bm, bn, acc, wave, lane);
-    else if (P.c_split) tile_epilogue_fast_act<BM, LDC_FMT_SPLIT>(P, b, bm, bn, acc, wave, lane);
-    else tile_epilogue_fast_act<BM, LDC_FMT_F32>(P, b, bm, bn, acc, wave, lane);
-    return;
-  }
-#endif
-  lane = fresh_lane();
-  const int M = P.d.M, N = P.d.N;
-  float* __restrict__ C = P.C + static_cast<long long>(b) * P.d.c_bs;
-  const float* __restrict__ R = P.R ? P.R + static_cast<long long>(b) * P.d.r_bs : nullptr;
-  const float* __restrict__ gate = P.gate ? P.gate + static_cast<long long>(b) * P.d.gate_bs : nullptr;
-  const int act = P.d.act;
-  const int n_lane = bn * BN + 4 * (lane >> 4);
-  const int Nw = P.c_split ? ((N + 7) & ~7) : N;  // operand rows are written in whole 8-column groups (pad columns zero)
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int m = bm * BM + 16 * (RT * wave + rt) + (lane & 15);
-    if (m >= M) continue;
-    float* crow = C + static_cast<long long>(m) * P.d.ldc;
-    const float* rrow = R ? R + static_cast<long long>(m) * P.d.ldr : nullptr;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      const int n = n_lane + 16 * ct;
-      if (n >= Nw) continue;
-      const bool pad = n >= N;  // operand rows with N = 4 mod 8: the pad half of the last group is written as zeros
-      const f32x4 av = acc[rt * 8 + ct];
-      if (P.vec4) {
-        float4 v = make_float4(av[0], av[1], av[2], av[3]);
-        if (P.bias && !pad) {
-          const float4 bv = *reinterpret_cast<const float4*>(P.bias + n);
-          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        }
-        v.x = ldc_apply_act(v.x, act); v.y = ldc_apply_act(v.y, act); v.z = ldc_apply_act(v.z, act); v.w = ldc_apply_act(v.w, act);
-        if (gate && !pad) {
-          const float4 gv = *reinterpret_cast<const float4*>(gate + n);
-          v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
-        }
-        if (rrow && !pad) {
-          const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
-        if (pad) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.c_split == LDC_FMT_BF16) {  // plain bf16 row: this lane's 4 columns are 8 bytes at byte offset 2 n
-          const uint2 h2 = make_uint2(ldc_pack_pair(v.x, v.y), ldc_pack_pair(v.z, v.w));
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(crow) + 2 * n) = h2;
-        } else if (P.c_split) {
-          // columns 8c..8c+7 of a row live in 32 bytes [hi x8 | lo x8]; this lane has half of a group, the lane 16 further
-          // (k-group ^ 1) the other half of the same row: v_permlane16_swap hands the even k-group both hi halves and the
-          // odd one both lo halves, so each lane stores 16 contiguous bytes instead of two 8-byte pieces
-          float r0, r1, r2, r3;
-          const unsigned hx = ldc_split_pair(v.x, v.y, r0, r1), hy = ldc_split_pair(v.z, v.w, r2, r3);
-          const unsigned lx = ldc_pack_pair(r0, r1), ly = ldc_pack_pair(r2, r3);
-          const auto sx = __builtin_amdgcn_permlane16_swap(hx, lx, false, false);  // [0]: even rows keep hi, odd rows get lo(even)
-          const auto sy = __builtin_amdgcn_permlane16_swap(hy, ly, false, false);  // [1]: even rows get hi(odd), odd rows keep lo
-          unsigned char* grp = reinterpret_cast<unsigned char*>(crow + (n & ~7)) + 4 * (n & 4);
-          *reinterpret_cast<uint4*>(grp) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        } else {
-          *reinterpret_cast<float4*>(crow + n) = v;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= N) continue;
-          float v = av[r] + (P.bias ? P.bias[n + r] : 0.f);
-          v = ldc_apply_act(v, act);
-          if (gate) v *= gate[n + r];
-          if (rrow) v += rrow[n + r];
-          crow[n + r] = v;
-        }
-      }
-    }
-  }
 }
 
 // Diagnostic build only (-DLDC_GEMM_STAMPS, `make stamps`): wall-clock / shader-clock stamps per workgroup into the
@@ -1199,6 +851,15 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
     // 128-row tiles only, as for the fp32 GEMMs (a tile is 2.7x the split kernel's MFMA time: balance beats the halved W traffic)
     q.d.flags = 0;
     return launch_v3<128, 0, true>(&q, nullptr, 1, workspace, workspace_bytes, stream, &cp);
+  }
+  if (ksize == 3) {  // round 5: the halo-staged kernel (conv_halo.hip) where it serves the shape
+    static const char* const halo_sw = LDC_AB_GETENV("LDC_CONV_HALO");  // measurement aid (A/B build): 0 = never
+    if (!(halo_sw && atoi(halo_sw) == 0)) {
+      if (workspace == nullptr || workspace_bytes < LDC_GEMM_COUNTER_BYTES) return LDC_ERR_ARG;
+      const int hs = ldc_conv_halo_dispatch(X, Wp, bias, R, Y, B, H, W, cin, ldx, cout, ldy, ldr, act, in_fmt, out_fmt,
+                                            static_cast<const unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES - 64, stream);
+      if (hs != LDC_ERR_UNSUPPORTED) return hs;
+    }
   }
   const long long tiles256 = static_cast<long long>(ldc_cdiv(M, 256)) * ldc_cdiv(cout, BN);
   // tile height: measured cross-over (tools/conv_bench.py) - 252 -> 252 at 120 x 240 (226 tiles of 256 rows): 101 us at 256 rows, 121 at

@@ -23,7 +23,7 @@ ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
 GEMM_F32_REGSTAGE = 8  # exact-fp32 problems: stay on the register-staged stream-K kernel (include/ladcast_hip.h)
 ATTN_OUT_SPLIT, ATTN_BF16_1TERM, ATTN_OUT_BF16 = 1, 2, 4
-ABI_VERSION = 3  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
+ABI_VERSION = 4  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
 FMT_F32, FMT_SPLIT, FMT_BF16 = 0, 1, 2  # activation formats of the producers' `out_split` arguments (True == FMT_SPLIT)
 
 
@@ -86,6 +86,7 @@ def _load():
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
+        "ldc_sphere_conv_plan": (I, [I, I, I, I, I, I, I, P, P]),
         "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
         "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
         "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
@@ -579,6 +580,13 @@ def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=
     ws = _grouped_workspace(X.device)
     _check(lib.ldc_sphere_conv_nhwc_split(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx, cout, ldy if ldy is not None else cout,
                                           ldr, ksize, act, int(in_fmt), int(out_fmt), _p(ws), ws.numel() * 4, _stream()), "ldc_sphere_conv_nhwc_split")
+
+
+def sphere_conv_plan(B, H, W, cin, cout, ksize=3, in_fmt=FMT_SPLIT):
+    """(halo, tile_rows, tile_w): which kernel `sphere_conv_nhwc_split` runs for the shape (ldc_sphere_conv_plan)"""
+    bm, tw = c_int(0), c_int(0)
+    halo = lib.ldc_sphere_conv_plan(B, H, W, cin, cout, ksize, int(in_fmt), ctypes.byref(bm), ctypes.byref(tw))
+    return bool(halo), bm.value, tw.value
 
 
 def split_rows(x, ys, *, rows, C, ldx=None, lds=None, fmt=FMT_SPLIT):

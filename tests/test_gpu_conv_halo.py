@@ -1,0 +1,114 @@
+"""The halo-staged 3x3 SphereConv2d kernel (csrc/conv_halo.hip, round 5) against the CPU oracle (oracle/sphere_conv.py, itself pinned to
+fixtures of the reference class: tests/test_oracle_sphere_conv.py) and against the two older HIP kernels of the same conv.  Shapes are
+chosen so that `ldc_sphere_conv_plan` reports the halo kernel with its 256-pixel tile, ragged tiles in both directions, a channel tail
+(cin % 32 != 0), a ragged output panel (cout % 128 != 0) and several frames; every case contains both pole rows (kernel-row flip,
+models/sphere_conv.py:174-192) and the longitude wrap.  Tolerances: split-bf16 2e-5 rel-L2 against the fp32 oracle (the kernel's
+arithmetic is the GEMM's: hi.hi + hi.lo + lo.hi, fp32 accumulate), single-term bf16 6e-3."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ladcast_amd.hip as hip  # noqa: E402
+from ladcast_amd.models.sphere_conv import pack_dense_weight, pack_dense_weight_bf16, pack_dense_weight_bf16x3  # noqa: E402
+from oracle.sphere_conv import SphereConv2d as OracleConv  # noqa: E402
+from tests.synth import rel_l2  # noqa: E402
+
+CASES = [  # (B, H, W, cin, cout): >= 192 tiles of 256 pixels each, so that the plan is the halo kernel
+    (16, 24, 48, 40, 136),  # two chunks with a channel tail, ragged output panel (136 = 128 + 8), tiles ragged in H
+    (16, 20, 40, 28, 256),  # ragged tiles in both directions, a single partial chunk
+    (12, 32, 64, 40, 256),  # whole tiles, twelve frames
+    (20, 17, 36, 96, 192),  # odd height, three full chunks, one and a half output panels
+]
+
+
+def _oracle(x, w, b, act=None, resid=None):
+    o = OracleConv(w.shape[1], w.shape[0], 3, 1, 1, bias=True)
+    with torch.no_grad():
+        o.weight.copy_(w)
+        o.bias.copy_(b)
+        y = o(x)
+    if act == "relu":
+        y = torch.relu(y)
+    if resid is not None:
+        y = y + resid
+    return y
+
+
+def _rows(t):  # NCHW -> [B*H*W, C]
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", CASES)
+def test_halo_conv_matches_oracle_split_mode(B, H, W, ci, co):
+    halo, rows, tw = hip.sphere_conv_plan(B, H, W, ci, co)
+    assert halo and rows == 256, (halo, rows, tw)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5
+    b = torch.randn(co, generator=g)
+    r = torch.randn(B, co, H, W, generator=g)
+    want = _oracle(x, w, b, act="relu", resid=r)
+    c8 = -(-ci // 8) * 8
+    xs = torch.empty(B * H * W, c8, device="cuda")
+    hip.split_rows(_rows(x).cuda(), xs, rows=B * H * W, C=ci)
+    y = torch.full((B * H * W, co), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_split(xs, pack_dense_weight_bf16x3(w.cuda()), y, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, bias=b.cuda(), R=_rows(r).cuda(), ldr=co,
+                               ksize=3, act=hip.ACT_RELU)
+    got = y.cpu()
+    assert torch.isfinite(got).all()
+    err = rel_l2(got, _rows(want))
+    assert err < 2e-5, err
+    # the exact-fp32 tile kernel of the same library (second implementation)
+    y32 = torch.empty_like(y)
+    hip.sphere_conv_nhwc(_rows(x).cuda(), pack_dense_weight(w.cuda()), y32, B=B, H=H, W=W, cin=ci, cout=co, bias=b.cuda(), R=_rows(r).cuda(), ldr=co, ksize=3,
+                         act=hip.ACT_RELU)
+    assert rel_l2(got, y32.cpu()) < 2e-5
+
+
+def test_halo_conv_writes_operand_rows_for_the_next_conv():
+    """out_fmt = split: the rows the next conv reads (hi / lo groups, zero pad columns) equal split_rows of the fp32 result"""
+    B, H, W, ci, co = 16, 24, 48, 40, 132  # cout % 8 == 4: the last group's pad half is written as zeros
+    assert hip.sphere_conv_plan(B, H, W, ci, co)[0]
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(B, ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5, torch.randn(co, generator=g)
+    c8, o8 = -(-ci // 8) * 8, -(-co // 8) * 8
+    xs = torch.empty(B * H * W, c8, device="cuda")
+    hip.split_rows(_rows(x).cuda(), xs, rows=B * H * W, C=ci)
+    wp = pack_dense_weight_bf16x3(w.cuda())
+    y = torch.empty(B * H * W, co, device="cuda")
+    hip.sphere_conv_nhwc_split(xs, wp, y, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, bias=b.cuda(), ksize=3)
+    ys = torch.full((B * H * W, o8), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_split(xs, wp, ys, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, ldy=o8, bias=b.cuda(), ksize=3, out_fmt=hip.FMT_SPLIT)
+    ref = torch.empty(B * H * W, o8, device="cuda")
+    hip.split_rows(y, ref, rows=B * H * W, C=co)
+    assert torch.equal(ys.view(torch.int32), ref.view(torch.int32))
+
+
+def test_halo_conv_single_term_bf16_mode():
+    B, H, W, ci, co = 16, 24, 48, 72, 136  # 64-channel chunks: one full, one with 8 channels
+    assert hip.sphere_conv_plan(B, H, W, ci, co, in_fmt=hip.FMT_BF16)[0]
+    g = torch.Generator().manual_seed(5)
+    x, w, b = torch.randn(B, ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) / (9 * ci) ** 0.5, torch.randn(co, generator=g)
+    want = _oracle(x, w, b)
+    c8 = -(-ci // 8) * 8
+    xs = torch.empty(B * H * W, c8, device="cuda")
+    hip.split_rows(_rows(x).cuda(), xs, rows=B * H * W, C=ci, fmt=hip.FMT_BF16)
+    y = torch.full((B * H * W, co), float("nan"), device="cuda")
+    hip.sphere_conv_nhwc_split(xs, pack_dense_weight_bf16(w.cuda()), y, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, bias=b.cuda(), ksize=3, in_fmt=hip.FMT_BF16)
+    err = rel_l2(y.cpu(), _rows(want))
+    assert err < 6e-3, err
+    # same operands rounded to bf16 once, exact products: what the single-term kernel computes up to fp32 summation order
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    assert rel_l2(y.cpu(), _rows(_oracle(xb, wb, b))) < 2e-6
+
+
+def test_dcae_layer_shapes_take_the_halo_kernel():
+    """the plan for the shipped DC-AE's 3x3 layers (configs/DC_AE_84_pretrain.yaml): full- and half-resolution stages on the halo
+    kernel at one frame already; the 30 x 60 / 15 x 30 stages once a batch of frames fills their tiles"""
+    assert hip.sphere_conv_plan(1, 120, 240, 252, 252)[:2] == (True, 256)
+    assert hip.sphere_conv_plan(1, 60, 120, 504, 1008)[:2] == (True, 256)
+    assert not hip.sphere_conv_plan(1, 60, 120, 504, 504)[0]  # 128 tiles: the gathered kernel cuts along K over all CUs instead
+    assert hip.sphere_conv_plan(8, 60, 120, 504, 504)[0] and hip.sphere_conv_plan(8, 30, 60, 504, 504)[0]
+    assert not hip.sphere_conv_plan(1, 6, 8, 16, 16)[0]  # narrower than a tile
+    assert not hip.sphere_conv_plan(1, 120, 240, 252, 252, ksize=5)[0] and not hip.sphere_conv_plan(1, 120, 240, 252, 252, in_fmt=hip.FMT_F32)[0]
