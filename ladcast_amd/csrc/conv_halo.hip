@@ -85,7 +85,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
   const unsigned abuf_b = static_cast<unsigned>(a.NP) * 1024u;      // one halo buffer
   const unsigned abuf0 = NSTAGE * WB;                                // LDS offset of halo buffer 0
   unsigned char* const dump = smem + abuf0 + 2 * abuf_b + wave * 1024;  // per-wave landing zone of the DMAs that carry nothing
-  const int n_k = a.n_chunks * TAPS;
 
   const int lane = fresh_lane();
   const int fr = lane & 15, kg = lane >> 4;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     return smem_lds + ab + (static_cast<unsigned>(p) << 7) + ((kg2 ^ halo_swz(p)) << 4);
   };
 
-  // weight DMA sources (k-step 0): instruction i covers panel rows [8 (wave + 8 i), + 8)
+  // weight DMA sources (chunk 0, tap 0): instruction i covers panel rows [8 (wave + 8 i), + 8)
   const long long w_row_bytes = static_cast<long long>(TAPS) * (CPK << P.kshift) * (TERMS == 1 ? 2 : 4);
   const unsigned char* w_src[2];
 #pragma unroll
@@ -124,41 +123,50 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     gn = gn < P.d.N ? gn : P.d.N - 1;
     w_src[i] = P.W + static_cast<long long>(gn) * w_row_bytes + ((lp ^ swz(r)) << 4);
   }
-  auto issue_w = [&](int kt_, int stage, int i) {
-    const bool live = kt_ < n_k;
-    const int kt = live ? kt_ : n_k - 1;
-    const int chunk = kt / TAPS, tap = kt - chunk * TAPS;
+  // (tap, stage, i are literals at every call site: the main loop is unrolled over the nine taps of a chunk)
+  auto issue_w = [&](int chunk_, int tap, int stage, int i) {
+    const bool live = chunk_ < a.n_chunks;
+    const int chunk = live ? chunk_ : a.n_chunks - 1;
     const long long koff = static_cast<long long>((tap << P.kshift) + chunk) * (BK * 4);
 #ifdef LDC_GEMM_DIAG_NODMA
-    if (kt >= 0) return;
+    if (chunk >= 0) return;
 #endif
     dma16(w_src[i] + koff, live ? smem + stage * WB + (wave + 8 * i) * 1024 : dump);
   };
-  // halo piece `slot` of this wave for channel chunk `chunk` (pieces q = wave + 8 slot, 8 pixels each)
-  const unsigned char* const Xb = reinterpret_cast<const unsigned char*>(P.A);
-  const long long row_b = static_cast<long long>(P.d.lda) * 4;
-  auto issue_a = [&](int chunk_, int slot) {
-    const int q = wave + 8 * slot;
-    const bool live = chunk_ < a.n_chunks && q < a.NP;
-    const int chunk = chunk_ < a.n_chunks ? chunk_ : a.n_chunks - 1;
-    int j = 8 * q + lr;
-    j = j < a.NPX ? j : a.NPX - 1;
-    const int hy = (j * a.hp_magic) >> 16, hx = j - hy * HP;
-    int r = y0 - 1 + hy, c = x0 - 1 + hx;
-    {  // rows past a pole mirror and roll by W / 2 (selects, no divergent branch in the main loop)
+  // halo pieces: piece q = wave + 8 slot covers halo pixels 8 q .. 8 q + 7; this lane's source pixel row of every slot is formed once
+  // (sphere padding: rows past a pole mirror and roll by W / 2, columns wrap); the chunk slot it fetches lands at slot lp of the piece.
+  // 64 slot = 0 mod 8 in bits 1, 2 of the halo pixel index, so the swizzle - and with it the channel group this lane fetches - is the
+  // same for all of this lane's pieces
+  constexpr int MAXSLOT = 7;  // pieces per wave and chunk: slot t is issued in tap t and has landed by the barrier of tap t + 2 <= 8
+  const int cs = lp ^ static_cast<int>(halo_swz(8 * wave + lr));
+  const int zthr = P.cin - 8 * (TERMS == 3 ? (cs >> 1) : cs);  // this lane's 8-column group holds channels while chunk * CPK < zthr
+  const unsigned char* a_row[MAXSLOT];
+  {
+    const unsigned char* const Xb = reinterpret_cast<const unsigned char*>(P.A);
+    const long long row_b = static_cast<long long>(P.d.lda) * 4;
+#pragma unroll
+    for (int s_ = 0; s_ < MAXSLOT; ++s_) {
+      int j = 8 * (wave + 8 * s_) + lr;
+      j = j < a.NPX ? j : a.NPX - 1;
+      const int hy = (j * a.hp_magic) >> 16, hx = j - hy * HP;
+      int r = y0 - 1 + hy, c = x0 - 1 + hx;
       const bool lo = r < 0, hi = r >= H;
       const int rm = lo ? -1 - r : 2 * H - 1 - r;
       r = (lo || hi) ? rm : r;
       c -= (lo || hi) ? (W >> 1) : 0;
+      r = r < 0 ? 0 : r;  // (rows of a ragged tile far past the pole: never used)
+      c += c < 0 ? W : 0;
+      c -= c >= W ? W : 0;
+      c = c < 0 ? 0 : (c >= W ? W - 1 : c);
+      a_row[s_] = Xb + static_cast<long long>(fbase + r * W + c) * row_b + (cs << 4);
     }
-    r = r < 0 ? 0 : r;  // (rows of a ragged tile far past the pole: never used)
-    c += c < 0 ? W : 0;
-    c -= c >= W ? W : 0;
-    c = c < 0 ? 0 : (c >= W ? W - 1 : c);
-    const int cs = lp ^ static_cast<int>(halo_swz(j));  // the chunk slot this lane fetches lands at slot lp
-    const unsigned char* src = Xb + static_cast<long long>(fbase + r * W + c) * row_b + chunk * (BK * 4) + (cs << 4);
-    // 8-column groups behind cin read zeros (their weights are zero too); a select, not a branch
-    src = (chunk * CPK + 8 * (TERMS == 3 ? (cs >> 1) : cs) >= P.cin) ? P.zero16 : src;
+  }
+  auto issue_a = [&](int chunk_, int slot) {
+    const int q = wave + 8 * slot;
+    const bool live = slot < MAXSLOT && chunk_ < a.n_chunks && q < a.NP;
+    const int chunk = chunk_ < a.n_chunks ? chunk_ : a.n_chunks - 1;
+    const unsigned char* src = a_row[slot < MAXSLOT ? slot : 0] + chunk * (BK * 4);
+    src = chunk * CPK >= zthr ? P.zero16 : src;  // 8-column groups behind cin read zeros (their weights are zero too)
 #ifdef LDC_GEMM_DIAG_NODMA
     if (chunk >= 0) return;
 #endif
@@ -172,10 +180,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
   i32x4v ah0[RT], al0[RT], ah1[RT], al1[RT];      // A fragments of the current / next k-step
 
 #define LDC_SB __builtin_amdgcn_sched_barrier(0)
-#define LDC_RD_W(WH, WL, SBH, SBL, CT)             \
-  {                                                \
-    LDC_DS_READ(WH, SBH, (CT) * (16 * ROW_B));     \
-    LDC_DS_READ(WL, SBL, (CT) * (16 * ROW_B));     \
+  // W fragments of column tile CT in ring stage ST: one base register per chunk kind, everything else an immediate
+#define LDC_RD_W(WH, WL, ST, CT)                                 \
+  {                                                              \
+    LDC_DS_READ(WH, w_hi, (ST) * WB + (CT) * (16 * ROW_B));      \
+    LDC_DS_READ(WL, w_lo, (ST) * WB + (CT) * (16 * ROW_B));      \
   }
   // A fragments of tap (KY, KX) from the halo buffer at LDS offset AB
 #define LDC_RD_A(AH, AL, KY, KX, AB)                                    \
@@ -216,97 +225,103 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #define LDC_WAIT(X, Y)                                     \
   asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(X), "+v"(Y)); \
   LDC_SB;
-  // one k-step kt = (chunk ch, tap tp): (AH, AL) current A fragments, (AHN, ALN) receive those of k-step kt + 1 = (chn, kyn, kxn).
+  // One k-step = tap TAP (a literal) of chunk ch: (AH, AL) current A fragments, (AHN, ALN) receive those of the next k-step.  Nine k-steps
+  // per chunk and a three-stage weight ring: tap t always sits in stage t % 3, so every weight fragment address is base + immediate.
   // DMAs: before the barrier the second weight piece of k-step kt + 2; behind it the first of kt + 3 (into this k-step's stage, free
-  // once every wave is past the barrier) and halo piece tp of chunk ch + 1 - whose buffer was last read for the fragments of k-step
+  // once every wave is past the barrier) and halo piece TAP of chunk ch + 1 - whose buffer was last read for the fragments of k-step
   // (ch - 1, tap 8), waited for before the barrier one k-step ago.  vmcnt(3) at the barrier leaves exactly those three in flight.
-#define LDC_KSTEP(AH, AL, AHN, ALN)                                                                                  \
+#define LDC_KSTEP(TAP, AH, AL, AHN, ALN)                                                                             \
   {                                                                                                                  \
-    const int st1 = st == NSTAGE - 1 ? 0 : st + 1;                                                                   \
-    const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;                                                                 \
-    const unsigned sb1 = st1 * WB;                                                                                   \
-    const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                             \
-    if constexpr (RT == 2) {                                                                                         \
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
-    } else {                                                                                                         \
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                         \
-    }                                                                                                                \
-    LDC_SB;                                                                                                          \
+    constexpr int st_ = (TAP) % 3, st1_ = ((TAP) + 1) % 3, st2_ = ((TAP) + 2) % 3;                                   \
+    constexpr int tn_ = ((TAP) + 1) % TAPS, cn_ = ((TAP) + 1) / TAPS;                                                \
     LDC_CT(0, wh0, wl0, AH, AL)                                                                                      \
-    LDC_RD_W(wh0, wl0, wch, wcl, 4)                                                                                  \
-    issue_w(kt + 2, st2, 1);                                                                                         \
+    LDC_RD_W(wh0, wl0, st_, 4)                                                                                       \
+    issue_w(ch + ((TAP) + 2) / TAPS, ((TAP) + 2) % TAPS, st2_, 1);                                                   \
     LDC_WAIT(wh1, wl1)                                                                                               \
     LDC_CT(1, wh1, wl1, AH, AL)                                                                                      \
-    LDC_RD_W(wh1, wl1, wch, wcl, 5)                                                                                  \
+    LDC_RD_W(wh1, wl1, st_, 5)                                                                                       \
     LDC_WAIT(wh2, wl2)                                                                                               \
     LDC_CT(2, wh2, wl2, AH, AL)                                                                                      \
-    LDC_RD_W(wh2, wl2, wch, wcl, 6)                                                                                  \
+    LDC_RD_W(wh2, wl2, st_, 6)                                                                                       \
     LDC_WAIT(wh3, wl3)                                                                                               \
     LDC_CT(3, wh3, wl3, AH, AL)                                                                                      \
-    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                                  \
+    LDC_RD_W(wh3, wl3, st_, 7)                                                                                       \
     LDC_WAIT(wh0, wl0)                                                                                               \
     LDC_CT(4, wh0, wl0, AH, AL)                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));         \
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                                 \
     __builtin_amdgcn_s_barrier();                                                                                    \
     LDC_SB;                                                                                                          \
-    /* next k-step's coordinates (scalar) */                                                                         \
-    const bool wrap_ = tp + 1 == TAPS;                                                                               \
-    const int tpn = wrap_ ? 0 : tp + 1, chn = wrap_ ? ch + 1 : ch;                                                   \
-    const int kyn = tpn >= 6 ? 2 : (tpn >= 3 ? 1 : 0), kxn = tpn - 3 * kyn;                                          \
-    LDC_RD_A(AHN, ALN, kyn, kxn, abuf0 + (chn & 1) * abuf_b)                                                         \
-    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                                  \
-    issue_w(kt + 3, st, 0);                                                                                          \
+    LDC_RD_A(AHN, ALN, tn_ / 3, tn_ % 3, abuf0 + ((ch + cn_) & 1) * abuf_b)                                          \
+    LDC_RD_W(wh0, wl0, st1_, 0)                                                                                      \
+    issue_w(ch + ((TAP) + 3) / TAPS, ((TAP) + 3) % TAPS, st_, 0);                                                    \
     LDC_SB;                                                                                                          \
     LDC_CT(5, wh1, wl1, AH, AL)                                                                                      \
-    LDC_RD_W(wh1, wl1, wnh, wnl, 1)                                                                                  \
-    issue_a(ch + 1, tp);                                                                                             \
+    LDC_RD_W(wh1, wl1, st1_, 1)                                                                                      \
+    issue_a(ch + 1, (TAP));                                                                                          \
     LDC_SB;                                                                                                          \
     LDC_CT(6, wh2, wl2, AH, AL)                                                                                      \
-    LDC_RD_W(wh2, wl2, wnh, wnl, 2)                                                                                  \
+    LDC_RD_W(wh2, wl2, st1_, 2)                                                                                      \
     LDC_SB;                                                                                                          \
     LDC_CT(7, wh3, wl3, AH, AL)                                                                                      \
-    LDC_RD_W(wh3, wl3, wnh, wnl, 3)                                                                                  \
+    LDC_RD_W(wh3, wl3, st1_, 3)                                                                                      \
     LDC_SB;                                                                                                          \
-    st = st1;                                                                                                        \
-    sb = sb1;                                                                                                        \
-    tp = tpn;                                                                                                        \
-    ch = chn;                                                                                                        \
   }
+  // the k-step's opening wait: the A fragments it consumes and the first weight column tile have landed
+#define LDC_OPEN(AH, AL)                                                                                             \
+  if constexpr (RT == 2) {                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(AH[1]), "+v"(AL[1]), "+v"(wh0), "+v"(wl0)); \
+  } else {                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0));                           \
+  }                                                                                                                  \
+  LDC_SB;
 
-  // prologue: the whole halo of chunk 0, the weights of k-steps 0 and 1; then (behind the barrier) the post-barrier DMAs of "k-step -1"
-  constexpr int MAXSLOT = 7;  // pieces per wave and chunk: slot t is issued in tap t and has landed by the barrier of tap t + 2 <= 8
+  // prologue: the whole halo of chunk 0, the weights of taps 0 and 1; then (behind the barrier) the post-barrier DMAs of "k-step -1"
 #pragma unroll
   for (int s_ = 0; s_ < MAXSLOT; ++s_) issue_a(0, s_);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) issue_w(0, 0, i);
+  for (int i = 0; i < 2; ++i) issue_w(0, 0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) issue_w(1, 1, i);
+  for (int i = 0; i < 2; ++i) issue_w(0, 1, 1, i);
   asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  LDC_RD_A(ah0, al0, 0, 0, abuf0)
-  LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
-  LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
-  LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
-  LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
-  issue_w(2, 2, 0);
+  LDC_RD_A(ah1, al1, 0, 0, abuf0)  // tap 0 finds its fragments in set 1, where tap 8 of the previous chunk leaves them
+  LDC_RD_W(wh0, wl0, 0, 0)
+  LDC_RD_W(wh1, wl1, 0, 1)
+  LDC_RD_W(wh2, wl2, 0, 2)
+  LDC_RD_W(wh3, wl3, 0, 3)
+  issue_w(0, 2, 2, 0);
   issue_a(a.n_chunks, 0);  // (a dump piece: keeps the barrier's vmcnt(3) exact in k-step 0)
   LDC_SB;
 
   // the loop in two copies, with and without MFMAs (a wave whose rows all lie outside the image): left to the compiler's loop unswitching the
-  // branch stayed inside the k-step and every join copied the accumulator file (336 v_mov per two k-steps, 206 VGPRs at 128 rows)
+  // branch stayed inside the k-step and every join copied the accumulator file
   auto main_loop = [&](auto wr_) {
     constexpr bool WR = decltype(wr_)::value;
-    unsigned sb = 0;
-    int st = 0, tp = 0, ch = 0;
-    int kt = 0;
-    for (; kt + 1 < n_k; ++kt) {  // pairs of k-steps (the A fragment sets alternate); n_k = 9 chunks is odd for an odd chunk count
-      LDC_KSTEP(ah0, al0, ah1, al1)
-      ++kt;
-      LDC_KSTEP(ah1, al1, ah0, al0)
-    }
-    if (kt < n_k) {
-      LDC_KSTEP(ah0, al0, ah1, al1)
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+      LDC_OPEN(ah1, al1)
+#pragma unroll
+      for (int rt_ = 0; rt_ < RT; ++rt_) {  // nine taps alternate between the two fragment sets: an odd count, so one copy per chunk
+        ah0[rt_] = ah1[rt_];
+        al0[rt_] = al1[rt_];
+      }
+      LDC_KSTEP(0, ah0, al0, ah1, al1)
+      LDC_OPEN(ah1, al1)
+      LDC_KSTEP(1, ah1, al1, ah0, al0)
+      LDC_OPEN(ah0, al0)
+      LDC_KSTEP(2, ah0, al0, ah1, al1)
+      LDC_OPEN(ah1, al1)
+      LDC_KSTEP(3, ah1, al1, ah0, al0)
+      LDC_OPEN(ah0, al0)
+      LDC_KSTEP(4, ah0, al0, ah1, al1)
+      LDC_OPEN(ah1, al1)
+      LDC_KSTEP(5, ah1, al1, ah0, al0)
+      LDC_OPEN(ah0, al0)
+      LDC_KSTEP(6, ah0, al0, ah1, al1)
+      LDC_OPEN(ah1, al1)
+      LDC_KSTEP(7, ah1, al1, ah0, al0)
+      LDC_OPEN(ah0, al0)
+      LDC_KSTEP(8, ah0, al0, ah1, al1)
     }
   };
   if (wave_rows) main_loop(std::true_type{});
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(ah0[rt]), "+v"(al0[rt]), "+v"(ah1[rt]), "+v"(al1[rt]));
+#undef LDC_OPEN
 #undef LDC_KSTEP
 #undef LDC_WAIT
 #undef LDC_CT
