@@ -125,6 +125,111 @@ def model_flops_per_forward(cfg, R, T_in=1, hw=450, split=False):
     return g + cg, a + ca
 
 
+def gpu_state(dev_index):
+    """Clock / power / temperature of this rank's GPU from sysfs (hwmon of the device's PCI function; readable as an ordinary user):
+    sampled right before and right after the timed region so that two runs whose `value` differs can be told apart by what the
+    chip was doing (DVFS: MI355X_MICROARCH.md, 'DVFS give-back' - devices differ by up to 12 % on MFMA-dense loops).  The read
+    happens outside the timed region; a missing file leaves its field out."""
+    import glob
+
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        out["pci_bus_id"] = bdf
+        out["name"] = pr.name
+        out["gcn_arch"] = getattr(pr, "gcnArchName", None)
+        out["uuid"] = str(getattr(pr, "uuid", ""))
+        base = f"/sys/bus/pci/devices/{bdf}"
+
+        def rd(path):
+            try:
+                with open(path) as f:
+                    return f.read().strip()
+            except OSError:
+                return None
+
+        for hw in glob.glob(base + "/hwmon/hwmon*"):
+            for key, fn, scale in (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_input", 1e-6),
+                                   ("power_w", "power1_average", 1e-6), ("power_cap_w", "power1_cap", 1e-6), ("temp_junction_c", "temp2_input", 1e-3),
+                                   ("temp_edge_c", "temp1_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3)):
+                v = rd(f"{hw}/{fn}")
+                if v is not None and key not in out:
+                    try:
+                        out[key] = round(float(v) * scale, 1)
+                    except ValueError:
+                        pass
+        lv = rd(base + "/pp_dpm_sclk")
+        if lv:
+            cur = [ln for ln in lv.splitlines() if ln.strip().endswith("*")]
+            out["pp_dpm_sclk"] = cur[0].strip() if cur else None
+    except Exception as e:  # diagnostics only: never fail the bench over it
+        out["error"] = repr(e)
+    return out
+
+
+class GpuStateSampler:
+    """Background thread: `gpu_state` every `period` seconds while the timed region runs (a sysfs read on the host; the launching thread
+    is asleep inside graph replays / the final synchronise, so the GPU never waits for it).  `summary()`: min / median / max of clock and
+    power, max temperature, number of samples."""
+
+    def __init__(self, dev_index, period=0.05):
+        import threading
+
+        self.dev_index, self.period, self.samples = dev_index, period, []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(gpu_state(self.dev_index))
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        return self.summary()
+
+    def summary(self):
+        import statistics
+
+        out = {"samples": len(self.samples)}
+        for key in ("sclk_mhz", "power_w"):
+            v = [x[key] for x in self.samples if key in x]
+            if v:
+                out[key] = dict(min=min(v), median=round(statistics.median(v), 1), max=max(v))
+        for key in ("temp_junction_c", "temp_mem_c", "temp_edge_c"):
+            v = [x[key] for x in self.samples if key in x]
+            if v:
+                out[key + "_max"] = max(v)
+        return out
+
+
+def host_description():
+    """CPU model string, sockets x physical cores, threads (lscpu): printed with cpu_baseline."""
+    import subprocess
+
+    d = {"threads_online": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for ln in txt.splitlines():
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                kv[k.strip()] = v.strip()
+        d["model"] = kv.get("Model name")
+        sockets, cps = int(kv.get("Socket(s)", "0") or 0), int(kv.get("Core(s) per socket", "0") or 0)
+        d["sockets"], d["physical_cores"] = sockets, sockets * cps
+        d["threads_per_core"] = int(kv.get("Thread(s) per core", "0") or 0)
+    except Exception as e:
+        d["error"] = repr(e)
+    return d
+
+
 class KernelTimer:
     """HIP-event bracket around every launch of selected C-ABI kernels on torch's current stream
     (the stream the kernels are launched on)."""
@@ -148,9 +253,9 @@ class KernelTimer:
             # K % 32 == 0 -> the 16x16x32 kernel; fp32 activations and K % 32 == 0 -> the 32x32x16 LDS-DMA kernel
             if not split_bf16:  # exact fp32: the ring kernel (gemm_bf16x3_v3.hip, TERMS = 0) when K % 32 == 0, else the register-staged one
                 ring = all(p[0].d.K % 32 == 0 and p[0].d.ldw == p[0].d.K for p in problems) and os.environ.get("LDC_F32_RING", "1") != "0"
-                name = "gemm_bf16x3_v3_kernel<fp32 rows>" if ring else "gemm_streamk_kernel"
+                name = "gemm_bf16x3_v3_kernel<128, 0, false>" if ring else "gemm_streamk_kernel"
             elif all(p[0].d.K % 32 == 0 for p in problems):
-                name = "gemm_bf16x3_v3_kernel" if all(p[0].d.flags & 1 for p in problems) else "gemm_bf16x3_dma_kernel"
+                name = timer.v3_variant(problems) if all(p[0].d.flags & 1 for p in problems) else "gemm_bf16x3_dma_kernel"
             else:
                 name = "gemm_streamk_bf16x3_kernel"
             timer.records.setdefault(name, []).append((s, e, work))
@@ -175,7 +280,7 @@ class KernelTimer:
             timer._orig["gemm_grouped_qkv"](problems, epilogues)
             e.record()
             work = sum(2.0 * p[0].d.M * p[0].d.N * p[0].d.K * p[0].d.batch for p in problems)
-            timer.records.setdefault("gemm_bf16x3_v3_kernel", []).append((s, e, work))
+            timer.records.setdefault(timer.v3_variant(problems), []).append((s, e, work))
 
         def attn_fwd_split(Q, K, V, O, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -186,6 +291,14 @@ class KernelTimer:
 
         hip.gemm, hip.attn_fwd, hip.gemm_grouped = gemm, attn_fwd, gemm_grouped
         hip.gemm_grouped_qkv, hip.attn_fwd_split = gemm_grouped_qkv, attn_fwd_split
+
+    @staticmethod
+    def v3_variant(problems):
+        """the template instance gemm_v3_dispatch (csrc/gemm_bf16x3_v3.hip) launches for a grouped call - the kernel name rocprofv3 prints:
+        128-row tiles while 256-row tiles would number fewer than 400, TERMS = 1 in the single-term bf16 mode"""
+        t256 = sum(p[0].d.batch * -(-p[0].d.M // 256) * -(-p[0].d.N // 128) for p in problems)
+        terms = 1 if (problems[0][0].d.flags & 4) else 3
+        return f"gemm_bf16x3_v3_kernel<{128 if t256 < 400 else 256}, {terms}, false>"
 
     def uninstall(self):
         self._hip.gemm, self._hip.attn_fwd, self._hip.gemm_grouped = self._orig["gemm"], self._orig["attn_fwd"], self._orig["gemm_grouped"]
@@ -215,13 +328,14 @@ def cpu_baseline(cfg_name, R, n_forwards):
     x = torch.randn(1, 84, R, 15, 30, generator=g)
     known = 0.5 * torch.randn(1, 84, 1, 15, 30, generator=torch.Generator().manual_seed(2))
     ts = torch.tensor([2018010100])
+    times = []
     with torch.no_grad():
         m(x, torch.tensor([0.5]), known, time_elapsed=ts)  # warm-up (page-in, thread pool)
-        t0 = time.perf_counter()
         for i in range(n_forwards):
-            m(x, torch.tensor([0.5 - 0.1 * i]), known, time_elapsed=ts)
-        dt = (time.perf_counter() - t0) / n_forwards
-    return dt
+            t0 = time.perf_counter()
+            m(x, torch.tensor([0.5 - 0.05 * i]), known, time_elapsed=ts)
+            times.append(time.perf_counter() - t0)
+    return times
 
 
 def self_launch(n):
@@ -260,10 +374,14 @@ def main():
                     "reference's scheduler loop with its EDM DPM-Solver++(2M) scheduler, N forwards; ddim = the same loop with ladcast_amd.schedulers.DDIMScheduler "
                     "(diffusers defaults, eta = 0), N forwards - BASELINE's literal '20-step DDIM'")
     ap.add_argument("--dump-output", default=None, help="rank 0 saves the (gathered) result tensor of the LAST timed step to this .pt file (tests)")
-    ap.add_argument("--cpu-forwards", type=int, default=3, help="oracle forwards timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-forwards", type=int, default=5, help="oracle forwards timed for cpu_baseline after one warm-up forward; the MEDIAN is reported (0 = skip)")
+    ap.add_argument("--strong-cfg3", action="store_true", help="also run BASELINE configs[2] (a fixed ensemble of 16 members, 40 lead steps = 10 chained chunks per member) "
+                    "as an extra leg and print it as `strong_cfg3` - always on with N > 1, where it is north_star's strong-scaling point; ~17 s per call at N = 1")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; nccl (= RCCL over xGMI) is the real one, "
                     "gloo only lets the N > 1 code path be dry-run on a box with fewer GPUs than ranks")
+    ap.add_argument("--no-strong-cfg3", action="store_true", help="skip the strong_cfg3 leg that N > 1 runs carry by default (tests of other fields)")
+    ap.add_argument("--collective-timeout", type=float, default=300.0, help="seconds before a rendezvous / collective is declared dead (the rank then exits non-zero)")
     ap.add_argument("--share-gpus", action="store_true", help="dry-run aid: map ranks onto the available GPUs modulo their count")
     ap.add_argument("--host-outputs", action="store_true", help="A/B aid: return every step's latents on the host as the reference's roll_out_serial does (one device "
                     "-> host copy + synchronise per step) instead of leaving them in HBM")
@@ -299,11 +417,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        from datetime import timedelta
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
+        # never a hang: rendezvous and every collective carry a timeout (the RCCL watchdog aborts the rank when one expires), and a failure
+        # to bring the communicator up ends the rank with the library's own error text and a non-zero exit code
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=args.collective_timeout))  # RCCL over xGMI
+            else:
+                dist.init_process_group("gloo", timeout=timedelta(seconds=args.collective_timeout))
+            probe = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(probe)  # the first collective builds the communicator: fail here, with a message, rather than inside the timed region
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py rank {rank}: cannot bring up the {args.backend} process group over {world} ranks: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     import ladcast_amd.hip as hip
     from ladcast_amd.models import LaDCastTransformer3DModel
@@ -389,7 +519,9 @@ def main():
     for _ in range(args.warmup):
         step()
     timer = KernelTimer()
+    state_before = gpu_state(dev_index)
     fence()
+    sampler = GpuStateSampler(dev_index).start()
     t0 = time.perf_counter()
     marks, evs = [], [torch.cuda.Event(enable_timing=True)]
     evs[0].record()
@@ -402,6 +534,8 @@ def main():
         evs[-1].record()  # device outputs: the host runs ahead; the step boundaries are read from the stream afterwards
     fence()
     elapsed = time.perf_counter() - t0
+    gpu_during = sampler.stop()
+    state_after = gpu_state(dev_index)
     if out_dev is None:
         step_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]  # diagnostic only (rank 0's view)
     else:
@@ -443,6 +577,63 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         sustained = dict(steps=n_sus, seconds=round(dt, 3), ms_per_step=round(1e3 * dt / n_sus, 3), value=round(total_members * lead * n_sus / dt, 4))
+    # BASELINE configs[2] as an extra leg (not `value`): a FIXED ensemble of 16 members x 40 lead steps (10 chained chunks per member) dealt to
+    # the ranks - north_star's strong-scaling workload (">= 6x at 8 GPUs vs 1").  Always with N > 1, so that the driver's SCALE record carries
+    # it; at N = 1 behind --strong-cfg3 (17 s per call).  One call is timed, after a one-chunk call that captures this rank's chunk graph.
+    strong_cfg3 = None
+    if (world > 1 or args.strong_cfg3) and not args.decode and not args.no_strong_cfg3:
+        E3, L3 = 16, 40
+        ids3 = shard_members(E3, rank, world)
+
+        def cfg3_call(lead_steps):
+            return roll_out_serial(
+                None, [datetime(2018, 1, 1, 0)], pipe, ensemble_size=len(ids3), num_inference_steps=args.solver_steps, return_seq_len=R,
+                latent_transform_args=targs, total_lead_time_hour=6 * lead_steps, sampler_type=sampler_type, return_latent=True,
+                known_latents_override=ic, member_ids=ids3, output_device=out_dev)
+
+        cfg3_call(R)  # set-up: weight plan + chunk graph for this rank's batch size
+        fence()
+        e3a, e3b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t3 = time.perf_counter()
+        e3a.record()
+        out3 = cfg3_call(L3)
+        e3b.record()
+        if world > 1:
+            out3 = gather_members(out3.to(dev) if args.backend == "nccl" else out3.to("cpu"), E3, member_dim=1)
+        fence()
+        dt3 = time.perf_counter() - t3
+        roll3 = e3a.elapsed_time(e3b)
+        per_rank3 = None
+        if world > 1:
+            mine3 = torch.tensor([dt3, roll3, float(len(ids3))], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            all3 = [torch.empty_like(mine3) for _ in range(world)]
+            dist.all_gather(all3, mine3)
+            all3 = torch.stack(all3).cpu()
+            dt3 = all3[:, 0].max().item()
+            per_rank3 = dict(seconds=[round(v, 3) for v in all3[:, 0].tolist()], rollout_ms=[round(v, 1) for v in all3[:, 1].tolist()],
+                             members=[int(v) for v in all3[:, 2].tolist()])
+        ref3 = None
+        try:
+            import glob as _glob
+
+            cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cfg3_whole_job_16members_one_gpu.json")))
+            if cands:
+                d3 = json.loads(open(cands[-1]).read().strip().splitlines()[-1])
+                v3 = d3["strong_cfg3"]["value"] if d3.get("strong_cfg3") else d3["value"]
+                ref3 = dict(value=v3, source=os.path.relpath(cands[-1], ROOT) + " (committed; the same workload on ONE MI355X)")
+        except Exception:
+            ref3 = None
+        v3now = E3 * L3 / dt3
+        strong_cfg3 = dict(
+            workload=f"BASELINE configs[2]: {args.model} AR, a FIXED ensemble of {E3} members over {world} GPU(s), {args.solver_steps} solver steps ({args.sampler}), {L3} lead steps = "
+                     f"{-(-L3 // R)} chained chunks per member, one RCCL gather of the (16, 84, 41, 15, 30) latents at the end",
+            value=round(v3now, 4), unit="member-steps/s", steps=1, ms_per_step=round(1e3 * dt3, 1), scaling="strong",
+            members_on_rank=[len(shard_members(E3, r, world)) for r in range(world)], per_rank=per_rank3, n1_reference=ref3,
+            # (only where the committed N = 1 figure is the same workload: 375M, edm, 20 solver steps, bf16x3)
+            speedup_vs_n1=None if (ref3 is None or world == 1 or not (args.solver_steps == 20 and args.sampler == "edm" and args.model == "375M" and args.precision == "bf16x3"))
+            else round(v3now / ref3["value"], 3),
+            expected=("members are independent and a rank's members run as one batch: at N = 8 two members per rank (35.8 member-steps/s per GPU measured at that batch, "
+                      "profiles/r04_x_bench_cfg3_share_2members_40leadsteps.json) -> ~286 against 37.5 at N = 1, i.e. ~7.6x; the gather moves 12.4 MB per rank"))
     other_sampler, ddim_sampler, host_outputs = None, None, None
     if not args.no_kernel_timers and rank == 0 and world == 1 and not args.decode:
         # Secondary numbers (not `value`): the same workload with the other samplers - BASELINE's metric says "20-step DDIM"; `edm` (the
@@ -497,26 +688,53 @@ def main():
         model.enable_hip_graph(not args.no_graph)
         return ms, timer.summary()
 
-    instrumented_ms, ks = None, {}
+    def bracket_overhead():
+        """what a HIP-event pair adds around one kernel on a busy stream: the bracket around a one-element kernel behind a long one, median of 20
+        (event record -> dispatch -> completion -> event record; the kernel's own time is below a microsecond)"""
+        import statistics
+
+        big, tiny, vals = torch.empty(64 << 20, device=dev), torch.empty(1, device=dev), []
+        for _ in range(20):
+            big.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.scale_f32(tiny, 1.0, tiny)
+            e1.record()
+            torch.cuda.synchronize()
+            vals.append(1e3 * e0.elapsed_time(e1))
+        return round(statistics.median(vals), 2)
+
+    instrumented_ms, ks, bracket_us = None, {}, None
     if not args.no_kernel_timers and rank == 0:
         instrumented_ms, ks = instrumented_step()
+        try:
+            bracket_us = bracket_overhead()
+        except Exception:
+            bracket_us = None
     # The same workload in the exact-fp32 mode (fp32-input MFMA everywhere), beside the headline: value, ms per step and the
     # dominant GEMM kernel against the 157.3 TFLOP/s fp32 matrix peak.  Single-GPU runs only (no collective inside).
     fp32_mode = None
     if args.precision != "fp32" and not args.no_kernel_timers and world == 1 and not args.decode:
         model.set_gemm_precision("fp32")
         step_local()  # set-up: weight plan + graph capture of the fp32 chunk
+        n32, w32 = max(10, args.steps), max(2, args.warmup)  # the headline's discipline: warm-up steps, then >= 10 timed steps with their own step_ms
+        for _ in range(w32):
+            step_local()
         torch.cuda.synchronize()
-        n32 = 3
+        ev32 = [torch.cuda.Event(enable_timing=True)]
+        ev32[0].record()
         t1 = time.perf_counter()
         for _ in range(n32):
             step_local()
+            ev32.append(torch.cuda.Event(enable_timing=True))
+            ev32[-1].record()
         torch.cuda.synchronize()
         dt32 = time.perf_counter() - t1
         _, ks32 = instrumented_step()
         g32 = [n for n in ks32 if n.startswith("gemm_")]
         d32 = max(g32, key=lambda n: ks32[n]["total_ms"]) if g32 else None
-        fp32_mode = dict(value=round(m * lead * n32 / dt32, 4), unit="member-steps/s", steps=n32, ms_per_step=round(1e3 * dt32 / n32, 3), dtype="f32")
+        fp32_mode = dict(value=round(m * lead * n32 / dt32, 4), unit="member-steps/s", steps=n32, warmup=w32, ms_per_step=round(1e3 * dt32 / n32, 3), dtype="f32",
+                         step_ms=[round(a_.elapsed_time(b_), 2) for a_, b_ in zip(ev32[:-1], ev32[1:])])
         if d32:
             k = ks32[d32]
             fp32_mode["roofline"] = dict(bound="mfma", kernel=d32, achieved=round(k["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -529,6 +747,12 @@ def main():
 
     chunks = -(-lead // R)
     fwd_per_chunk = (2 * args.solver_steps - 1) if args.sampler == "edm" else args.solver_steps
+    me = gpu_state(dev_index)
+    rank_devices = [dict(rank=rank, device_index=dev_index, name=me.get("name"), pci_bus_id=me.get("pci_bus_id"), gcn_arch=me.get("gcn_arch"))]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
     if rank == 0:
         gflops, aflops = model_flops_per_forward(cfg, R)
         (mg, ma), (cg, ca) = model_flops_per_forward(cfg, R, split=True)
@@ -553,7 +777,7 @@ def main():
                     from ladcast_amd.build_id import csrc_sha16
 
                     doc = json.load(open(pmc))
-                    ent = doc.get(kname, {})
+                    ent = doc.get(kname) or doc.get(kname.split("<")[0], {})
                     traffic = ent.get("hbm_bytes_per_launch")
                     if traffic is not None:
                         built = (doc.get("_build") or {}).get("csrc_sha16")
@@ -562,16 +786,39 @@ def main():
                                           f"sources {built}; this run's sources are {csrc_sha16()}; not re-measured in this run")
                 except Exception:
                     traffic = None
+            # every instance of the dominant kernel template on its own row: launches, HIP-event average, exact flops per launch, and - when the
+            # committed rocprofv3 summary of the headline leg holds that instance - its AverageNs there and the rate that follows from it
+            import csv
             import glob
 
-            stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench_cfg2.csv")))
-            roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s",
-                        kernel_stats_source=(os.path.relpath(stats[-1], ROOT) + ": rocprofv3 --kernel-trace --stats summary of this command (committed; the "
-                                             "kernel's AverageNs there x `flops_per_launch` reproduces `achieved`)") if stats else None,
+            stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench_cfg2*.csv")))
+            prof_avg = {}
+            if stats:
+                try:
+                    for row in csv.DictReader(open(stats[-1])):
+                        nm = row.get("Name", "").replace("(anonymous namespace)::", "").replace("void ", "")
+                        prof_avg[nm.split("(")[0].strip()] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]))
+                except Exception:
+                    prof_avg = {}
+            variants = []
+            for vn in sorted(n for n in ks if n.startswith(dom.split("<")[0])):
+                kv = ks[vn]
+                rowv = dict(kernel=vn, launches=kv["launches"], avg_launch_us=round(kv["avg_us"], 2), flops_per_launch=kv["work_per_launch"],
+                            achieved=round(kv["tflops"], 2), frac=round(kv["tflops"] / peak, 4))
+                if vn in prof_avg:
+                    rowv["rocprof_avg_us"] = round(prof_avg[vn][0], 2)
+                    rowv["achieved_rocprof"] = round(kv["work_per_launch"] / (prof_avg[vn][0] * 1e-6) / 1e12, 2)
+                variants.append(rowv)
+            roof = dict(bound="mfma", kernel=kname, achieved=round(k["tflops"], 2), peak=peak, unit="TFLOP/s", variants=variants,
+                        event_bracket_overhead_us=bracket_us,
+                        kernel_stats_source=(os.path.relpath(stats[-1], ROOT) + ": rocprofv3 --kernel-trace --stats summary of the headline leg alone (bench.py "
+                                             "--steps K --warmup W --no-kernel-timers --cpu-forwards 0 --sustained-seconds 0; committed).  Per template instance, "
+                                             "`flops_per_launch` / its AverageNs there = `achieved_rocprof` in `variants`; `achieved` is the live HIP-event figure, which "
+                                             "contains `event_bracket_overhead_us` per launch and therefore reads lower") if stats else None,
                         frac=round(k["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale, launches=k["launches"],
                         avg_launch_us=round(k["avg_us"], 2),
                         flops_per_launch=k["work_per_launch"],
-                        note="one launch = one grouped stream-K GEMM call; achieved = ALGORITHMIC 2*M*N*K summed over the call's problems / "
+                        note="one launch = one grouped stream-K GEMM call of the dominant template instance (`kernel`); achieved = ALGORITHMIC 2*M*N*K summed over the call's problems / "
                              "HIP-event time of the call, averaged over one instrumented step run right after the timed region (see instrumented_ms_per_step)."
                              + (" Split-bf16: the kernel issues 3 bf16 MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi), so its "
                                 "ceiling against this peak is 1/3; frac_of_attainable = achieved / (peak/3)." if split else ""))
@@ -603,6 +850,10 @@ def main():
                             "timed region ends with barrier + synchronise (two alternating instances of the captured chunk); --host-outputs copies every step's result to the host as the reference's "
                             "roll_out_serial does") if out_dev is not None else "copied to the host after every step (as the reference)",
             },
+            "gpu": {"device_index": dev_index, "before": state_before, "during_timed_region": gpu_during, "after": state_after,
+                    "note": "rank 0's GPU from sysfs (hwmon of its PCI function): one reading before the timed region, one every 50 ms during it (background thread), one "
+                            "after; two runs whose `value` differs on different boxes can be compared by the clock / power the chip held"},
+            "strong_cfg3": strong_cfg3,
             "instrumented_ms_per_step": None if instrumented_ms is None else round(instrumented_ms, 3),
             "other_sampler": other_sampler,
             "ddim_sampler": ddim_sampler,
@@ -611,7 +862,7 @@ def main():
             "fp32_mode": fp32_mode,
             # the like-for-like-precision reader's roofline (exact fp32 everywhere), at the top level beside the split one
             "roofline_fp32": None if not fp32_mode else fp32_mode.get("roofline"),
-            "ranks": {"world_size": world if dist is None else dist.get_world_size(), "backend": "none" if dist is None else args.backend,
+            "ranks": {"world_size": world if dist is None else dist.get_world_size(), "backend": "none" if dist is None else args.backend, "devices": rank_devices,
                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and args.backend == "nccl") else None,
                       "visible_gpus": torch.cuda.device_count(), "per_rank": rank_stats},
             "model_tflops": round(total_members * chunks * flops_per_chunk * args.steps / elapsed / 1e12, 2),
@@ -627,13 +878,17 @@ def main():
                 if an != "attn_fwd_f32_kernel" and split:
                     line["attention_kernel"]["frac_of_attainable"] = round(3 * k["tflops"] / apeak, 4)
         if args.cpu_forwards > 0 and world == 1:
+            import statistics
+
             cores = torch.get_num_threads()
-            dt = cpu_baseline(args.model, R, args.cpu_forwards)
+            times = cpu_baseline(args.model, R, args.cpu_forwards)
+            dt = statistics.median(times)
             cpu_value = lead / (chunks * fwd_per_chunk * dt)
             line["cpu_baseline"] = dict(
-                value=round(cpu_value, 5), unit="member-steps/s", cores=cores, kind="port",
-                sample=f"{args.cpu_forwards} forwards of the same {args.model} model (1 member, R={R}) by the PyTorch CPU oracle, {dt:.2f} s each, "
-                       f"scaled to {chunks * fwd_per_chunk} forwards per step",
+                value=round(cpu_value, 5), unit="member-steps/s", cores=cores, kind="port", host=host_description(),
+                forward_seconds=[round(t, 3) for t in times],
+                sample=f"{args.cpu_forwards} forwards (after one warm-up forward) of the same {args.model} model (1 member, R={R}) by the PyTorch CPU oracle on {cores} torch "
+                       f"threads, median {dt:.2f} s per forward, scaled to {chunks * fwd_per_chunk} forwards per step",
             )
             line["gpu_over_cpu"] = round(value / cpu_value, 1)
         else:

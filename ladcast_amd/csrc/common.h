@@ -115,7 +115,8 @@ __device__ __forceinline__ int ldc_sphere_src_pixel(int h, int w, int ky, int kx
 
 // conv_halo.hip: the halo-staged 3 x 3 conv (LDC_ERR_UNSUPPORTED: shape not served - run the gathered conv of gemm_bf16x3_v3.hip)
 int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W, int cin,
-                           int ldx, int cout, int ldy, int ldr, int act, int in_fmt, int out_fmt, const void* zero16, void* stream);
+                           int ldx, int cout, int ldy, int ldr, int act, int in_fmt, int out_fmt, void* workspace, long long workspace_bytes,
+                           void* stream);
 
 // Measurement switches (tile height / unit ranges / tile order / kernel choice forced from the environment) exist only in the A/B build
 // (`make ab` -> libladcast_hip_ab.so, loaded by tools/ through LDC_LIB_PATH); the shipped library reads no environment variable.

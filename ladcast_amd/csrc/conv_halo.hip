@@ -36,7 +36,10 @@ struct HaloArgs {
   int hp_magic;              // j / HP == (j * hp_magic) >> 16 for j < 8 NP (checked by the host)
   int tiles_x, tiles_y, tn;  // pixel tiles per frame, column panels
   int n_chunks;              // channel chunks of CPK
-  int G;                     // work items = frames * tiles_y * tiles_x * tn = grid size
+  int ksplit;                // workgroups per tile: each takes a contiguous share of the channel chunks (1 = whole tiles)
+  int G;                     // work items = frames * tiles_y * tiles_x * tn * ksplit = grid size
+  float* ws;                 // ksplit > 1: one accumulator slab (256 x 128 floats) per work item
+  unsigned* counters;        // ksplit > 1: one arrival counter per tile (zero between launches)
 };
 
 // tile row r -> output pixel row of Y (0x7fffffff: outside the image)
@@ -67,9 +70,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     const int q = G >> 3, r = G & 7, xcd = bid & 7;
     g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  int bn, y0, x0, frame;
+  int bn, y0, x0, frame, c0, c1, item;
   {
-    const unsigned gu = static_cast<unsigned>(g), tn = static_cast<unsigned>(a.tn);
+    const unsigned ks = static_cast<unsigned>(a.ksplit);
+    const unsigned it_ = static_cast<unsigned>(g) / ks, piece = static_cast<unsigned>(g) - it_ * ks;
+    item = __builtin_amdgcn_readfirstlane(static_cast<int>(it_));
+    c0 = __builtin_amdgcn_readfirstlane(static_cast<int>(piece * static_cast<unsigned>(a.n_chunks) / ks));        // this workgroup's channel chunks
+    c1 = __builtin_amdgcn_readfirstlane(static_cast<int>((piece + 1) * static_cast<unsigned>(a.n_chunks) / ks));
+    const unsigned gu = it_, tn = static_cast<unsigned>(a.tn);
     unsigned t = gu / tn;
     bn = __builtin_amdgcn_readfirstlane(static_cast<int>(gu - t * tn));
     const unsigned tx_i = t % static_cast<unsigned>(a.tiles_x);
@@ -125,8 +133,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
   }
   // (tap, stage, i are literals at every call site: the main loop is unrolled over the nine taps of a chunk)
   auto issue_w = [&](int chunk_, int tap, int stage, int i) {
-    const bool live = chunk_ < a.n_chunks;
-    const int chunk = live ? chunk_ : a.n_chunks - 1;
+    const bool live = chunk_ < c1;
+    const int chunk = live ? chunk_ : c1 - 1;
     const long long koff = static_cast<long long>((tap << P.kshift) + chunk) * (BK * 4);
 #ifdef LDC_GEMM_DIAG_NODMA
     if (chunk >= 0) return;
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
   }
   auto issue_a = [&](int chunk_, int slot) {
     const int q = wave + 8 * slot;
-    const bool live = slot < MAXSLOT && chunk_ < a.n_chunks && q < a.NP;
-    const int chunk = chunk_ < a.n_chunks ? chunk_ : a.n_chunks - 1;
+    const bool live = slot < MAXSLOT && chunk_ < c1 && q < a.NP;
+    const int chunk = chunk_ < c1 ? chunk_ : c1 - 1;
     const unsigned char* src = a_row[slot < MAXSLOT ? slot : 0] + chunk * (BK * 4);
     src = chunk * CPK >= zthr ? P.zero16 : src;  // 8-column groups behind cin read zeros (their weights are zero too)
 #ifdef LDC_GEMM_DIAG_NODMA
@@ -278,27 +286,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 
   // prologue: the whole halo of chunk 0, the weights of taps 0 and 1; then (behind the barrier) the post-barrier DMAs of "k-step -1"
 #pragma unroll
-  for (int s_ = 0; s_ < MAXSLOT; ++s_) issue_a(0, s_);
+  for (int s_ = 0; s_ < MAXSLOT; ++s_) issue_a(c0, s_);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) issue_w(0, 0, 0, i);
+  for (int i = 0; i < 2; ++i) issue_w(c0, 0, 0, i);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) issue_w(0, 1, 1, i);
+  for (int i = 0; i < 2; ++i) issue_w(c0, 1, 1, i);
   asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  LDC_RD_A(ah1, al1, 0, 0, abuf0)  // tap 0 finds its fragments in set 1, where tap 8 of the previous chunk leaves them
+  LDC_RD_A(ah1, al1, 0, 0, abuf0 + (c0 & 1) * abuf_b)  // tap 0 finds its fragments in set 1, where tap 8 of the previous chunk leaves them
   LDC_RD_W(wh0, wl0, 0, 0)
   LDC_RD_W(wh1, wl1, 0, 1)
   LDC_RD_W(wh2, wl2, 0, 2)
   LDC_RD_W(wh3, wl3, 0, 3)
-  issue_w(0, 2, 2, 0);
-  issue_a(a.n_chunks, 0);  // (a dump piece: keeps the barrier's vmcnt(3) exact in k-step 0)
+  issue_w(c0, 2, 2, 0);
+  issue_a(c1, 0);  // (a dump piece: keeps the barrier's vmcnt(3) exact in k-step 0)
   LDC_SB;
 
   // the loop in two copies, with and without MFMAs (a wave whose rows all lie outside the image): left to the compiler's loop unswitching the
   // branch stayed inside the k-step and every join copied the accumulator file
   auto main_loop = [&](auto wr_) {
     constexpr bool WR = decltype(wr_)::value;
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
+    for (int ch = c0; ch < c1; ++ch) {
       LDC_OPEN(ah1, al1)
 #pragma unroll
       for (int rt_ = 0; rt_ < RT; ++rt_) {  // nine taps alternate between the two fragment sets: an odd count, so one copy per chunk
@@ -339,6 +347,46 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #undef LDC_SB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped DMAs of the last k-steps land in this wave's dump slot: before the LDS goes back
 
+  if (a.ksplit > 1) {
+    // the pieces of a tile meet through write-through slabs and ONE ticket per workgroup; the piece whose ticket is the last re-reads all
+    // slabs of the tile in piece order (bitwise reproducible whatever the arrival order) and applies the epilogue - gemm_bf16x3_v3.hip's
+    // hand-off, with the channel-chunk share as the k range
+    constexpr int SLOT_FLOATS = BM * BN;
+    const int lane_h = fresh_lane();
+    float* slot = a.ws + static_cast<long long>(g) * SLOT_FLOATS + lane_h;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store(slot + ((wave * NACC + i) * 4 + r) * 64, acc[i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned* cnt = a.counters + item;
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle (every DMA of this workgroup has landed)
+    if (wave == 0 && lane_h == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned last = (ticket == static_cast<unsigned>(a.ksplit) - 1) ? 1u : 0u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const unsigned is_last = *flag;
+    if (!is_last) return;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < a.ksplit; ++p) {
+      const float* sl = a.ws + (static_cast<long long>(item) * a.ksplit + p) * SLOT_FLOATS;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane_h];
+      }
+    }
+  }
   TileRows rows{fbase, y0, x0, a.tw_shift, a.TW - 1, H, W};
   tile_epilogue<BM, false, TileRows, false>(P, 0, 0, bn, acc, wave, lane, rows);
 }
@@ -363,7 +411,7 @@ int launch_halo(const HaloArgs& a, size_t lds, hipStream_t st) {
 // give most CUs a tile stays on the gathered kernel, which cuts along K over all of them.  (A 128-pixel tile of this kernel was slower
 // than the gathered conv on every shape - the weight stream per FLOP doubles - and is not built.)
 // Among the tile shapes the one with the fewest tiles wins, then the smallest halo.
-static bool halo_plan(int B, int H, int W, int cout, int* bm_out, int* tw_out) {
+static bool halo_plan(int B, int H, int W, int cout, int n_chunks, int* bm_out, int* tw_out, int* ksplit_out) {
   constexpr int bm = 256;
   const int tn = ldc_cdiv(cout, BN);
   int best_tw = 0, best_np = 0;
@@ -384,22 +432,39 @@ static bool halo_plan(int B, int H, int W, int cout, int* bm_out, int* tw_out) {
     }
   }
   static const char* const min_tiles = LDC_AB_GETENV("LDC_CONV_HALO_MIN_TILES");
-  if (best_tw == 0 || best_tiles < (min_tiles ? atoll(min_tiles) : 192)) return false;
+  static const char* const force_ks = LDC_AB_GETENV("LDC_CONV_HALO_KSPLIT");
+  if (best_tw == 0) return false;
+  int ks = 1;
+  if (best_tiles < (min_tiles ? atoll(min_tiles) : 192)) {
+    // too few tiles for the chip: TWO workgroups per tile, each with half of the channel chunks, summed in the launch by the last arriver
+    // (504 -> 504 at 60 x 120, one frame: 128 tiles x 2 - 102.6 -> 86.5 us against the gathered kernel, profiles/r05_f_conv_ksplit_ab.log).
+    // Three pieces already lost to the gathered kernel (two frames of 504 -> 504 at 30 x 60: 58 -> 63 us), and more would make one
+    // workgroup re-read megabytes of slabs: such launches stay on the gathered kernel, which cuts along K over all CUs.
+    ks = 0;
+    for (int k = 2; k <= 2; ++k)
+      if (best_tiles * k >= 192 && best_tiles * k <= 256 && n_chunks / k >= 2) {
+        ks = k;
+        break;
+      }
+    if (force_ks && atoi(force_ks) == 1) ks = 0;
+    if (ks == 0) return false;
+  }
   // useful share of the rounds: a launch just past a multiple of 256 tiles (257 -> two rounds) is better cut along K
-  const long long rounds = (best_tiles + 255) / 256;
-  if (static_cast<double>(best_tiles) / (256.0 * rounds) < 0.7) return false;
+  const long long items = best_tiles * ks, rounds = (items + 255) / 256;
+  if (static_cast<double>(items) / (256.0 * rounds) < 0.7) return false;
   *bm_out = bm;
   *tw_out = best_tw;
+  *ksplit_out = ks;
   return true;
 }
 
 // which kernel ldc_sphere_conv_nhwc_split runs for a shape (include/ladcast_hip.h): 1 = the halo-staged kernel, with its tile
 extern "C" int ldc_sphere_conv_plan(int B, int H, int W, int cin, int cout, int ksize, int in_fmt, int* tile_rows, int* tile_w) {
-  (void)cin;
-  int bm = 0, tw = 0;
+  int bm = 0, tw = 0, ks = 1;
+  const int n_chunks = ldc_cdiv(cin > 0 ? cin : 1, in_fmt == LDC_FMT_BF16 ? 2 * BK : BK);
   static const char* const halo_sw = LDC_AB_GETENV("LDC_CONV_HALO");
   const bool halo = ksize == 3 && (in_fmt == LDC_FMT_SPLIT || in_fmt == LDC_FMT_BF16) && B > 0 && H > 0 && W > 0 && cout > 0 &&
-                    !(halo_sw && atoi(halo_sw) == 0) && halo_plan(B, H, W, cout, &bm, &tw);
+                    !(halo_sw && atoi(halo_sw) == 0) && cin > 0 && halo_plan(B, H, W, cout, n_chunks, &bm, &tw, &ks);
   if (tile_rows) *tile_rows = halo ? bm : 0;
   if (tile_w) *tile_w = halo ? tw : 0;
   return halo ? 1 : 0;
@@ -408,15 +473,17 @@ extern "C" int ldc_sphere_conv_plan(int B, int H, int W, int cin, int cout, int 
 // Launch.  Returns LDC_ERR_UNSUPPORTED when the halo kernel does not serve the shape (the caller then runs the gathered conv of
 // gemm_bf16x3_v3.hip): exact-fp32 rows, images too small to fill tiles.
 int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, const float* R, float* Y, int B, int H, int W, int cin,
-                           int ldx, int cout, int ldy, int ldr, int act, int in_fmt, int out_fmt, const void* zero16, void* stream) {
+                           int ldx, int cout, int ldy, int ldr, int act, int in_fmt, int out_fmt, void* workspace, long long workspace_bytes,
+                           void* stream) {
   if (in_fmt != LDC_FMT_SPLIT && in_fmt != LDC_FMT_BF16) return LDC_ERR_UNSUPPORTED;
   const bool one = in_fmt == LDC_FMT_BF16;
   const int cpk = one ? 2 * BK : BK;
   const long long M = static_cast<long long>(B) * H * W;
   if (M * ldx * 4 >= (1LL << 40) || M > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   const int tn = ldc_cdiv(cout, BN);
-  int best_bm = 0, best_tw = 0;
-  if (!halo_plan(B, H, W, cout, &best_bm, &best_tw)) return LDC_ERR_UNSUPPORTED;
+  int best_bm = 0, best_tw = 0, ksplit = 1;
+  if (!halo_plan(B, H, W, cout, ldc_cdiv(cin, cpk), &best_bm, &best_tw, &ksplit)) return LDC_ERR_UNSUPPORTED;
+  if (workspace == nullptr || workspace_bytes < LDC_GEMM_COUNTER_BYTES) return LDC_ERR_ARG;
   HaloArgs a{};
   DevProblem& P = a.P;
   P.A = X;
@@ -446,7 +513,7 @@ int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, co
   P.ks = 3;
   int ktpt = ldc_cdiv(cin, cpk);
   while ((1 << P.kshift) < ktpt) ++P.kshift;
-  P.zero16 = static_cast<const unsigned char*>(zero16);
+  P.zero16 = static_cast<const unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES - 64;  // 64 zero bytes behind the counters (written by nobody)
   a.n_chunks = ktpt;  // chunks behind ceil(cin / cpk) hold only zero weights: not visited (the gathered conv walks all 2^kshift)
   a.TW = best_tw;
   a.TH = best_bm / best_tw;
@@ -460,9 +527,17 @@ int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, co
   a.tiles_x = ldc_cdiv(W, a.TW);
   a.tiles_y = ldc_cdiv(H, a.TH);
   a.tn = tn;
-  const long long G = static_cast<long long>(B) * a.tiles_y * a.tiles_x * tn;
+  const long long tiles = static_cast<long long>(B) * a.tiles_y * a.tiles_x * tn;
+  const long long G = tiles * ksplit;
   if (G > 0x7fffffffLL) return LDC_ERR_UNSUPPORTED;
   a.G = static_cast<int>(G);
+  a.ksplit = ksplit;
+  if (ksplit > 1) {  // the GEMM's workspace: [counter block, zero between launches | slabs]
+    const long long slab = 256LL * BN * static_cast<long long>(sizeof(float));
+    if (tiles > LDC_GEMM_COUNTER_BYTES / 4 - 16 || workspace_bytes < LDC_GEMM_COUNTER_BYTES + G * slab) return LDC_ERR_UNSUPPORTED;
+    a.counters = static_cast<unsigned*>(workspace);
+    a.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES);
+  }
   const size_t lds = static_cast<size_t>(NSTAGE) * BN * ROW_B + 2u * a.NP * 1024u + 8u * 1024u;
   const hipStream_t st = static_cast<hipStream_t>(stream);
   return one ? launch_halo<256, 1>(a, lds, st) : launch_halo<256, 3>(a, lds, st);

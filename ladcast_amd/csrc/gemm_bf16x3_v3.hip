@@ -856,8 +856,7 @@ extern "C" int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const 
     static const char* const halo_sw = LDC_AB_GETENV("LDC_CONV_HALO");  // measurement aid (A/B build): 0 = never
     if (!(halo_sw && atoi(halo_sw) == 0)) {
       if (workspace == nullptr || workspace_bytes < LDC_GEMM_COUNTER_BYTES) return LDC_ERR_ARG;
-      const int hs = ldc_conv_halo_dispatch(X, Wp, bias, R, Y, B, H, W, cin, ldx, cout, ldy, ldr, act, in_fmt, out_fmt,
-                                            static_cast<const unsigned char*>(workspace) + LDC_GEMM_COUNTER_BYTES - 64, stream);
+      const int hs = ldc_conv_halo_dispatch(X, Wp, bias, R, Y, B, H, W, cin, ldx, cout, ldy, ldr, act, in_fmt, out_fmt, workspace, workspace_bytes, stream);
       if (hs != LDC_ERR_UNSUPPORTED) return hs;
     }
   }

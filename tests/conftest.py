@@ -31,9 +31,16 @@ def full_dcae_oracle():
 
     o = make_dcae(dict(CONFIG_DCAE_84))
     f, st = synth_field(1, 84, 120, 240), synth_field(1, 5, 120, 240, seed=1)
-    with torch.no_grad():
-        z = o.encode(f, static_conditioning_tensor=st).latent
-        y = o.decode(z).sample
+    gold = os.path.join(ROOT, "tests", "golden", "fullsize_dcae.npz")
+    if os.path.exists(gold):  # the oracle's outputs as committed by tests/golden/make_fullsize_golden.py (y: every 7th value, tests/synth.py Sub)
+        from tests.synth import load_fullsize_golden
+
+        g = load_fullsize_golden(gold)
+        z, y = g["z"], g["y"]
+    else:
+        with torch.no_grad():
+            z = o.encode(f, static_conditioning_tensor=st).latent
+            y = o.decode(z).sample
     return SimpleNamespace(model=o, cfg=dict(CONFIG_DCAE_84), f=f, st=st, z=z, y=y)
 
 
@@ -84,6 +91,19 @@ def fullsize_chunk_oracle(full_dcae_oracle, oracle_375m):
     from oracle.ar_model import CONFIG_375M
     from oracle.scheduler import EDMDPMSolverMultistepScheduler as OracleScheduler
     d = full_dcae_oracle
+    gold = os.path.join(ROOT, "tests", "golden", "fullsize_375m_chunk.npz")
+    if os.path.exists(gold):
+        # the oracle's side of the chunk as committed by tests/golden/make_fullsize_golden.py (made in the build container from the same
+        # seeds): per-evaluation tensors as every 32nd value, the decoded frames as every 16th (tests/synth.py Sub); ~4 minutes of CPU
+        # oracle per GPU session less, and the 20-forward `pipeline` chunk comes with it
+        from tests.synth import load_fullsize_golden
+
+        g = load_fullsize_golden(gold)
+        targs = {"mean": g["mean"].tolist(), "std": g["std"].tolist(), "target_std": 0.5}
+        return SimpleNamespace(ar=oracle_375m, cfg=dict(CONFIG_375M), targs=targs, known=g["known"], ts=torch.tensor([2018010100]), want=g["want_edm"],
+                               ins=g["ins_edm"], outs=g["outs_edm"], latents=g["latents"], decoded=g["decoded"], in20=g["in20"], fwd_in20=g["fwd_in20_t0p3"],
+                               seconds=float(g["seconds_edm"][0]), pipeline=SimpleNamespace(want=g["want_pipeline"], ins=g["ins_pipeline"], outs=g["outs_pipeline"],
+                                                                                             seconds=float(g["seconds_pipeline"][0])))
     z = d.z[0]  # (84, 15, 30)
     mu, sd = z.mean(dim=(1, 2)), z.std(dim=(1, 2))
     targs = {"mean": mu.tolist(), "std": sd.tolist(), "target_std": 0.5}
@@ -95,8 +115,10 @@ def fullsize_chunk_oracle(full_dcae_oracle, oracle_375m):
     want = OP.ensemble_AR_sampler(OP.AutoRegressive2DPipeline(rec, OracleScheduler()), 1, 4, 20, known_latents=known, timestamps=ts, sampler_type="edm")
     lat = OP.get_inv_transform_3D("normalize", targs)(want.permute(1, 0, 2, 3, 4).reshape(84, 4, 15, 30)).reshape(84, 1, 4, 15, 30).permute(1, 0, 2, 3, 4)
     decoded = OP.decode_latent_ens(d.model, lat)
+    with torch.no_grad():
+        fwd = ar(rec.ins[20], torch.tensor([0.3]), known, time_elapsed=ts).sample
     return SimpleNamespace(ar=ar, cfg=dict(CONFIG_375M), targs=targs, known=known, ts=ts, want=want, ins=rec.ins, outs=rec.outs, latents=lat,
-                           decoded=decoded, seconds=time.perf_counter() - t0)
+                           decoded=decoded, in20=rec.ins[20], fwd_in20=fwd, seconds=time.perf_counter() - t0, pipeline=None)
 
 
 @pytest.fixture(autouse=True)

@@ -85,7 +85,49 @@ def synth_field(batch, channels, h, w, seed=0):
     return torch.randn(batch, channels, h, w, generator=torch.Generator().manual_seed(seed))
 
 
+class Sub:
+    """A tensor kept as every `stride`-th value of its flattening (+ its shape and full 2-norm): the form in which the full-size oracle
+    outputs are committed (tests/golden/fullsize_*.npz, made by tests/golden/make_fullsize_golden.py).  `rel_l2(got, Sub)` compares the
+    same subsample of `got`: an unbiased estimate of the full relative error (thousands of values), at 1/stride of the bytes."""
+
+    def __init__(self, values, stride, shape, norm):
+        self.values, self.stride, self.shape, self.norm = values, int(stride), tuple(int(v) for v in shape), float(norm)
+
+    @staticmethod
+    def of(t, stride):
+        f = t.detach().cpu().float().contiguous().flatten()
+        return Sub(f[::stride].clone(), stride, t.shape, f.double().norm().item())
+
+    def pick(self, t):
+        assert tuple(t.shape) == self.shape, (tuple(t.shape), self.shape)
+        return t.detach().cpu().float().contiguous().flatten()[:: self.stride]
+
+
+def load_fullsize_golden(path):
+    """tests/golden/fullsize_*.npz -> dict: full arrays as tensors, `<key>__sub` / `<key>__meta` pairs as Sub, `<key>__n` lists as lists"""
+    import numpy as np
+
+    z = np.load(path)
+    out, lists = {}, {}
+    for k in z.files:
+        if k.endswith("__sub"):
+            base = k[: -len("__sub")]
+            meta = z[base + "__meta"]
+            out[base] = Sub(torch.from_numpy(z[k]), int(meta[0]), [int(v) for v in meta[2:]], float(meta[1]))
+        elif k.endswith("__meta"):
+            continue
+        elif k.endswith("__n"):
+            lists[k[: -len("__n")]] = int(z[k][0])
+        else:
+            out[k] = torch.from_numpy(z[k])
+    for base, n in lists.items():
+        out[base] = [out.pop(f"{base}_{i}") for i in range(n)]
+    return out
+
+
 def rel_l2(a, b):
+    if isinstance(b, Sub):
+        a, b = b.pick(a), b.values
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm()).item()
 

@@ -16,13 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_self_launches_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--steps", "2", "--warmup", "1",
-           "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers"]
+           "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--no-strong-cfg3"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints the one JSON line
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "gloo"
+    assert line["strong_cfg3"] is None  # (--no-strong-cfg3; the leg itself is asserted in the two tests below)
+    # the line explains itself: the GPU's clock / power during the timed region, every rank's device
+    assert [d["rank"] for d in line["ranks"]["devices"]] == [0, 1] and all(d["pci_bus_id"] for d in line["ranks"]["devices"])
+    assert line["gpu"]["during_timed_region"]["samples"] >= 1 and "before" in line["gpu"] and "after" in line["gpu"]
     assert line["scaling"] == "weak" and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["members_per_gpu"] == 1  # weak scaling: 2 members in all, one per rank
 
@@ -40,6 +44,11 @@ def test_bench_strong_scaling_fixed_ensemble_over_two_ranks():
         assert len(lines) == 1, r.stdout[-2000:]
         line = json.loads(lines[0])
         assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["value"] > 0
+        # north_star's strong-scaling point rides on every N > 1 line: 16 members x 40 lead steps dealt to the ranks
+        s3 = line["strong_cfg3"]
+        assert s3["members_on_rank"] == [8, 8] and s3["scaling"] == "strong" and s3["steps"] == 1 and s3["per_rank"]["members"] == [8, 8]
+        assert abs(s3["value"] - 16 * 40 / (s3["ms_per_step"] * 1e-3)) / s3["value"] < 1e-3 and len(s3["per_rank"]["rollout_ms"]) == 2
+        assert s3["speedup_vs_n1"] is None  # 4 solver steps here: not the workload of the committed N = 1 figure, no ratio is printed
         assert line["config"]["ensemble_size"] == E and line["config"]["members_on_rank"] == want and line["config"]["members_per_gpu"] is None
         assert abs(line["value"] - E * 1 * 1 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3  # value = E x lead steps x steps / time
 
@@ -94,6 +103,9 @@ def test_eight_ranks_cfg3_shape_gather_equals_the_one_process_result(tmp_path):
         assert len(pr["ms_per_step"]) == 8 and pr["members"] == [2] * 8 and len(pr["gather_ms_per_step"]) == 8
         assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and all(v > 0 for v in pr["rollout_ms_per_step"])
         assert abs(line["value"] - 16 * 4 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+        s3 = line["strong_cfg3"]  # the extra leg: 16 members x 40 lead steps over the 8 ranks, two members each
+        assert s3["members_on_rank"] == [2] * 8 and s3["per_rank"]["members"] == [2] * 8 and s3["value"] > 0 and len(s3["per_rank"]["seconds"]) == 8
+        assert len(line["ranks"]["devices"]) == 8
         got = torch.load(dump)
         assert got.shape == (1, 16, 84, 5, 15, 30) and torch.isfinite(got).all()
         # the same work in ONE process: the eight member pairs one after the other, then all 16 members as one batch

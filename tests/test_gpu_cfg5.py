@@ -128,15 +128,14 @@ def test_cfg5_full_size_single_chunk_bf16_mixed(full_dcae_oracle, fullsize_chunk
     e_dec = rel_l2(dec[0, :, :, 1:], fx.decoded)
     # the decoder alone, on the oracle's latents
     y = gae.decode(fx.latents[0].permute(1, 0, 2, 3).contiguous().cuda()).sample
-    e_dec_only = rel_l2(y.cpu(), fx.decoded[0].permute(1, 0, 2, 3))
+    e_dec_only = rel_l2(y.cpu().permute(1, 0, 2, 3)[None], fx.decoded)  # (frames, C, H, W) -> the fixture's (1, C, frames, H, W)
     with torch.no_grad(), OA.reference_autocast("cuda"):
         a_enc = rel_l2(d.model.encode(d.f, static_conditioning_tensor=d.st).latent.float(), d.z)
         a_dec = rel_l2(d.model.decode(d.z).sample.float(), d.y)
-    with torch.no_grad():
-        w_fwd = fx.ar(fx.ins[20], torch.tensor([0.3]), fx.known, time_elapsed=fx.ts).sample
-        with OA.reference_autocast("cuda"):
-            a_fwd = rel_l2(fx.ar(fx.ins[20], torch.tensor([0.3]), fx.known, time_elapsed=fx.ts).sample.float(), w_fwd)
-    g_fwd = rel_l2(gar(fx.ins[20].cuda(), torch.tensor([0.3]).cuda(), fx.known.cuda(), time_elapsed=fx.ts.cuda()).sample.cpu(), w_fwd)
+    w_fwd = fx.fwd_in20  # the fp32 oracle's forward of network input 20 at t = 0.3 (session fixture / committed golden)
+    with torch.no_grad(), OA.reference_autocast("cuda"):
+        a_fwd = rel_l2(fx.ar(fx.in20, torch.tensor([0.3]), fx.known, time_elapsed=fx.ts).sample.float(), w_fwd)
+    g_fwd = rel_l2(gar(fx.in20.cuda(), torch.tensor([0.3]).cuda(), fx.known.cuda(), time_elapsed=fx.ts.cuda()).sample.cpu(), w_fwd)
     e_dec1 = rel_l2(gae.decode(d.z.cuda()).sample.cpu(), d.y)
     print(f"\ncfg5 full size, 1 member, 1 chunk [bf16 mode] vs fp32 oracle: encode {e_enc:.2e} -> chunk latents {e_lat:.2e} -> decoded fields {e_dec:.2e}"
           f" (decoder alone {e_dec_only:.2e})")

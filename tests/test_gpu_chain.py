@@ -59,6 +59,8 @@ def test_full_375m_chunk_matches_oracle(fullsize_chunk_oracle):
     for sampler, n_fwd in (("edm", 39), ("pipeline", 20)):
         if sampler == "edm":
             want, ins, outs, t_cpu = fx.want, fx.ins, fx.outs, fx.seconds
+        elif fx.pipeline is not None:  # committed oracle outputs (tests/golden/fullsize_375m_chunk.npz)
+            want, ins, outs, t_cpu = fx.pipeline.want, fx.pipeline.ins, fx.pipeline.outs, fx.pipeline.seconds
         else:
             ro = Rec(o)
             t0 = time.perf_counter()
@@ -241,3 +243,53 @@ def test_375m_two_members_three_chained_full_size_chunks():
         print(f"\n375M, 2 members x 12 lead steps = 3 chained chunks, 5 forwards each (oracle {tc:.0f} s) [{mode}] per-chunk rel-L2: {_fmt(per_chunk)}")
         assert max(per_chunk) < TOL, (mode, per_chunk)
     g.set_gemm_precision("fp32")
+
+
+def _literal_chunk_vs_golden(golden_dir, name, cfg, members, label):
+    """one 20-step Heun chunk (39 forwards) at literal width against the committed oracle run (tests/golden/make_fullsize_golden.py), fp32 and
+    split-bf16, with the per-evaluation error curves; eager (recorded) and graph-replayed samples must agree bit for bit"""
+    import os
+
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, ensemble_AR_sampler
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from tests.synth import load_fullsize_golden
+
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated (python tests/golden/make_fullsize_golden.py)")
+    fx = load_fullsize_golden(path)
+    assert len(fx["outs"]) == 39 and tuple(fx["want"].shape) == (members, 84, 4, 15, 30)
+    o = make_ar(dict(cfg))  # the same seeded weights the golden run used
+    g = to_hip(o, dict(cfg))
+    del o
+    known, ts = synth_known(1).cuda(), torch.tensor([2018010100]).cuda()
+    for mode in ("fp32", "bf16x3"):
+        g.set_gemm_precision(mode)
+        rg = Rec(g)
+        got = ensemble_AR_sampler(AutoRegressive2DPipeline(rg, EDMDPMSolverMultistepScheduler()), members, 4, 20, known_latents=known, timestamps=ts,
+                                  sampler_type="edm", device="cuda")
+        assert len(rg.outs) == 39
+        e_in, e_out, e = _curve(rg.ins, fx["ins"]), _curve(rg.outs, fx["outs"]), rel_l2(got.cpu(), fx["want"])
+        print(f"\n{label}: {members} member(s), 20-step Heun chunk, 39 forwards (oracle {float(fx['seconds'][0]):.0f} s in the build container) [{mode}]: sample rel-L2 {e:.2e}")
+        print(f"  network-input  error per evaluation: {_fmt(e_in)}")
+        print(f"  network-output error per evaluation: {_fmt(e_out)}")
+        assert e < TOL and max(e_in) < TOL and max(e_out) < TOL, (mode, e, max(e_in), max(e_out))
+        g.enable_hip_graph(True)
+        got_g = ensemble_AR_sampler(AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), members, 4, 20, known_latents=known, timestamps=ts,
+                                    sampler_type="edm", device="cuda")
+        g.enable_hip_graph(False)
+        assert torch.equal(got_g, got), mode
+    g.set_gemm_precision("fp32")
+
+
+def test_1_6b_full_length_heun_chunk_vs_committed_oracle(golden_dir):
+    """VERDICT r04 item 4 / missing 4: the 1.6B model at the reference's default chunk length (pipelines/edm_sampler.py:60-113: 20 steps, 39
+    network evaluations), 1 member - until round 4 the 1.6B was compared at 5 forwards per chunk only."""
+    from oracle.ar_model import CONFIG_1_6B
+
+    _literal_chunk_vs_golden(golden_dir, "fullsize_1p6b_chunk.npz", CONFIG_1_6B, 1, "1.6B")
+
+
+def test_375m_two_members_full_length_heun_chunk_vs_committed_oracle(golden_dir):
+    """the 375M at batch 2 (cfg 3's share of one GPU) at the literal 20 solver steps: 39 forwards of a 2-member batch"""
+    _literal_chunk_vs_golden(golden_dir, "fullsize_375m_2members.npz", CONFIG_375M, 2, "375M")

@@ -19,6 +19,7 @@ CASES = [  # (B, H, W, cin, cout): >= 192 tiles of 256 pixels each, so that the 
     (16, 20, 40, 28, 256),  # ragged tiles in both directions, a single partial chunk
     (12, 32, 64, 40, 256),  # whole tiles, twelve frames
     (20, 17, 36, 96, 192),  # odd height, three full chunks, one and a half output panels
+    (2, 60, 120, 128, 256),  # 120 tiles: two workgroups per tile, two channel chunks each, summed in the launch by the last arriver
 ]
 
 
@@ -108,7 +109,8 @@ def test_dcae_layer_shapes_take_the_halo_kernel():
     kernel at one frame already; the 30 x 60 / 15 x 30 stages once a batch of frames fills their tiles"""
     assert hip.sphere_conv_plan(1, 120, 240, 252, 252)[:2] == (True, 256)
     assert hip.sphere_conv_plan(1, 60, 120, 504, 1008)[:2] == (True, 256)
-    assert not hip.sphere_conv_plan(1, 60, 120, 504, 504)[0]  # 128 tiles: the gathered kernel cuts along K over all CUs instead
+    assert hip.sphere_conv_plan(1, 60, 120, 504, 504)[0]  # 128 tiles x 2 workgroups, eight channel chunks each
+    assert not hip.sphere_conv_plan(1, 30, 60, 504, 504)[0]  # 32 tiles: the gathered kernel cuts along K over all CUs instead
     assert hip.sphere_conv_plan(8, 60, 120, 504, 504)[0] and hip.sphere_conv_plan(8, 30, 60, 504, 504)[0]
     assert not hip.sphere_conv_plan(1, 6, 8, 16, 16)[0]  # narrower than a tile
     assert not hip.sphere_conv_plan(1, 120, 240, 252, 252, ksize=5)[0] and not hip.sphere_conv_plan(1, 120, 240, 252, 252, in_fmt=hip.FMT_F32)[0]

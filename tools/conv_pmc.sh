@@ -18,11 +18,11 @@ for SUF in "$@"; do
   python3 - "$O" "$SUF" "$SHAPE" <<'PY' | tee -a $O/conv_pmc_summary.txt
 import csv, glob, sys
 O, suf, shape = sys.argv[1:4]
-def mean(cdir, counter, key="gemm_bf16x3_v3_kernel"):
+def mean(cdir, counter, keys=("conv_halo_kernel", "gemm_bf16x3_v3_kernel")):
     v = []
     for f in glob.glob(f"{O}/{cdir}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and key in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in keys):
                 v.append(float(r["Counter_Value"]))
     return sum(v) / max(len(v), 1), len(v)
 f, n = mean("p_FETCH_SIZE", "FETCH_SIZE"); w, _ = mean("p_WRITE_SIZE", "WRITE_SIZE")
