@@ -440,6 +440,12 @@ int ldc_pixel_unshuffle_shortcut_split(const float* cv, const float* x, float* y
                                        int cin, int lds, int fmt, void* stream);
 int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H, int W, int cout, int cin,
                                      int lds, int fmt, void* stream);
+/* ABI 4: `cv` of ldc_pixel_shuffle_shortcut_split may be NULL - y is then the block's shortcut term alone,
+ * pixel_shuffle(x.repeat_interleave(4 cout / cin, dim=1), 2) (models/DCAE.py:526-530), which the interpolate form of the up block adds to
+ * its conv as the residual operand R.  ldc_upsample_nearest2x_rows: F.interpolate(scale_factor=2, mode="nearest") on NHWC rows
+ * (models/DCAE.py:519-522, upsample_block_type = "interpolate"): y[b, 2h+i, 2w+j, :] = x[b, h, w, :], as fp32 rows (y, ldy) and / or operand
+ * rows (ys, lds, fmt) for the conv that follows; C % 4 == 0. */
+int ldc_upsample_nearest2x_rows(const float* x, float* y, float* ys, int B, int H, int W, int C, int ldx, int ldy, int lds, int fmt, void* stream);
 int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, int fmt, void* stream);
 /* ldc_sphere_dwconv_nhwc / ldc_relu_linear_attn_nhwc with the output format as an argument (LDC_FMT_F32 | _SPLIT | _BF16). */
 int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int C, int ldx,

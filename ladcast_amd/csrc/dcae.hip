@@ -565,13 +565,36 @@ __global__ __launch_bounds__(256) void pixel_shuffle_shortcut_kernel(const float
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = 4 * (4 * c4 + e) + 2 * (hf & 1) + (wf & 1);
-    o[e] = cv[src * (4LL * cout) + q] + x[src * cin + q / rep];
+    o[e] = (cv ? cv[src * (4LL * cout) + q] : 0.f) + x[src * cin + q / rep];  // cv == NULL: the shortcut alone (interpolate up block)
   }
   if (y) *reinterpret_cast<float4*>(y + pix * cout + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
   if (ys) {
     unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
     ldc_store_fmt4(sr, 4 * c4, fmt, o[0], o[1], o[2], o[3]);
     if ((cout & 4) && c4 == cq - 1) ldc_zero_fmt4(sr, 4 * c4 + 4, fmt);
+  }
+}
+
+// nearest-neighbour x2 up-sampling of NHWC rows: y[b, 2h + i, 2w + j, :] = x[b, h, w, :] (F.interpolate(scale_factor=2, mode="nearest"),
+// DCUpBlock2d with interpolate=True: models/DCAE.py:519-525) - fp32 rows and / or operand rows for the conv that follows
+__global__ __launch_bounds__(256) void upsample_nearest2x_rows_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ ys, int H, int W,
+                                                                      int C, int ldx, int ldy, int lds, int fmt, long long total4) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int cq = C >> 2;
+  const int c4 = static_cast<int>(idx % cq);
+  const long long pix = idx / cq;  // b*(2H)*(2W) + hf*(2W) + wf
+  const int wf = static_cast<int>(pix % (2 * W));
+  const long long bh = pix / (2 * W);
+  const int hf = static_cast<int>(bh % (2 * H));
+  const long long b = bh / (2 * H);
+  const long long src = (b * H + (hf >> 1)) * W + (wf >> 1);
+  const float4 v = *reinterpret_cast<const float4*>(x + src * ldx + 4 * c4);
+  if (y) *reinterpret_cast<float4*>(y + pix * ldy + 4 * c4) = v;
+  if (ys) {
+    unsigned char* sr = reinterpret_cast<unsigned char*>(ys + pix * lds);
+    ldc_store_fmt4(sr, 4 * c4, fmt, v.x, v.y, v.z, v.w);
+    if ((C & 4) && c4 == cq - 1) ldc_zero_fmt4(sr, 4 * c4 + 4, fmt);
   }
 }
 
@@ -770,8 +793,7 @@ extern "C" int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float
 
 extern "C" int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H, int W, int cout,
                                                 int cin, int lds, int fmt, void* stream) {
-  LDC_CHECK_PTR(cv);
-  LDC_CHECK_PTR(x);
+  LDC_CHECK_PTR(x);  // cv may be NULL (ABI 4): y = the shortcut term alone
   if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
   if ((cout & 3) || (4 * cout) % cin) return LDC_ERR_UNSUPPORTED;
   const int ok = split_out_ok(y, ys, cout, lds, fmt);
@@ -779,6 +801,21 @@ extern "C" int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x,
   const long long total4 = static_cast<long long>(B) * 4 * H * W * (cout >> 2);
   hipLaunchKernelGGL(pixel_shuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), cv, x, y, ys, H, W, cout, cin, 4 * cout / cin, lds, fmt, total4);
+  return ldc_launch_status();
+}
+
+extern "C" int ldc_upsample_nearest2x_rows(const float* x, float* y, float* ys, int B, int H, int W, int C, int ldx, int ldy, int lds, int fmt,
+                                           void* stream) {
+  LDC_CHECK_PTR(x);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return LDC_ERR_ARG;
+  if ((C & 3) || (ldx & 3) || ldx < C || (y && ((ldy & 3) || ldy < C))) return LDC_ERR_ALIGN;
+  LDC_CHECK_ALIGN16(x);
+  if (y) LDC_CHECK_ALIGN16(y);
+  const int ok = split_out_ok(y, ys, C, lds, fmt);
+  if (ok != LDC_OK) return ok;
+  const long long total4 = static_cast<long long>(B) * 4 * H * W * (C >> 2);
+  hipLaunchKernelGGL(upsample_nearest2x_rows_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, ys, H, W, C, ldx,
+                     ldy, lds, fmt, total4);
   return ldc_launch_status();
 }
 

@@ -91,6 +91,7 @@ def _load():
         "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
         "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
         "ldc_split_rows": (I, [P, P, L, I, I, I, I, P]),
+        "ldc_upsample_nearest2x_rows": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
         "ldc_sphere_dwconv_nhwc_fmt": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
         "ldc_relu_linear_attn_nhwc_fmt": (I, [P, P, I, I, I, I, I, F, I, P, L, P]),
         "ldc_ensemble_scores_workspace_bytes": (L, [I, I, I]),
@@ -641,6 +642,13 @@ def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin, ys=None, lds=None, f
     _check(lib.ldc_pixel_shuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H, W, cout, cin,
                                                 (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, int(fmt), _stream()),
            "ldc_pixel_shuffle_shortcut_split")
+
+
+def upsample_nearest2x_rows(x, y, *, B, H, W, C, ldx=None, ldy=None, ys=None, lds=None, fmt=FMT_SPLIT):
+    """NHWC rows [B*H*W, ldx] -> [B*2H*2W, C] nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest")): fp32 rows `y` and / or operand rows `ys`"""
+    _dev(x, y, ys)
+    _check(lib.ldc_upsample_nearest2x_rows(_p(x), _p(y), _p(ys), B, H, W, C, ldx if ldx is not None else C, ldy if ldy is not None else C,
+                                           (lds if lds is not None else (ys.shape[1] if ys is not None else 0)), int(fmt), _stream()), "ldc_upsample_nearest2x_rows")
 
 
 def chan_regroup(x, y, *, M, cin, cout):

@@ -127,10 +127,12 @@ class DCDownBlock2d(nn.Module):
 
 
 class DCUpBlock2d(nn.Module):
-    def __init__(self, in_channels, out_channels):
+    """models/DCAE.py:493-536: conv at 4x the width + pixel_shuffle, or (interpolate, `upsample_block_type="interpolate"`) nearest x2 + conv"""
+
+    def __init__(self, in_channels, out_channels, interpolate=False):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.conv = SphereConv2d(in_channels, out_channels * 4, 3, 1, 1)
+        self.in_channels, self.out_channels, self.interpolate = in_channels, out_channels, interpolate
+        self.conv = SphereConv2d(in_channels, out_channels if interpolate else out_channels * 4, 3, 1, 1)
 
 
 def _get_block(block_type, ch, head_dim, act_fn, multiscales):
@@ -158,7 +160,8 @@ class Encoder(nn.Module):
 
 
 class Decoder(nn.Module):
-    def __init__(self, out_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu"):
+    def __init__(self, out_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu",
+                 upsample_block_type="pixel_shuffle"):
         super().__init__()
         n = len(block_out_channels)
         if layers_per_block[0] <= 0:
@@ -167,7 +170,7 @@ class Decoder(nn.Module):
         self.up_blocks = nn.ModuleList()
         for i, (ch, nl) in reversed(list(enumerate(zip(block_out_channels, layers_per_block)))):
             if i < n - 1 and nl > 0:
-                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch))
+                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, interpolate=upsample_block_type == "interpolate"))
             for _ in range(nl):
                 self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i]))
         self.norm_out = _RMSNormP(block_out_channels[0], 1e-7)
@@ -205,8 +208,9 @@ class AutoencoderDC(ModelMixin):
         self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
         if temb_channels is not None:
             raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
-        if upsample_block_type != "pixel_shuffle" or downsample_block_type != "pixel_unshuffle":
-            raise NotImplementedError("only pixel_(un)shuffle sampling (configs/DC_AE_84_pretrain.yaml:45-46)")
+        if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
+            # ("conv" down-sampling builds a stride-2 SphereConv2d, which the reference's SphereConv2d itself refuses: it asserts stride 1)
+            raise NotImplementedError("sampling: pixel_unshuffle down (configs/DC_AE_84_pretrain.yaml:45-46), pixel_shuffle | interpolate up")
         if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
             raise NotImplementedError("only rms_norm / silu decoders")
         n = len(encoder_block_out_channels)
@@ -214,7 +218,7 @@ class AutoencoderDC(ModelMixin):
         dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
         self.encoder = Encoder(in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales)
         self.decoder = Decoder(out_channels if out_channels is not None else in_channels, latent_channels, attention_head_dim, dbt,
-                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales)
+                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales, upsample_block_type=upsample_block_type)
         self.spatial_compression_ratio = 2 ** (n - 1)
         self.temporal_compression_ratio = 1
         self.use_slicing = False
@@ -434,6 +438,16 @@ class AutoencoderDC(ModelMixin):
                 ys = self._srows(M2, blk.out_channels, cv.device)
                 hip.pixel_unshuffle_shortcut(cv, x[0], y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys, fmt=self._fmt)
                 x, H, W = (y, ys), H // 2, W // 2
+            elif isinstance(blk, DCUpBlock2d) and blk.interpolate:
+                # nearest x2 (operand rows for the conv) -> conv at the output width with the shortcut as its residual operand (models/DCAE.py:519-532)
+                M4, ci, co = B * 4 * H * W, blk.in_channels, blk.out_channels
+                up32 = torch.empty(M4, ci, device=x[0].device, dtype=torch.float32) if not self._split else None
+                ups = self._srows(M4, ci, x[0].device)
+                hip.upsample_nearest2x_rows(x[0], up32, B=B, H=H, W=W, C=ci, ldx=x[0].shape[1], ys=ups, fmt=self._fmt)
+                sc = torch.empty(M4, co, device=x[0].device, dtype=torch.float32)
+                hip.pixel_shuffle_shortcut(None, x[0], sc, B=B, H=H, W=W, cout=co, cin=ci)
+                y = self._conv((up32, ups), B, 2 * H, 2 * W, blk.conv, R=sc)
+                x, H, W = self._stream(y, M4, co), 2 * H, 2 * W
             elif isinstance(blk, DCUpBlock2d):
                 cv = self._conv(x, B, H, W, blk.conv)
                 y = torch.empty(B * 4 * H * W, blk.out_channels, device=cv.device, dtype=torch.float32)

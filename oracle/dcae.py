@@ -173,17 +173,22 @@ class DCDownBlock2d(nn.Module):
 
 
 class DCUpBlock2d(nn.Module):
-    """models/DCAE.py:493-536 (pixel_shuffle form)"""
+    """models/DCAE.py:493-536: the pixel_shuffle form, or (interpolate=True, `upsample_block_type="interpolate"`, :498-525) nearest-neighbour
+    x2 up-sampling followed by a conv at the output width"""
 
-    def __init__(self, in_channels, out_channels, shortcut=True):
+    def __init__(self, in_channels, out_channels, shortcut=True, interpolate=False, interpolation_mode="nearest"):
         super().__init__()
         self.factor = 2
         self.repeats = out_channels * self.factor**2 // in_channels
         self.shortcut = shortcut
-        self.conv = SphereConv2d(in_channels, out_channels * self.factor**2, 3, 1, 1)
+        self.interpolate, self.interpolation_mode = interpolate, interpolation_mode
+        self.conv = SphereConv2d(in_channels, out_channels if interpolate else out_channels * self.factor**2, 3, 1, 1)
 
     def forward(self, x, temb=None):
-        y = F.pixel_shuffle(self.conv(x), self.factor)
+        if self.interpolate:
+            y = self.conv(F.interpolate(x, scale_factor=self.factor, mode=self.interpolation_mode))
+        else:
+            y = F.pixel_shuffle(self.conv(x), self.factor)
         if self.shortcut:
             s = F.pixel_shuffle(x.repeat_interleave(self.repeats, dim=1), self.factor)
             y = y + s
@@ -218,7 +223,8 @@ class Encoder(nn.Module):
 class Decoder(nn.Module):
     """models/DCAE.py:634-732"""
 
-    def __init__(self, out_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu"):
+    def __init__(self, out_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu",
+                 upsample_block_type="pixel_shuffle"):
         super().__init__()
         n = len(block_out_channels)
         assert layers_per_block[0] > 0
@@ -227,7 +233,7 @@ class Decoder(nn.Module):
         self.up_blocks = nn.ModuleList()
         for i, (ch, nl) in reversed(list(enumerate(zip(block_out_channels, layers_per_block)))):
             if i < n - 1 and nl > 0:
-                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True))
+                self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True, interpolate=upsample_block_type == "interpolate"))  # models/DCAE.py:677-682
             for _ in range(nl):
                 self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i]))
         ch0 = block_out_channels[0]
@@ -289,8 +295,9 @@ class AutoencoderDC(nn.Module):
         super().__init__()
         if temb_channels is not None:
             raise NotImplementedError("timestep-conditioned DCAE is not on the shipped-config path")
-        if upsample_block_type != "pixel_shuffle" or downsample_block_type != "pixel_unshuffle":
-            raise NotImplementedError("only pixel_(un)shuffle sampling is on the shipped-config path")
+        if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
+            # (downsample_block_type "conv" builds a stride-2 SphereConv2d, which the reference's SphereConv2d refuses: sphere_conv.py asserts stride 1)
+            raise NotImplementedError("sampling: pixel_unshuffle down, pixel_shuffle | interpolate up")
         if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
             raise NotImplementedError
         self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
@@ -308,6 +315,7 @@ class AutoencoderDC(nn.Module):
             decoder_block_out_channels,
             decoder_layers_per_block,
             decoder_qkv_multiscales,
+            upsample_block_type=upsample_block_type,
         )
         self.spatial_compression_ratio = 2 ** (n - 1)
         self.static_channels = static_channels

@@ -220,40 +220,7 @@ def _ref_classes(path, names, ns):
     return ns
 
 
-def piece_inputs():
-    """seeded inputs of the reference-owned building blocks (shared by the generator and tests/test_oracle_reference_pins.py)"""
-    g = torch.Generator().manual_seed(31)
-    return {
-        "down_x": torch.randn(2, 8, 6, 8, generator=g), "up_x": torch.randn(2, 16, 3, 4, generator=g), "proj_x": torch.randn(2, 96, 6, 8, generator=g),
-        "attn_x": torch.randn(2, 64, 6, 8, generator=g), "patch_x": torch.randn(2, 12, 3, 5, 6, generator=g), "dec_z": torch.randn(2, 4, 3, 2, 3, generator=g),
-    }
-
-
-def piece_modules():
-    """the oracle's modules for those blocks with seeded weights (torch CPU RNG: the same numbers on every machine)"""
-    from oracle import ar_model as OM
-    from oracle import dcae as OD
-
-    torch.manual_seed(77)
-    m = {
-        "down": OD.DCDownBlock2d(8, 16), "up": OD.DCUpBlock2d(16, 8), "proj": OD.SanaMultiscaleAttentionProjection(32, 1, 5),
-        "attn": OD.SanaMultiscaleLinearAttention(64, 64, attention_head_dim=32, kernel_sizes=(5,)), "patch": OM.HunyuanVideoPatchEmbed((1, 1, 1), 12, 40),
-    }
-    with torch.no_grad():
-        m["attn"].norm_out.weight.uniform_(0.5, 1.5)
-        m["attn"].norm_out.bias.uniform_(-0.5, 0.5)
-    return {k: v.eval() for k, v in m.items()}
-
-
-class ToyDecoder:
-    """decode(z) -> object with .sample; elementwise + a channel repeat (for decode_latent_ens)"""
-
-    device = torch.device("cpu")
-
-    def decode(self, z):
-        from types import SimpleNamespace
-
-        return SimpleNamespace(sample=(z * 1.5 - 0.25).repeat_interleave(2, dim=1))
+from tests.synth import ToyDecoder, piece_inputs, piece_modules  # noqa: E402,F401  (in tests/synth.py: the GPU box uses them without importing this script)
 
 
 def piece_fixtures():
@@ -289,6 +256,9 @@ def piece_fixtures():
         ref = ns["DCUpBlock2d"](16, 8, interpolate=False, shortcut=True)
         ref.load_state_dict(om["up"].state_dict(), strict=True)
         out["up"] = ref(x["up_x"]).numpy()
+        ref = ns["DCUpBlock2d"](16, 8, interpolate=True, shortcut=True)  # upsample_block_type = "interpolate" (models/DCAE.py:498-525,677-682)
+        ref.load_state_dict(om["up_interp"].state_dict(), strict=True)
+        out["up_interp"] = ref(x["up_x"]).numpy()
         ref = ns["SanaMultiscaleAttentionProjection"](32, 1, 5)
         ref.load_state_dict(om["proj"].state_dict(), strict=True)
         out["proj"] = ref(x["proj_x"]).numpy()

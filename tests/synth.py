@@ -195,3 +195,41 @@ class ToyNet:
         ts = 0.0 if time_elapsed is None else (time_elapsed.reshape(-1, 1, 1, 1, 1) % 100).to(x.dtype) * 0.01
         y = 0.75 * x - 0.25 * x / (1.0 + x.abs()) + 0.5 * known.mean(dim=2, keepdim=True) + 0.0625 * t + ts  # bounded, IEEE-exact ops only
         return SimpleNamespace(sample=y) if return_dict else (y,)
+
+
+# ---- inputs / seeded oracle modules of the building-block fixtures (tests/golden/pieces_ref.npz, made by make_golden.py::piece_fixtures) ----
+def piece_inputs():
+    """seeded inputs of the reference-owned building blocks (shared by the generator and tests/test_oracle_reference_pins.py)"""
+    g = torch.Generator().manual_seed(31)
+    return {
+        "down_x": torch.randn(2, 8, 6, 8, generator=g), "up_x": torch.randn(2, 16, 3, 4, generator=g), "proj_x": torch.randn(2, 96, 6, 8, generator=g),
+        "attn_x": torch.randn(2, 64, 6, 8, generator=g), "patch_x": torch.randn(2, 12, 3, 5, 6, generator=g), "dec_z": torch.randn(2, 4, 3, 2, 3, generator=g),
+    }
+
+
+def piece_modules():
+    """the oracle's modules for those blocks with seeded weights (torch CPU RNG: the same numbers on every machine)"""
+    from oracle import ar_model as OM
+    from oracle import dcae as OD
+
+    torch.manual_seed(77)
+    m = {
+        "down": OD.DCDownBlock2d(8, 16), "up": OD.DCUpBlock2d(16, 8), "proj": OD.SanaMultiscaleAttentionProjection(32, 1, 5),
+        "attn": OD.SanaMultiscaleLinearAttention(64, 64, attention_head_dim=32, kernel_sizes=(5,)), "patch": OM.HunyuanVideoPatchEmbed((1, 1, 1), 12, 40),
+    }
+    with torch.no_grad():
+        m["attn"].norm_out.weight.uniform_(0.5, 1.5)
+        m["attn"].norm_out.bias.uniform_(-0.5, 0.5)
+    m["up_interp"] = OD.DCUpBlock2d(16, 8, interpolate=True)  # (round 5; drawn AFTER everything above: the older fixtures keep their weights)
+    return {k: v.eval() for k, v in m.items()}
+
+
+class ToyDecoder:
+    """decode(z) -> object with .sample; elementwise + a channel repeat (for decode_latent_ens)"""
+
+    device = torch.device("cpu")
+
+    def decode(self, z):
+        from types import SimpleNamespace
+
+        return SimpleNamespace(sample=(z * 1.5 - 0.25).repeat_interleave(2, dim=1))

@@ -597,3 +597,52 @@ def test_dc_ae_ray_1024_shape_one_frame():
         assert zg.shape == zo.shape and yg.shape == yo.shape
         assert ez < 1e-4 and ey < 1e-4, (mode, ez, ey)
 
+
+
+def test_interpolate_upsampling_variant_matches_oracle(golden_dir):
+    """VERDICT r04 missing 3 / item 8: `upsample_block_type="interpolate"` (models/DCAE.py:498-525,677-682: nearest x2 up-sampling, a conv at
+    the output width, the same shortcut) used to raise NotImplementedError.  (a) the up block alone against the fixture made by the
+    REFERENCE's own DCUpBlock2d code (tests/golden/pieces_ref.npz `up_interp`, make_golden.py::piece_fixtures); (b) a tiny DC-AE with
+    interpolate decoders, decode in the three arithmetic modes against the oracle (whose block is pinned to the same fixture in
+    tests/test_oracle_reference_pins.py)."""
+    from ladcast_amd.precision import tolerance
+    from tests.synth import piece_inputs, piece_modules
+
+    import ladcast_amd.hip as hip
+
+    z = np.load(os.path.join(golden_dir, "pieces_ref.npz"))
+    om, x = piece_modules()["up_interp"], piece_inputs()["up_x"]
+    B, ci, H, W = x.shape
+    co = om.conv.out_channels
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, ci).contiguous().cuda()
+    up = torch.empty(B * 4 * H * W, ci, device="cuda")
+    hip.upsample_nearest2x_rows(rows, up, B=B, H=H, W=W, C=ci)
+    assert torch.equal(up.reshape(B, 2 * H, 2 * W, ci).permute(0, 3, 1, 2).cpu(), F.interpolate(x, scale_factor=2, mode="nearest"))
+    sc = torch.empty(B * 4 * H * W, co, device="cuda")
+    hip.pixel_shuffle_shortcut(None, rows, sc, B=B, H=H, W=W, cout=co, cin=ci)
+    assert torch.equal(sc.reshape(B, 2 * H, 2 * W, co).permute(0, 3, 1, 2).cpu(), F.pixel_shuffle(x.repeat_interleave(om.repeats, dim=1), 2))
+    from ladcast_amd.models.sphere_conv import pack_dense_weight
+
+    y = torch.empty(B * 4 * H * W, co, device="cuda")
+    hip.sphere_conv_nhwc(up, pack_dense_weight(om.conv.weight.detach().cuda()), y, B=B, H=2 * H, W=2 * W, cin=ci, cout=co, bias=om.conv.bias.detach().cuda(), R=sc, ldr=co,
+                         ksize=3)
+    got = y.reshape(B, 2 * H, 2 * W, co).permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, torch.from_numpy(z["up_interp"])) < 2e-6
+    # (b) the whole autoencoder with interpolate decoders
+    cfg = dict(tiny_dcae_config(), upsample_block_type="interpolate")
+    o, g = _pair(cfg)
+    assert all(b.interpolate for b in g.decoder.up_blocks if hasattr(b, "interpolate"))
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        zz = o.encode(f, static_conditioning_tensor=st).latent
+        want = o.decode(zz).sample
+    for mode in ("fp32", "bf16x3", "bf16"):
+        g.set_gemm_precision(mode)
+        got = g.decode(zz.cuda()).sample
+        e = rel_l2(got.cpu(), want)
+        print(f"\ntiny DC-AE, interpolate up-sampling, decode [{mode}]: rel-L2 {e:.2e}")
+        assert e < (tolerance("bf16", "dcae_decode") if mode == "bf16" else 2e-5 if mode == "fp32" else 5e-5), (mode, e)
+    g.set_gemm_precision("fp32")
+    g.enable_hip_graph(True)
+    assert torch.equal(g.decode(zz.cuda()).sample, g.decode(zz.cuda()).sample)
+    g.enable_hip_graph(False)

@@ -85,7 +85,7 @@ def test_building_blocks_equal_the_reference_classes(golden_dir):
     decode_latent_ens: the oracle's classes against outputs of the reference's own class code on the same seeded weights
     (tests/golden/pieces_ref.npz; the reference classes loaded the oracle's state dicts with strict=True, so the parameter names
     agree too).  Convolutions and matmuls on the CPU: 1e-6."""
-    from tests.golden.make_golden import ToyDecoder, piece_inputs, piece_modules
+    from tests.synth import ToyDecoder, piece_inputs, piece_modules
 
     z = np.load(f"{golden_dir}/pieces_ref.npz")
     x, m = piece_inputs(), piece_modules()
@@ -98,6 +98,7 @@ def test_building_blocks_equal_the_reference_classes(golden_dir):
     with torch.no_grad():
         assert close(m["down"](x["down_x"]), "down")
         assert close(m["up"](x["up_x"]), "up")
+        assert close(m["up_interp"](x["up_x"]), "up_interp")  # upsample_block_type = "interpolate": nearest x2 + conv + shortcut (models/DCAE.py:519-532)
         assert close(m["proj"](x["proj_x"]), "proj")
         assert close(m["attn"](x["attn_x"]), "attn")
         assert close(m["patch"](x["patch_x"]), "patch")
