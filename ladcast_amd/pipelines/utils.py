@@ -164,8 +164,8 @@ def ensemble_AR_sampler(
     sizes = [batch_size] * int(sample_size / batch_size) + [sample_size % batch_size]
     samples = torch.empty(
         sample_size, pipeline.ar_model.config.out_channels, return_seq_len, *known_latents.shape[-2:],
-        device=device, dtype=pipeline.ar_model.dtype,
-    )
+        device=device, dtype=torch.float32,  # (pipelines/utils.py:690-696 asks for ar_model.dtype: this build's models compute and return fp32 - a model
+    )                                        # cast to bf16 / fp16 is up-cast at its first use, AFTER this buffer exists; see pipeline_AR.py)
     sampler_kwargs = sampler_kwargs or {}
     if sampler_type == "edm":
         model = pipeline.ar_model
