@@ -13,6 +13,9 @@ their norm (tests/synth.py: Sub); small ones (latents, one network input) in ful
                                input 20 in full, de-normalised latents (full), the four decoded frames (stride 16)
   fullsize_1p6b_chunk.npz      1.6B, 1 member, 20-step Heun chunk (39 forwards): sample (full), per-evaluation inputs / outputs (stride 32)
   fullsize_375m_2members.npz   375M, 2 members, 20-step Heun chunk (39 forwards, batch 2): sample (full), per-evaluation inputs / outputs
+  fullsize_1p6b_truncated_chunks.npz, fullsize_375m_2members_3chunks.npz
+                               the chained roll_out_serial runs of tests/test_gpu_chain.py (3 solver steps per chunk): 1.6B, 6 lead steps = chunk +
+                               truncated chunk; 375M, 2 members, 12 lead steps = 3 chained chunks
 """
 import os
 import sys
@@ -105,8 +108,37 @@ def chunk(name, cfg, members):
     print(f"{name}: {out['seconds'][0]:.0f} s", flush=True)
 
 
+def chained_rollout(name, cfg, members, lead_hours, stride):
+    """oracle side of tests/test_gpu_chain.py's chained roll_out_serial tests: 3 solver steps per chunk (5 forwards), chunks chained through
+    each member's own last frame; the IC latent comes from a stand-in encoder (the DCAE is not part of these tests)"""
+    from datetime import datetime
+
+    o = make_ar(dict(cfg))
+    targs = {"mean": [0.1] * 84, "std": [1.3] * 84, "target_std": 0.5}
+    ic = synth_known(1)[0] * 2.6 + 0.1
+
+    class FakeAE:
+        device = torch.device("cpu")
+        config = type("c", (), dict(latent_channels=84, out_channels=89, static_channels=5))
+
+        def encode(self, x, static_conditioning_tensor=None):
+            return type("o", (), dict(latent=ic.permute(1, 0, 2, 3)))
+
+    t0 = time.perf_counter()
+    want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), [datetime(2018, 1, 1, 0)], OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
+                              static_tensor4encdec=torch.zeros(5, 120, 240), ensemble_size=members, num_inference_steps=3, return_seq_len=4,
+                              latent_transform_args=targs, total_lead_time_hour=lead_hours, sampler_type="edm", return_latent=True)
+    out = {"seconds": np.array([time.perf_counter() - t0])}
+    put(out, "want", want, stride)
+    np.savez(os.path.join(HERE, name), **out)
+    print(f"{name}: {out['seconds'][0]:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dcae375", "2members", "1p6b"]
+    which = sys.argv[1:] or ["dcae375", "2members", "1p6b", "chained"]
+    if "chained" in which:
+        chained_rollout("fullsize_1p6b_truncated_chunks.npz", CONFIG_1_6B, 1, 36, None)   # (1, 1, 84, 7, 15, 30): kept in full (1 MB)
+        chained_rollout("fullsize_375m_2members_3chunks.npz", CONFIG_375M, 2, 72, 2)      # (1, 2, 84, 13, 15, 30): every 2nd value
     if "dcae375" in which:
         dcae_and_375m()
     if "2members" in which:

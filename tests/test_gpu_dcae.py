@@ -634,7 +634,7 @@ def test_interpolate_upsampling_variant_matches_oracle(golden_dir):
     assert all(b.interpolate for b in g.decoder.up_blocks if hasattr(b, "interpolate"))
     f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
     with torch.no_grad():
-        zz = o.encode(f, static_conditioning_tensor=st).latent
+        zz = o.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
         want = o.decode(zz).sample
     for mode in ("fp32", "bf16x3", "bf16"):
         g.set_gemm_precision(mode)
