@@ -1,7 +1,7 @@
 // Dense 3x3 SphereConv2d (models/sphere_conv.py:62-129,174-192) as an implicit GEMM whose pixel operand is staged ONCE per channel
 // chunk: round 5's replacement for the gathered-row conv of gemm_bf16x3_v3.hip (CONV = true) on the DCAE's large layers.
 //
-// Why (profiles/r05_a_conv_variants.log, r05_a_conv_pmc_summary.txt): in the gathered form every k-step (tap, 32-channel chunk) pulls its
+// Why (profiles/r05_a_conv_variants_nodma_and_chunk_major.log, r05_a_conv_pmc_gathered_vs_chunk_major.txt): in the gathered form every k-step (tap, 32-channel chunk) pulls its
 // own BM x 128 B pixel panel through L2 into LDS - nine DMA'd copies of (nearly) the same pixels per chunk, 48 KB per k-step and CU with
 // the weight tile, 571 MB of fabric traffic per 252 -> 252 full-resolution launch against 60 MB algorithmic.  The same kernel with the
 // DMAs compiled out runs the launch in 78 us instead of 112; ordering the k-steps chunk-major so that L2 serves the re-reads cut the
@@ -406,10 +406,11 @@ int launch_halo(const HaloArgs& a, size_t lds, hipStream_t st) {
 
 // Tile choice.  Tiles are 256 pixels (TH x TW, TW a power of two >= 16, at most seven halo pieces per wave and chunk) and a launch is whole
 // tiles, one per workgroup, in ceil(tiles / 256) rounds.  Measured against the gathered conv on the DCAE's layer shapes, same box
-// (profiles/r05_c_conv_tile_sweep.log): 252 -> 252 at 120 x 240 (240 tiles) 104 -> 92 us, 504 -> 1008 at 60 x 120 (256 tiles) 187 -> 174,
-// eight frames of every 3 x 3 layer 8 - 14 % less - but 504 -> 504 at 60 x 120 in ONE frame (128 tiles) 106 -> 164: a launch that cannot
-// give most CUs a tile stays on the gathered kernel, which cuts along K over all of them.  (A 128-pixel tile of this kernel was slower
-// than the gathered conv on every shape - the weight stream per FLOP doubles - and is not built.)
+// (profiles/r05_d_conv_halo_static_taps_ab.log, r05_f_conv_ksplit_ab.log): 252 -> 252 at 120 x 240 (240 tiles) 99 -> 80 us, 504 -> 1008 at
+// 60 x 120 (256 tiles) 182 -> 145, eight frames of every 3 x 3 layer 20 - 27 % less.  A launch that cannot give most CUs a tile
+// (504 -> 504 at 30 x 60 in one frame: 32 tiles) stays on the gathered kernel, which cuts along K over all of them; between 96 and 128
+// tiles two workgroups share a tile (below).  (A 128-pixel tile of this kernel was slower than the gathered conv on every shape - the
+// weight stream per FLOP doubles - and is not built: r05_c_conv_tile_sweep.log.)
 // Among the tile shapes the one with the fewest tiles wins, then the smallest halo.
 static bool halo_plan(int B, int H, int W, int cout, int n_chunks, int* bm_out, int* tw_out, int* ksplit_out) {
   constexpr int bm = 256;

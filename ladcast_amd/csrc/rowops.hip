@@ -261,7 +261,7 @@ __device__ __forceinline__ float modulate_nocontract(float v, float scale, float
 // those two registers before their use takes that first read; reading x.x / x.z instead does not help (control).  Two instructions per
 // staged float4, no measurable cost (73.3 / 78.0 -> 72.5 / 77.2 us, tools/gemv_bench.py), bit-identical results; one process on one stream
 // never runs two kernels at once and never showed the effect.  -DLDC_LS_NO_FIRST_READ in the A/B build compiles the guard out
-// (tools/canary/victim_pattern.py reproduces the wrong words with it).
+// (tools/canary/first_read_repro.hip, built both ways by `make repro`, reproduces the wrong words with it: tests/test_gpu_multistream_victims.py).
 __device__ __forceinline__ void ls_first_read(float4& v) {
 #if !(defined(LDC_AB_BUILD) && defined(LDC_LS_NO_FIRST_READ))
   float t0, t1;

@@ -44,10 +44,10 @@ def _victims():
     a3, g3 = rnd(2, 450, D, seed=3), rnd(2, 2 * D, seed=4)
     v["gate_residual"] = (lambda: torch.empty(2, 450, D, device="cuda"),
                           lambda y: hip.gate_residual(x3, a3, g3[:, D:], y, B=2, rows=450, D=D, ld_res=D, res_bs=450 * D, ld_y=D, y_bs=450 * D, gate_bs=2 * D))
-    xs, Wg, bg = rnd(2, D, seed=5), rnd(9216, D, seed=6) / 39, rnd(9216, seed=7)
-    v["linear_small_gemv_2rows"] = (lambda: torch.empty(2, 9216, device="cuda"), lambda y: hip.linear_small(xs, Wg, y, rows=2, N=9216, K=D, bias=bg, act_in=hip.ACT_SILU))
+    xs, Wg, bg = rnd(2, D, seed=5), rnd(58368, D, seed=6) / 39, rnd(58368, seed=7)  # the AdaLN modulation GEMV of the 375M model: the launch where the effect was found
+    v["linear_small_gemv_2rows"] = (lambda: torch.empty(2, 58368, device="cuda"), lambda y: hip.linear_small(xs, Wg, y, rows=2, N=58368, K=D, bias=bg, act_in=hip.ACT_SILU))
     x20 = rnd(20, D, seed=8)
-    v["linear_small_mfma_20rows"] = (lambda: torch.empty(20, 9216, device="cuda"), lambda y: hip.linear_small(x20, Wg, y, rows=20, N=9216, K=D, bias=bg, act_in=hip.ACT_SILU))
+    v["linear_small_mfma_20rows"] = (lambda: torch.empty(20, 58368, device="cuda"), lambda y: hip.linear_small(x20, Wg, y, rows=20, N=58368, K=D, bias=bg, act_in=hip.ACT_SILU))
     xt = rnd(2, 84, 1800, seed=9)
     v["chan_to_token"] = (lambda: torch.empty(2, 1800, 96, device="cuda"), lambda y: hip.chan_to_token(xt, y, B=2, C=84, N=1800, ldo=96, fill_cols=96))
     tk = rnd(2, 1800, 96, seed=10)
@@ -123,3 +123,28 @@ def test_row_kernels_next_to_an_mfma_aggressor_on_a_second_stream():
         bad = [i for i, o in enumerate(outs) if not torch.equal(o.view(torch.uint8), ref.view(torch.uint8))]
         assert not bad, f"{name}: {len(bad)} of {LAUNCHES} launches next to the MFMA aggressor differ from the solo run (first: launch {bad[0]})"
     assert overlap_seen >= len(VICTIMS) - 2, f"only {overlap_seen} of {len(VICTIMS)} victim windows overlapped the aggressor's"
+
+
+def test_first_read_reproducer_guarded_build_is_clean():
+    """tools/canary/first_read_repro.hip - ONE translation unit holding the library's GEMV source and the aggressor, one
+    process, two streams - as a regression test.  Built twice by `make -C ladcast_amd/csrc repro` (part of build()): as shipped, and with the
+    guard of rowops.hip (ls_first_read) compiled out.  The shipped build must be clean next to the MFMA-streaming aggressor; the unguarded
+    build's count is printed (round 4 measured 2880 of 2880 launches wrong on the MI355X it was found on): should a toolchain change make
+    the guard unnecessary - or defeat it - this is where it shows."""
+    import re
+    import subprocess
+
+    d = os.path.join(ROOT, "tools", "canary", "build")
+    g, u = os.path.join(d, "first_read_repro_guarded"), os.path.join(d, "first_read_repro_unguarded")
+    if not (os.path.exists(g) and os.path.exists(u)):
+        pytest.skip("reproducer binaries not built (make -C ladcast_amd/csrc repro)")
+    out = {}
+    for name, exe in (("guarded", g), ("unguarded", u)):
+        r = subprocess.run([exe, "1.5"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"next to the (\S+) aggressor: (\d+) of (\d+) launches wrong", r.stdout)}
+        print(f"\n[{name}] " + r.stdout.strip().replace("\n", "\n[" + name + "] "))
+    for mode in ("VALU-only", "MFMA-streaming"):
+        wrong, launches = out["guarded"][mode]
+        assert launches > 50 and wrong == 0, (mode, out["guarded"])
+    assert out["unguarded"]["VALU-only"][0] == 0  # the control: without MFMAs next to it even the unguarded GEMV is right

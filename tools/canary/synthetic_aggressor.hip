@@ -85,7 +85,7 @@ static void run(double seconds, const float* src, float* sink, int iters) {
   printf("synthetic aggressor mode %d: %llu launches\n", MODE, launches);
 }
 
-// the same kernels as a library, for an aggressor on a second stream of the VICTIM's own process (victim_pattern.py ... local<mode>):
+// the same kernels as a function, for an aggressor on a second stream of the VICTIM's own process (first_read_repro.hip):
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/canary/synthetic_aggressor.hip -o /tmp/libsynth.so
 static float *g_src = nullptr, *g_sink = nullptr;
 extern "C" int synth_launch(int mode, int iters, int blocks, void* stream) {

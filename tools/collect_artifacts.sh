@@ -23,7 +23,7 @@ if [ "${2:-all}" = pmc ]; then
   cat $O/pmc_summary.txt
   exit 0
 fi
-python3 $B > $O/bench_cfg2_bf16x3.json 2> $O/bench.err
+python3 $B --steps 20 --warmup 5 > $O/bench_cfg2_bf16x3.json 2> $O/bench.err
 python3 $B --no-batched-conditioning $Q > $O/bench_cfg2_bf16x3_conditioning_per_evaluation.json 2>> $O/bench.err
 python3 $B --precision bf16 $Q > $O/bench_cfg2_bf16.json 2>> $O/bench.err
 python3 $B --members-per-gpu 2 --lead-steps 40 --steps 3 --warmup 1 $Q --no-kernel-timers > $O/bench_cfg3_share_2members_40leadsteps.json 2>> $O/bench.err
@@ -31,7 +31,9 @@ python3 $B --model 1.6B --lead-steps 10 --steps 3 --warmup 1 $Q --no-kernel-time
 python3 $B --decode --lead-steps 40 --precision bf16 --steps 3 --warmup 1 $Q --no-kernel-timers > $O/bench_cfg5_share_decode_40leadsteps_bf16.json 2>> $O/bench.err
 python3 $B --decode --lead-steps 40 --steps 3 --warmup 1 $Q --no-kernel-timers > $O/bench_cfg5_share_decode_40leadsteps_bf16x3.json 2>> $O/bench.err
 python3 $B --workload dcae --cpu-forwards 0 > $O/dcae_encode_decode.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B $Q > $O/stats_run.log 2>&1
+python3 $B --ensemble-size 16 --lead-steps 40 --steps 2 --warmup 0 $Q --no-kernel-timers > $O/bench_cfg3_whole_job_16members_one_gpu.json 2>> $O/bench.err
+# the headline leg ALONE under rocprofv3: per template instance, AverageNs x bench.py's flops_per_launch = achieved_rocprof
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --steps 20 --warmup 5 $Q --no-kernel-timers > $O/stats_run.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $B --steps 2 --warmup 1 $Q --no-kernel-timers > $O/trace_run.log 2>&1
 python3 $R/tools/trace_forward.py $O/trace v > $O/forward_timeline.txt 2>&1
 pmc_passes
@@ -41,7 +43,7 @@ rocprofv3 --kernel-trace --output-format csv -d $O/dtrace -- python3 $R/tools/dc
 TRACE_START=-1 python3 $R/tools/trace_forward.py $O/dtrace v > $O/dcae_decode_1frame_timeline.txt 2>&1
 rm -rf $O/dtrace
 # keep the merged scratch small: the raw traces are large
-find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_cfg2.csv \;
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_cfg2_headline.csv \;
 rm -rf $O/stats $O/trace $O/mfma
 cd $R
 LDC_LIB_PATH=ladcast_amd/libladcast_hip_stamps.so python3 tools/gemm_launch_stamps.py > $O/gemm_launch_stamps.log 2>&1
