@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .embeddings import get_year_sincos_embedding, rope_tables_from_grid
+from .embeddings import get_year_sincos_embedding, rope_tables_from_grid, rotary_1d
 from .modeling_utils import ModelMixin
 
 
@@ -248,8 +248,7 @@ class LaDCastTransformer3DModel(ModelMixin):
     ) -> None:
         super().__init__()
         self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
-        if nope:
-            raise NotImplementedError("nope is not used by any shipped config")
+        # nope=True (models/LaDCast_3D_model.py:710-712,897-918): the rotary tables are temporal-only over the whole head dimension (_rope_tables)
         if patch_size != 1 or patch_size_t != 1:
             raise NotImplementedError("shipped configs use patch size 1 (configs/ladcast_375M.yaml:11-12)")
         if attention_head_dim != 128 or qk_norm != "rms_norm":
@@ -491,8 +490,13 @@ class LaDCastTransformer3DModel(ModelMixin):
             pred_t = torch.arange(1, r + 1, dtype=torch.float32)
             lat = torch.linspace(self.rope_spatial_grid_start_pos[0], self.rope_spatial_grid_end_pos[0], steps=h, dtype=torch.float32)
             lon = torch.linspace(self.rope_spatial_grid_start_pos[1], self.rope_spatial_grid_end_pos[1], steps=w, dtype=torch.float32)
-            pc, ps = rope_tables_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
-            cc, cs = rope_tables_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
+            if getattr(c, "nope", False):  # get_1d_rotary_pos_embed(head_dim, temporal coordinate), a frame's row repeated over its h * w tokens (:897-918)
+                n = h * w
+                pc, ps = (t.repeat_interleave(n, dim=0).contiguous() for t in rotary_1d(c.attention_head_dim, pred_t, c.rope_theta))
+                cc, cs = (t.repeat_interleave(n, dim=0).contiguous() for t in rotary_1d(c.attention_head_dim, cond_t, c.rope_theta))
+            else:
+                pc, ps = rope_tables_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
+                cc, cs = rope_tables_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
             pc, ps, cc, cs = (t.to(dev) for t in (pc, ps, cc, cs))
             # compact (cos_i, sin_i) tables for the fused QKV epilogue: pred rows, cond rows, and the joint table of the single-stream
             # blocks (pred rows, then cond rows)

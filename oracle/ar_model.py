@@ -298,7 +298,7 @@ CONFIG_1_6B = dict(CONFIG_375M, num_attention_heads=16, num_layers=5, num_single
 
 
 class LaDCastTransformer3DModel(nn.Module):
-    """models/LaDCast_3D_model.py:569-1071 (``nope`` stays at its default False: no shipped config sets it;
+    """models/LaDCast_3D_model.py:569-1071 (``nope`` - temporal-only rotary embedding - is restated since round 5;
     ``scale_attn_by_lat`` - also off in both shipped configs - is restated: a (1, 1, 1, keys) float mask of normalised
     cos-latitude weights ADDED to the attention scores of every block, :682-693,873-882,950)."""
 
@@ -328,8 +328,8 @@ class LaDCastTransformer3DModel(nn.Module):
         scale_attn_by_lat: bool = False,
     ):
         super().__init__()
-        if nope:
-            raise NotImplementedError("nope is not on the shipped-config path")
+        # nope=True (models/LaDCast_3D_model.py:710-712,897-918): no spatial rotary embedding - the whole head dimension rotates with the
+        # temporal coordinate only (see rope_tables)
         if patch_size != 1 or patch_size_t != 1:
             raise NotImplementedError("shipped configs use patch size 1")
         self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
@@ -391,6 +391,13 @@ class LaDCastTransformer3DModel(nn.Module):
         lon = torch.linspace(
             self.rope_spatial_grid_start_pos[1], self.rope_spatial_grid_end_pos[1], steps=width, device=device, dtype=torch.float32
         )
+        if getattr(c, "nope", False):  # :897-918: get_1d_rotary_pos_embed(head_dim, temporal coordinate), every frame's row repeated over its h * w tokens
+            from .layers import get_1d_rotary_pos_embed
+
+            pc, ps = get_1d_rotary_pos_embed(c.attention_head_dim, pred_t, c.rope_theta)
+            cc, cs = get_1d_rotary_pos_embed(c.attention_head_dim, cond_t, c.rope_theta)
+            n = height * width
+            return (pc.repeat_interleave(n, dim=0), ps.repeat_interleave(n, dim=0)), (cc.repeat_interleave(n, dim=0), cs.repeat_interleave(n, dim=0))
         pred = rope_from_grid(c.rope_axes_dim, [pred_t, lat, lon], c.rope_theta)
         cond = rope_from_grid(c.conditioning_tensor_rope_axes_dim, [cond_t, lat, lon], c.rope_theta)
         return pred, cond

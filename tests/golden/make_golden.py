@@ -451,6 +451,19 @@ def ar_forward_fixtures():
             y = model(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
             out[name] = y[::7].float().numpy()
             out[name + "_norm"] = np.array(y.norm().item())
+        # nope = True (off in both shipped configs; round 5): the reference forward takes its rotary tables from get_1d_rotary_pos_embed over the
+        # TEMPORAL coordinate alone, for the whole head dimension (:897-918).  get_1d_rotary_pos_embed is diffusers' (the oracle's restatement,
+        # here with the reference's own call signature); which rows get which table, and the repeat over a frame's tokens, is reference code.
+        from oracle.layers import get_1d_rotary_pos_embed as _g1d
+
+        ns["get_1d_rotary_pos_embed"] = lambda dim, pos, theta, use_real=True: _g1d(dim, pos, theta)
+        object.__setattr__(model, "scale_attn_by_lat", False)
+        model.config.nope = True
+        x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+        y = model(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
+        out["nope"] = y[::7].float().numpy()
+        out["nope_norm"] = np.array(y.norm().item())
+        model.config.nope = False
     np.savez_compressed(os.path.join(HERE, "ar_forward_ref.npz"), **out)
 
 

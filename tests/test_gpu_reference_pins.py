@@ -76,6 +76,27 @@ def test_product_transformer_reproduces_the_reference_forward_code(golden_dir):
             assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < tol
 
 
+def test_product_nope_reproduces_the_reference_forward_code(golden_dir):
+    """`nope=True` (round 5; models/LaDCast_3D_model.py:710-712,897-918): temporal-only rotary tables over the whole head dimension, in both
+    attention paths (fp32: qk_rmsnorm_rope kernel; split modes: the QKV GEMM epilogue's compact table), against the fixture made by the
+    reference's forward code; the sampler chunk (graph) runs with it too."""
+    from ladcast_amd.models import LaDCastTransformer3DModel
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    cfg = dict(tiny_ar_config(), nope=True)
+    m = LaDCastTransformer3DModel.from_config(cfg)
+    m.load_state_dict(make_ar(tiny_ar_config()).state_dict(), strict=True)
+    m = m.cuda().eval()
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3)).cuda()
+    want = torch.from_numpy(z["nope"]).double()
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 5e-3)):
+        m.set_gemm_precision(prec)
+        y = m(x, torch.tensor([0.3]).cuda(), synth_known(2).cuda(), time_elapsed=torch.tensor([2018010100]).cuda()).sample.double().flatten().cpu()
+        assert ((y[::7] - want).norm() / want.norm()).item() < tol, prec
+    m.set_gemm_precision("fp32")
+
+
 def test_product_scale_attn_by_lat_reproduces_the_reference_forward_code(golden_dir):
     """`scale_attn_by_lat=True`: the per-key score bias of every attention call (refiner: cond keys; blocks: pred + cond keys) against the
     fixtures made by the reference's forward code, with the reference's weights and with them amplified 200x; all three arithmetic modes."""

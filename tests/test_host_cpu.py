@@ -257,4 +257,7 @@ def test_gemv_first_read_guard_is_in_the_shipped_kernels():
     assert "ls_first_read(xv);" in src
     assert "#if !(defined(LDC_AB_BUILD) && defined(LDC_LS_NO_FIRST_READ))" in src
     mk = open(os.path.join(ROOT, "ladcast_amd", "csrc", "Makefile")).read()
-    assert "LDC_LS_NO_FIRST_READ" not in mk
+    # the only place the Makefile names the switch is the UNGUARDED build of the reproducer (a test program, `make repro`), never a library object
+    uses = [ln for ln in mk.splitlines() if "LDC_LS_NO_FIRST_READ" in ln and not ln.lstrip().startswith("#")]
+    assert len(uses) == 1 and "first_read_repro" not in uses[0] and "$(REPRO_F)" in uses[0] and "$@" in uses[0]
+    assert "first_read_repro_unguarded:" in mk

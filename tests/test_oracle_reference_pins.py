@@ -148,6 +148,24 @@ def test_scale_attn_by_lat_equals_the_reference_forward_code(golden_dir):
             assert abs(y.norm().item() / float(z[name + "_norm"]) - 1) < 1e-6
 
 
+def test_nope_equals_the_reference_forward_code(golden_dir):
+    """`nope=True` (off in both shipped configs): the reference forward replaces the grid RoPE by a temporal-only rotary table over the whole
+    head dimension (models/LaDCast_3D_model.py:710-712,897-918).  Fixture `nope` was made by the reference's forward code
+    (make_golden.py::ar_forward_fixtures); it differs from the grid-RoPE output of the same inputs far beyond rounding."""
+    from tests.synth import make_ar, synth_known, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    m = make_ar(dict(tiny_ar_config(), nope=True))
+    assert [k for k in m.state_dict()] == [k for k in make_ar(tiny_ar_config()).state_dict()]  # no parameters involved
+    x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        y = m(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
+        y_grid = make_ar(tiny_ar_config())(x, torch.tensor([0.3]), synth_known(2), time_elapsed=torch.tensor([2018010100])).sample.double().flatten()
+    want = torch.from_numpy(z["nope"]).double()
+    assert ((y[::7] - want).norm() / want.norm()).item() < 1e-6 and abs(y.norm().item() / float(z["nope_norm"]) - 1) < 1e-6
+    assert ((y_grid[::7] - want).norm() / want.norm()).item() > 1e-3  # the variant really changes the output
+
+
 def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
     """tests/golden/dcae_forward_ref.npz: the tiny autoencoder's latent and reconstruction when the forward of every DCAE class the reference
     defines (ResBlock, GLUMBConv, EfficientViTBlock, the linear-attention container + processor, DCDown/UpBlock2d, Encoder, Decoder) is the
