@@ -59,9 +59,31 @@ class SanaMultiscaleAttnProcessor2_0:
     """marker of the built-in (fused) linear-attention path, models/DCAE.py:200-267; never called"""
 
 
-class SanaMultiscaleLinearAttention(nn.Module):
-    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15):
+class TimestepEmbedding(nn.Module):
+    """parameter container of diffusers' TimestepEmbedding(256, temb_channels): linear_2(SiLU(linear_1(sinusoid(t))))"""
+
+    def __init__(self, in_channels, time_embed_dim):
         super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+class AdaLayerNormZeroSingle4Sana(nn.Module):
+    """parameter container of models/DCAE.py:36-64: Linear(C -> 3C) producing (shift, scale, gate); the LayerNorm has no parameters"""
+
+    def __init__(self, embedding_dim, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(embedding_dim, 3 * embedding_dim, bias=bias)
+
+
+class SanaMultiscaleLinearAttention(nn.Module):
+    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15, temb_channels=None):
+        super().__init__()
+        if temb_channels is not None:  # models/DCAE.py:147-153: the block's projection of relu(temb) + AdaLayerNormZeroSingle4Sana (:36-64)
+            self.time_emb_porj = nn.Linear(temb_channels, out_channels)
+            self.norm_in = AdaLayerNormZeroSingle4Sana(out_channels)
+        else:
+            self.time_emb_porj, self.norm_in = None, None
         if attention_head_dim != 32:
             raise NotImplementedError("the linear-attention kernel is built for attention_head_dim 32")
         self.eps = eps
@@ -103,8 +125,9 @@ class GLUMBConv(nn.Module):
 
 
 class ResBlock(nn.Module):
-    def __init__(self, in_channels, out_channels, act_fn="silu"):
+    def __init__(self, in_channels, out_channels, act_fn="silu", temb_channels=None):
         super().__init__()
+        self.time_emb_porj = nn.Linear(temb_channels, 2 * out_channels) if temb_channels is not None else None  # models/DCAE.py:351-354
         self.act = {"silu": hip.ACT_SILU, "relu": hip.ACT_RELU}[act_fn]
         self.conv1 = SphereConv2d(in_channels, in_channels, 3, 1, 1)
         self.conv2 = SphereConv2d(in_channels, out_channels, 3, 1, 1, bias=False)
@@ -112,9 +135,10 @@ class ResBlock(nn.Module):
 
 
 class EfficientViTBlock(nn.Module):
-    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,)):
+    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,), temb_channels=None):
         super().__init__()
-        self.attn = SanaMultiscaleLinearAttention(in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales)
+        self.attn = SanaMultiscaleLinearAttention(in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales,
+                                                  temb_channels=temb_channels)
         self.conv_out = GLUMBConv(in_channels, in_channels)
 
 
@@ -135,16 +159,16 @@ class DCUpBlock2d(nn.Module):
         self.conv = SphereConv2d(in_channels, out_channels if interpolate else out_channels * 4, 3, 1, 1)
 
 
-def _get_block(block_type, ch, head_dim, act_fn, multiscales):
+def _get_block(block_type, ch, head_dim, act_fn, multiscales, temb_channels=None):
     if block_type == "ResBlock":
-        return ResBlock(ch, ch, act_fn)
+        return ResBlock(ch, ch, act_fn, temb_channels=temb_channels)
     if block_type == "EfficientViTBlock":
-        return EfficientViTBlock(ch, head_dim, tuple(multiscales))
+        return EfficientViTBlock(ch, head_dim, tuple(multiscales), temb_channels=temb_channels)
     raise ValueError(f"Block with {block_type=} is not supported.")
 
 
 class Encoder(nn.Module):
-    def __init__(self, in_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales):
+    def __init__(self, in_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
         if layers_per_block[0] <= 0:
@@ -153,7 +177,7 @@ class Encoder(nn.Module):
         self.down_blocks = nn.ModuleList()
         for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
             for _ in range(nl):
-                self.down_blocks.append(_get_block(block_type[i], ch, head_dim, "silu", qkv_multiscales[i]))
+                self.down_blocks.append(_get_block(block_type[i], ch, head_dim, "silu", qkv_multiscales[i], temb_channels))
             if i < n - 1 and nl > 0:
                 self.down_blocks.append(DCDownBlock2d(ch, block_out_channels[i + 1]))
         self.conv_out = SphereConv2d(block_out_channels[-1], latent_channels, 3, 1, 1)
@@ -161,7 +185,7 @@ class Encoder(nn.Module):
 
 class Decoder(nn.Module):
     def __init__(self, out_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu",
-                 upsample_block_type="pixel_shuffle"):
+                 upsample_block_type="pixel_shuffle", temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
         if layers_per_block[0] <= 0:
@@ -172,7 +196,7 @@ class Decoder(nn.Module):
             if i < n - 1 and nl > 0:
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, interpolate=upsample_block_type == "interpolate"))
             for _ in range(nl):
-                self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i]))
+                self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i], temb_channels))
         self.norm_out = _RMSNormP(block_out_channels[0], 1e-7)
         self.conv_out = SphereConv2d(block_out_channels[0], out_channels, 3, 1, 1)
 
@@ -206,8 +230,6 @@ class AutoencoderDC(ModelMixin):
     ) -> None:
         super().__init__()
         self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
-        if temb_channels is not None:
-            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
         if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
             # ("conv" down-sampling builds a stride-2 SphereConv2d, which the reference's SphereConv2d itself refuses: it asserts stride 1)
             raise NotImplementedError("sampling: pixel_unshuffle down (configs/DC_AE_84_pretrain.yaml:45-46), pixel_shuffle | interpolate up")
@@ -216,9 +238,12 @@ class AutoencoderDC(ModelMixin):
         n = len(encoder_block_out_channels)
         ebt = (encoder_block_types,) * n if isinstance(encoder_block_types, str) else tuple(encoder_block_types)
         dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
-        self.encoder = Encoder(in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales)
+        self.encoder = Encoder(in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales,
+                               temb_channels=temb_channels)
+        # models/DCAE.py:845-850: Timesteps(256) (a sinusoid, no parameters: ldc_timestep_embedding) + TimestepEmbedding(256, temb_channels)
+        self.timestep_embedder = TimestepEmbedding(256, temb_channels) if temb_channels is not None else None
         self.decoder = Decoder(out_channels if out_channels is not None else in_channels, latent_channels, attention_head_dim, dbt,
-                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales, upsample_block_type=upsample_block_type)
+                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales, upsample_block_type=upsample_block_type, temb_channels=temb_channels)
         self.spatial_compression_ratio = 2 ** (n - 1)
         self.temporal_compression_ratio = 1
         self.use_slicing = False
@@ -386,18 +411,47 @@ class AutoencoderDC(ModelMixin):
         hip.rmsnorm_rows(u, norm.weight, y32, rows=M, C=C, eps=norm.eps, b=norm.bias, resid=resid, act=act, ys=ys, fmt=self._fmt)
         return y32, ys
 
-    def _resblock(self, blk, x, B, H, W):
+    def _resblock(self, blk, x, B, H, W, temb=None):
+        if blk.time_emb_porj is not None:
+            # timestep-conditioned ResBlock (models/DCAE.py:361-365): act(conv1(x)) * scale + shift, (scale | shift) = Linear(act(temb)) per frame
+            if temb is None:
+                raise ValueError("this autoencoder was built with temb_channels: encode / decode need `temb`")
+            M, C = B * H * W, blk.conv1.out_channels
+            t32 = self._conv(x, B, H, W, blk.conv1, act=blk.act)
+            mod = torch.empty(B, 2 * C, device=t32.device, dtype=torch.float32)
+            hip.linear_small(temb, blk.time_emb_porj.weight, mod, rows=B, N=2 * C, K=temb.shape[1], bias=blk.time_emb_porj.bias, act_in=blk.act)
+            for b in range(B):  # per frame: x * scale_c + shift_c over its H W pixel rows, in place (two roundings, as the reference's mul + add)
+                rows = t32[b * H * W : (b + 1) * H * W]
+                hip.chan_affine(rows, rows, mod[b, C:], mod[b, :C], 1.0, outer=H * W, C=C, inner=1, inverse=True)
+            u = self._conv(self._stream(t32, M, C), B, H, W, blk.conv2)
+            return self._norm(u, blk.norm, x[0], M, blk.conv2.out_channels)
         t = self._conv(x, B, H, W, blk.conv1, act=blk.act, out_split=True)  # only conv2 reads it
         t = (None, t) if self._split else (t, None)
         u = self._conv(t, B, H, W, blk.conv2)
         return self._norm(u, blk.norm, x[0], B * H * W, blk.conv2.out_channels)
 
-    def _evit(self, blk, x, B, H, W):
+    def _evit(self, blk, x, B, H, W, temb=None):
         M = B * H * W
         at = blk.attn
         C, inner, heads = at.to_q.in_features, at.inner, at.heads
         dev = x[0].device
         split = self._split
+        gate = None
+        if at.norm_in is not None:
+            # timestep-conditioned attention (models/DCAE.py:36-64,193-198): emb = Linear(relu(temb)); (shift, scale, gate) = Linear(SiLU(emb));
+            # x <- LayerNorm_channels(x, eps 1e-15) (1 + scale) + shift - which is also the block's residual (:217) - and gate scales to_out's output
+            if temb is None:
+                raise ValueError("this autoencoder was built with temb_channels: encode / decode need `temb`")
+            e1 = torch.empty(B, C, device=dev, dtype=torch.float32)
+            hip.linear_small(temb, at.time_emb_porj.weight, e1, rows=B, N=C, K=temb.shape[1], bias=at.time_emb_porj.bias, act_in=hip.ACT_RELU)
+            mod = torch.empty(B, 3 * C, device=dev, dtype=torch.float32)
+            hip.linear_small(e1, at.norm_in.linear.weight, mod, rows=B, N=3 * C, K=C, bias=at.norm_in.linear.bias, act_in=hip.ACT_SILU)
+            xn = torch.empty(M, C, device=dev, dtype=torch.float32)
+            ldx = x[0].shape[1]
+            hip.layernorm_mod(x[0], xn, B=B, rows=H * W, D=C, ldx=ldx, x_bs=H * W * ldx, ldy=C, y_bs=H * W * C, scale=mod[:, C:], shift=mod, mod_bs=3 * C, mode=0,
+                              eps=1e-15)
+            x = self._stream(xn, M, C)
+            gate = mod[:, 2 * C :]
         n_ms = len(at.to_qkv_multiscale)
         wide = 3 * inner * (1 + n_ms)
         qkv = torch.empty(M, wide, device=dev, dtype=torch.float32)
@@ -412,6 +466,10 @@ class AutoencoderDC(ModelMixin):
                                   out_fmt=self._fmt if split else hip.FMT_F32)
         o = torch.empty(M, C, device=dev, dtype=torch.float32)
         self._mm((None, att) if split else (att, None), id(at.to_out), at.to_out.weight, o, B, H, W, N=C, K=groups * 32)
+        if gate is not None:  # models/DCAE.py:256-257: hidden_states * gate, before norm_out
+            og = torch.empty_like(o)
+            hip.gate_residual(torch.zeros_like(o), o, gate, og, B=B, rows=H * W, D=C, ld_res=C, res_bs=H * W * C, ld_y=C, y_bs=H * W * C, gate_bs=3 * C)
+            o = og
         y = self._norm(o, at.norm_out, x[0], M, C)
         # GLUMBConv, models/DCAE.py:304-324
         g = blk.conv_out
@@ -425,12 +483,12 @@ class AutoencoderDC(ModelMixin):
         self._mm((None, h2) if split else (h2, None), id(g.conv_point), self._plan[id(g.conv_point)], h3, B, H, W, N=C, K=hid2 // 2)
         return self._norm(h3, g.norm, y[0], M, C)
 
-    def _run_blocks(self, blocks, x, B, H, W):
+    def _run_blocks(self, blocks, x, B, H, W, temb=None):
         for blk in blocks:
             if isinstance(blk, ResBlock):
-                x = self._resblock(blk, x, B, H, W)
+                x = self._resblock(blk, x, B, H, W, temb)
             elif isinstance(blk, EfficientViTBlock):
-                x = self._evit(blk, x, B, H, W)
+                x = self._evit(blk, x, B, H, W, temb)
             elif isinstance(blk, DCDownBlock2d):
                 cv = self._conv(x, B, H, W, blk.conv)
                 M2 = B * (H // 2) * (W // 2)
@@ -465,7 +523,29 @@ class AutoencoderDC(ModelMixin):
             hip.split_rows(x32, xs, rows=M, C=C, ldx=x32.shape[1], lds=xs.shape[1], fmt=self._fmt)
         return x32, xs
 
-    def _encode_launch(self, x, st=None):
+    def _embed_t_launch(self, t, B):
+        """raw timesteps (B,) or (1,) -> temb [B, temb_channels]: time_proj (the 256-wide sinusoid, fused as the GEMV's input transform) +
+        timestep_embedder (models/DCAE.py:982-984,845-850); launches only"""
+        te = self.timestep_embedder
+        T = te.linear_2.out_features
+        n = t.numel()
+        mid, out = torch.empty(n, T, device=t.device, dtype=torch.float32), torch.empty(n, T, device=t.device, dtype=torch.float32)
+        hip.linear_small(t.reshape(-1), te.linear_1.weight, mid, rows=n, N=T, K=256, bias=te.linear_1.bias, act_in=hip.ACT_IN_TIMESTEP_SINCOS, act_out=hip.ACT_SILU)
+        hip.linear_small(mid, te.linear_2.weight, out, rows=n, N=T, K=T, bias=te.linear_2.bias)
+        return out if n == B else out.expand(B, T).contiguous()
+
+    def _temb_arg(self, temb, embedded_t, B, dev):
+        """the `temb` argument of encode / decode as a device tensor: (B, temb_channels) when already embedded, else raw timesteps"""
+        if temb is None:
+            return None
+        if self.timestep_embedder is None:
+            raise ValueError("temb was given, but this autoencoder was built without temb_channels")
+        t = temb.to(device=dev, dtype=torch.float32).contiguous()
+        if embedded_t and t.shape[0] != B:
+            t = t.expand(B, -1).contiguous()
+        return t
+
+    def _encode_launch(self, x, st=None, temb=None, embedded_t=True):
         """kernel launches only (capturable): NCHW fp32 device tensors -> latent (B, lc, H/8, W/8)"""
         enc = self.encoder
         dev = x.device
@@ -477,8 +557,10 @@ class AutoencoderDC(ModelMixin):
         hip.chan_to_token(x, tok, B=B, C=C, N=H * W, ldo=cp, fill_cols=C if cs else cp)
         if cs:
             hip.chan_to_token(st, tok[:, C:], B=B, C=cs, N=H * W, ldo=cp, fill_cols=cp - C)
+        if temb is not None and not embedded_t:
+            temb = self._embed_t_launch(temb, B)
         h = self._conv(self._stream(tok, B * H * W, cp), B, H, W, enc.conv_in)
-        h, H, W = self._run_blocks(enc.down_blocks, self._stream(h, B * H * W, enc.conv_in.out_channels), B, H, W)
+        h, H, W = self._run_blocks(enc.down_blocks, self._stream(h, B * H * W, enc.conv_in.out_channels), B, H, W, temb)
         lc = enc.conv_out.out_channels
         sc = torch.empty(B * H * W, lc, device=dev, dtype=torch.float32)
         hip.chan_regroup(h[0], sc, M=B * H * W, cin=enc.conv_out.in_channels, cout=lc)  # out shortcut, :624-627
@@ -487,7 +569,7 @@ class AutoencoderDC(ModelMixin):
         hip.token_to_chan(z, out, B=B, C=lc, N=H * W, ldi=lc)
         return out
 
-    def _decode_launch(self, z, return_static=False):
+    def _decode_launch(self, z, return_static=False, temb=None, embedded_t=True):
         """kernel launches only (capturable): latent (B, C, h, w) -> fields (B, keep, 8h, 8w)"""
         dec = self.decoder
         dev = z.device
@@ -497,8 +579,10 @@ class AutoencoderDC(ModelMixin):
         c0 = dec.conv_in.out_channels
         rep = torch.empty(B * H * W, c0, device=dev, dtype=torch.float32)
         hip.chan_regroup(tok, rep, M=B * H * W, cin=C, cout=c0)
+        if temb is not None and not embedded_t:
+            temb = self._embed_t_launch(temb, B)
         h = self._conv(self._stream(tok, B * H * W, C), B, H, W, dec.conv_in, R=rep)  # in shortcut = repeat_interleave, :720-722
-        h, H, W = self._run_blocks(dec.up_blocks, self._stream(h, B * H * W, c0), B, H, W)
+        h, H, W = self._run_blocks(dec.up_blocks, self._stream(h, B * H * W, c0), B, H, W, temb)
         n = self._norm(h[0], dec.norm_out, None, B * H * W, dec.norm_out.weight.numel(), act=hip.ACT_RELU, want32=False)  # only conv_out reads it
         y = self._conv(n, B, H, W, dec.conv_out)
         co = dec.conv_out.out_channels
@@ -513,8 +597,6 @@ class AutoencoderDC(ModelMixin):
     # -- public API ---------------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x, return_dict: bool = True, temb=None, embedded_t: bool = False, static_conditioning_tensor=None):
-        if temb is not None:
-            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
         if self.use_slicing and x.shape[0] > 1:
             raise NotImplementedError("Slicing is not supported for encoding.")
         if self._plan is None:
@@ -533,7 +615,14 @@ class AutoencoderDC(ModelMixin):
             st = st.contiguous()
             cs = st.shape[1]
         assert C + cs == enc.conv_in.in_channels, "channel count does not match conv_in"
-        if self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
+        t = self._temb_arg(temb, embedded_t, B, dev)
+        if t is not None:  # timestep-conditioned variant (models/DCAE.py:982-984): temb is one more static input of the captured launch sequence
+            emb = bool(embedded_t)
+            if self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
+                out = self._graphed(("enc_t", B, C, H, W, cs, emb, tuple(t.shape)), lambda xx, *r: self._encode_launch(xx, r[0] if cs else None, r[-1], emb), [x] + ([st] if cs else []) + [t])
+            else:
+                out = self._encode_launch(x, st if cs else None, t, emb)
+        elif self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
             out = self._graphed(("enc", B, C, H, W, cs), self._encode_launch, [x] + ([st] if cs else []))
         else:
             out = self._encode_launch(x, st if cs else None)
@@ -543,8 +632,6 @@ class AutoencoderDC(ModelMixin):
 
     @torch.no_grad()
     def decode(self, z, return_dict: bool = True, temb=None, embedded_t: bool = False, return_static=False):
-        if temb is not None:
-            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
         if self.use_slicing and z.size(0) > 1:
             raise NotImplementedError("Slicing is not supported for decoding.")
         if self._plan is None:
@@ -557,7 +644,14 @@ class AutoencoderDC(ModelMixin):
         dec = self.decoder
         if C % 4:
             raise NotImplementedError("latent_channels must be a multiple of 4")
-        if self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
+        t = self._temb_arg(temb, embedded_t, B, dev)
+        if t is not None:
+            emb = bool(embedded_t)
+            if self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
+                out = self._graphed(("dec_t", B, C, H, W, bool(return_static), emb, tuple(t.shape)), lambda zz, tt: self._decode_launch(zz, return_static, tt, emb), [z, t])
+            else:
+                out = self._decode_launch(z, return_static, t, emb)
+        elif self.use_hip_graph and B <= self.GRAPH_MAX_FRAMES:
             out = self._graphed(("dec", B, C, H, W, bool(return_static)), lambda zz: self._decode_launch(zz, return_static), [z])
         else:
             out = self._decode_launch(z, return_static)
@@ -566,10 +660,9 @@ class AutoencoderDC(ModelMixin):
         return DecoderOutput(sample=out)
 
     def forward(self, sample, return_dict: bool = True, time_elapsed=None, static_conditioning_tensor=None, return_static: bool = False):
-        if time_elapsed is not None:
-            raise NotImplementedError("timestep-conditioned DCAE is not used by the shipped configs")
-        z = self.encode(sample, return_dict=False, static_conditioning_tensor=static_conditioning_tensor)[0]
-        y = self.decode(z, return_dict=False, return_static=return_static)[0]
+        # models/DCAE.py:1067-1085: `time_elapsed` is embedded once and handed to both halves (embedded_t=True there; the same values here)
+        z = self.encode(sample, return_dict=False, temb=time_elapsed, static_conditioning_tensor=static_conditioning_tensor)[0]
+        y = self.decode(z, return_dict=False, temb=time_elapsed, return_static=return_static)[0]
         if not return_dict:
             return (y,)
         return DecoderOutput(sample=y)

@@ -1,6 +1,7 @@
 """Oracle restatement of ``AutoencoderDC`` and its blocks (models/DCAE.py:67-1087)
-for the shipped configuration (configs/DC_AE_84_pretrain.yaml:1-48): no timestep
-conditioning (``temb_channels=None``), ``rms_norm``, pixel-(un)shuffle sampling.
+for the shipped configuration (configs/DC_AE_84_pretrain.yaml:1-48: ``rms_norm``, pixel-(un)shuffle sampling, no timestep
+conditioning) and, since round 5, the constructor variants ``upsample_block_type="interpolate"`` and ``temb_channels`` (the
+timestep-conditioned ResBlock / linear attention, models/DCAE.py:36-64,110-153,193-198,334-365,786-850,982-984).
 
 Parameter names equal the reference's.  RMSNorm comes from
 ``oracle.layers`` (PARITY UNPINNED); SphereConv2d from ``oracle.sphere_conv`` (PINNED); every forward in THIS file is PINNED to the
@@ -16,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .autocast import fp32_island
-from .layers import RMSNorm
+from .layers import RMSNorm, TimestepEmbedding, get_timestep_embedding
 from .sphere_conv import SphereConv2d
 
 
@@ -41,14 +42,37 @@ class SanaMultiscaleAttentionProjection(nn.Module):
         return self.proj_out(self.proj_in(x))
 
 
+class AdaLayerNormZeroSingle4Sana(nn.Module):
+    """models/DCAE.py:36-64 (the reference's own class): emb -> Linear(SiLU(emb)) -> (shift, scale, gate); LayerNorm over the channels of every
+    pixel without affine, eps 1e-15 (diffusers' FP32LayerNorm: computed in fp32, cast back), x_hat (1 + scale) + shift."""
+
+    def __init__(self, embedding_dim: int, bias: bool = True):
+        super().__init__()
+        self.linear = nn.Linear(embedding_dim, 3 * embedding_dim, bias=bias)
+        self.embedding_dim = embedding_dim
+
+    def forward(self, x, emb):
+        emb = self.linear(F.silu(emb))
+        shift, scale, gate = emb.chunk(3, dim=1)
+        xl = x.movedim(1, -1)
+        xn = F.layer_norm(xl.float(), (self.embedding_dim,), None, None, 1e-15).to(xl.dtype)
+        return (xn * (1 + scale[:, None, None]) + shift[:, None, None]).movedim(-1, 1), gate[:, :, None, None]
+
+
 class SanaMultiscaleLinearAttention(nn.Module):
     """models/DCAE.py:96-267 (processor folded in).  Heads = ``int(C // 32)`` so the
     inner width is 480 / 992 for C = 504 / 1008; the multi-scale concat is regrouped
     as consecutive 96-channel groups split (q, k, v) = (32, 32, 32) -- reference quirk,
     reproduced literally (models/DCAE.py:226-243)."""
 
-    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15, residual_connection=True):
+    def __init__(self, in_channels, out_channels, attention_head_dim=32, mult=1.0, kernel_sizes=(5,), eps=1e-15, residual_connection=True,
+                 temb_channels=None):
         super().__init__()
+        if temb_channels is not None:  # models/DCAE.py:147-153
+            self.time_emb_porj = nn.Linear(temb_channels, out_channels)
+            self.norm_in = AdaLayerNormZeroSingle4Sana(out_channels)
+        else:
+            self.time_emb_porj, self.norm_in = None, None
         self.eps = eps
         self.attention_head_dim = attention_head_dim
         self.residual_connection = residual_connection
@@ -64,6 +88,9 @@ class SanaMultiscaleLinearAttention(nn.Module):
         self.norm_out = RMSNorm(out_channels, eps=1e-5, elementwise_affine=True, bias=True)  # get_normalization default eps
 
     def forward(self, x, temb=None):
+        gate = None
+        if self.norm_in is not None:  # models/DCAE.py:193-198: the block's own projection of relu(temb), then the AdaLN; the residual below
+            x, gate = self.norm_in(x, self.time_emb_porj(F.relu(temb)))  # is the NORMALISED tensor (the processor takes it from its input, :217)
         b, _, h, w = x.shape
         residual = x
         xl = x.movedim(1, -1)
@@ -84,6 +111,8 @@ class SanaMultiscaleLinearAttention(nn.Module):
         out = out.to(original_dtype)  # models/DCAE.py:249
         out = out.reshape(b, -1, h, w)
         out = self.to_out(out.movedim(1, -1)).movedim(-1, 1)
+        if gate is not None:  # models/DCAE.py:256-257
+            out = out * gate
         out = _chan_rmsnorm(self.norm_out, out)
         if self.residual_connection:
             out = out + residual
@@ -115,16 +144,21 @@ class GLUMBConv(nn.Module):
 class ResBlock(nn.Module):
     """models/DCAE.py:327-377"""
 
-    def __init__(self, in_channels, out_channels, act_fn="silu"):
+    def __init__(self, in_channels, out_channels, act_fn="silu", temb_channels=None):
         super().__init__()
         self.nonlinearity = _act(act_fn)
         self.conv1 = SphereConv2d(in_channels, in_channels, 3, 1, 1)
         self.conv2 = SphereConv2d(in_channels, out_channels, 3, 1, 1, bias=False)
         self.norm = RMSNorm(out_channels, eps=1e-5, elementwise_affine=True, bias=True)
+        self.time_emb_porj = nn.Linear(temb_channels, 2 * out_channels) if temb_channels is not None else None  # models/DCAE.py:351-354
 
     def forward(self, x, temb=None):
         residual = x
         x = self.nonlinearity(self.conv1(x))
+        if self.time_emb_porj is not None:  # models/DCAE.py:361-365: scale and shift (not 1 + scale) from the block's activation of temb
+            t = self.time_emb_porj(self.nonlinearity(temb))[:, :, None, None]
+            scale, shift = torch.chunk(t, 2, dim=1)
+            x = x * scale + shift
         x = self.conv2(x)
         x = _chan_rmsnorm(self.norm, x)
         return x + residual
@@ -133,22 +167,22 @@ class ResBlock(nn.Module):
 class EfficientViTBlock(nn.Module):
     """models/DCAE.py:380-414"""
 
-    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,)):
+    def __init__(self, in_channels, attention_head_dim=32, qkv_multiscales=(5,), temb_channels=None):
         super().__init__()
         self.attn = SanaMultiscaleLinearAttention(
-            in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales
+            in_channels, in_channels, attention_head_dim=attention_head_dim, kernel_sizes=qkv_multiscales, temb_channels=temb_channels
         )
         self.conv_out = GLUMBConv(in_channels, in_channels)
 
     def forward(self, x, temb=None):
-        return self.conv_out(self.attn(x))
+        return self.conv_out(self.attn(x, temb))
 
 
-def get_block(block_type, channels, attention_head_dim, act_fn, qkv_multiscales):
+def get_block(block_type, channels, attention_head_dim, act_fn, qkv_multiscales, temb_channels=None):
     if block_type == "ResBlock":
-        return ResBlock(channels, channels, act_fn)
+        return ResBlock(channels, channels, act_fn, temb_channels=temb_channels)
     if block_type == "EfficientViTBlock":
-        return EfficientViTBlock(channels, attention_head_dim, tuple(qkv_multiscales))
+        return EfficientViTBlock(channels, attention_head_dim, tuple(qkv_multiscales), temb_channels=temb_channels)
     raise ValueError(f"Block with {block_type=} is not supported.")
 
 
@@ -198,7 +232,8 @@ class DCUpBlock2d(nn.Module):
 class Encoder(nn.Module):
     """models/DCAE.py:539-631"""
 
-    def __init__(self, in_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales):
+    def __init__(self, in_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales,
+                 temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
         assert layers_per_block[0] > 0
@@ -206,7 +241,7 @@ class Encoder(nn.Module):
         self.down_blocks = nn.ModuleList()
         for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
             for _ in range(nl):
-                self.down_blocks.append(get_block(block_type[i], ch, attention_head_dim, "silu", qkv_multiscales[i]))
+                self.down_blocks.append(get_block(block_type[i], ch, attention_head_dim, "silu", qkv_multiscales[i], temb_channels))
             if i < n - 1 and nl > 0:
                 self.down_blocks.append(DCDownBlock2d(ch, block_out_channels[i + 1], shortcut=True))
         self.conv_out = SphereConv2d(block_out_channels[-1], latent_channels, 3, 1, 1)
@@ -224,7 +259,7 @@ class Decoder(nn.Module):
     """models/DCAE.py:634-732"""
 
     def __init__(self, out_channels, latent_channels, attention_head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, act_fn="silu",
-                 upsample_block_type="pixel_shuffle"):
+                 upsample_block_type="pixel_shuffle", temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
         assert layers_per_block[0] > 0
@@ -235,7 +270,7 @@ class Decoder(nn.Module):
             if i < n - 1 and nl > 0:
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True, interpolate=upsample_block_type == "interpolate"))  # models/DCAE.py:677-682
             for _ in range(nl):
-                self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i]))
+                self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i], temb_channels))
         ch0 = block_out_channels[0]
         self.norm_out = RMSNorm(ch0, 1e-7, elementwise_affine=True, bias=True)
         self.conv_out = SphereConv2d(ch0, out_channels, 3, 1, 1)
@@ -293,8 +328,6 @@ class AutoencoderDC(nn.Module):
         static_channels: int = 0,
     ):
         super().__init__()
-        if temb_channels is not None:
-            raise NotImplementedError("timestep-conditioned DCAE is not on the shipped-config path")
         if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
             # (downsample_block_type "conv" builds a stride-2 SphereConv2d, which the reference's SphereConv2d refuses: sphere_conv.py asserts stride 1)
             raise NotImplementedError("sampling: pixel_unshuffle down, pixel_shuffle | interpolate up")
@@ -305,7 +338,8 @@ class AutoencoderDC(nn.Module):
         ebt = (encoder_block_types,) * n if isinstance(encoder_block_types, str) else tuple(encoder_block_types)
         dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
         self.encoder = Encoder(
-            in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales
+            in_channels, latent_channels, attention_head_dim, ebt, encoder_block_out_channels, encoder_layers_per_block, encoder_qkv_multiscales,
+            temb_channels=temb_channels,
         )
         self.decoder = Decoder(
             out_channels if out_channels is not None else in_channels,
@@ -316,7 +350,10 @@ class AutoencoderDC(nn.Module):
             decoder_layers_per_block,
             decoder_qkv_multiscales,
             upsample_block_type=upsample_block_type,
+            temb_channels=temb_channels,
         )
+        # models/DCAE.py:845-850: Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) (no parameters) + TimestepEmbedding(256, temb_channels)
+        self.timestep_embedder = TimestepEmbedding(256, temb_channels) if temb_channels is not None else None
         self.spatial_compression_ratio = 2 ** (n - 1)
         self.static_channels = static_channels
         self.use_slicing = False
@@ -334,20 +371,28 @@ class AutoencoderDC(nn.Module):
     def from_config(cls, cfg: dict):
         return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
 
+    def _embed_t(self, temb, embedded_t):
+        """models/DCAE.py:982-984,1036-1038: a raw timestep goes through time_proj (sinusoid, 256) + timestep_embedder unless already embedded"""
+        if temb is not None and not embedded_t:
+            temb = self.timestep_embedder(get_timestep_embedding(temb, 256))
+        return temb
+
     def encode(self, x, return_dict=True, temb=None, embedded_t=False, static_conditioning_tensor=None):
+        temb = self._embed_t(temb, embedded_t)
         if static_conditioning_tensor is not None:
             x = torch.cat((x, static_conditioning_tensor), dim=1)
         if self.use_slicing and x.shape[0] > 1:
             raise NotImplementedError("Slicing is not supported for encoding.")
-        z = self.encoder(x, None)
+        z = self.encoder(x, temb)
         if not return_dict:
             return (z,)
         return SimpleNamespace(latent=z)
 
     def decode(self, z, return_dict=True, temb=None, embedded_t=False, return_static=False):
+        temb = self._embed_t(temb, embedded_t)
         if self.use_slicing and z.size(0) > 1:
             raise NotImplementedError("Slicing is not supported for decoding.")
-        y = self.decoder(z, None)
+        y = self.decoder(z, temb)
         if not return_static and self.static_channels is not None:
             y = y[:, : -self.static_channels, :, :]
         if not return_dict:
@@ -355,8 +400,9 @@ class AutoencoderDC(nn.Module):
         return SimpleNamespace(sample=y)
 
     def forward(self, sample, return_dict=True, time_elapsed=None, static_conditioning_tensor=None, return_static=False):
-        z = self.encode(sample, return_dict=False, static_conditioning_tensor=static_conditioning_tensor)[0]
-        y = self.decode(z, return_dict=False, return_static=return_static)[0]
+        temb = self._embed_t(time_elapsed, False)  # models/DCAE.py:1067-1071
+        z = self.encode(sample, return_dict=False, temb=temb, embedded_t=True, static_conditioning_tensor=static_conditioning_tensor)[0]
+        y = self.decode(z, return_dict=False, temb=temb, embedded_t=True, return_static=return_static)[0]
         if not return_dict:
             return (y,)
         return SimpleNamespace(sample=y)

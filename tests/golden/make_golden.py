@@ -298,32 +298,51 @@ def dcae_forward_fixtures():
     _ref_classes(R, ["SanaMultiscaleAttnProcessor2_0"], ns)
     methods = {"SanaMultiscaleLinearAttention": ["apply_linear_attention", "forward"], "GLUMBConv": ["forward"], "ResBlock": ["forward"],
                "EfficientViTBlock": ["forward"], "DCDownBlock2d": ["forward"], "DCUpBlock2d": ["forward"], "Encoder": ["forward"], "Decoder": ["forward"],
-               "AutoencoderDC": ["_encode", "encode", "_decode", "decode", "forward"]}
+               "AutoencoderDC": ["_encode", "encode", "_decode", "decode", "forward"], "AdaLayerNormZeroSingle4Sana": ["forward"]}
     from types import SimpleNamespace
 
     ns["EncoderOutput"] = lambda latent: SimpleNamespace(latent=latent)
     ns["DecoderOutput"] = lambda sample: SimpleNamespace(sample=sample)
     _ref_functions(R, [], ns, class_methods=methods)
 
+    class FP32LayerNormNoAffine(nn.Module):  # diffusers FP32LayerNorm(C, elementwise_affine=False, eps): layer_norm in fp32, cast back
+        def __init__(self, dim, eps):
+            super().__init__()
+            self.dim, self.eps = dim, eps
+
+        def forward(self, x):
+            return F.layer_norm(x.float(), (self.dim,), None, None, self.eps).to(x.dtype)
+
+    def bind(ae, temb):
+        """the reference's forward methods onto the oracle's containers; temb: the timestep-conditioned variant keeps its time_emb_porj /
+        norm_in sub-modules (the shipped config's containers get the None the reference's constructors would set)"""
+        from oracle.layers import get_timestep_embedding
+
+        no_t = {} if temb else dict(norm_in=None, time_emb_porj=None)
+        shims = {
+            OD.SanaMultiscaleLinearAttention: dict(norm_type="rms_norm", nonlinearity=nn.ReLU(), processor=ns["SanaMultiscaleAttnProcessor2_0"](), **no_t),
+            OD.GLUMBConv: dict(nonlinearity=nn.SiLU(), norm_type="rms_norm", residual_connection=True),
+            OD.ResBlock: dict(norm_type="rms_norm", **({} if temb else dict(time_emb_porj=None))),
+            OD.EfficientViTBlock: {}, OD.DCDownBlock2d: dict(downsample=True), OD.DCUpBlock2d: dict(interpolate=False),
+            OD.Encoder: dict(out_shortcut=True), OD.Decoder: dict(in_shortcut=True, conv_act=nn.ReLU()),
+            OD.AutoencoderDC: dict(time_proj=(lambda t: get_timestep_embedding(t, 256))) if temb else {},
+            OD.AdaLayerNormZeroSingle4Sana: dict(silu=nn.SiLU()),
+        }
+        bound = 0
+        for mod in ae.modules():
+            for cls, attrs in shims.items():
+                if type(mod) is cls:
+                    for k, v in attrs.items():
+                        object.__setattr__(mod, k, v)  # plain attributes (not registered sub-modules: the state dict stays the oracle's)
+                    if cls is OD.AdaLayerNormZeroSingle4Sana:
+                        object.__setattr__(mod, "norm", FP32LayerNormNoAffine(mod.embedding_dim, 1e-15))
+                    for meth in methods[cls.__name__]:
+                        object.__setattr__(mod, meth, types.MethodType(ns[f"{cls.__name__}_{meth}"], mod))
+                    bound += 1
+        return bound
+
     ae = make_dcae(tiny_dcae_config())
-    shims = {
-        OD.SanaMultiscaleLinearAttention: dict(norm_type="rms_norm", nonlinearity=nn.ReLU(), norm_in=None, time_emb_porj=None,
-                                               processor=ns["SanaMultiscaleAttnProcessor2_0"]()),
-        OD.GLUMBConv: dict(nonlinearity=nn.SiLU(), norm_type="rms_norm", residual_connection=True),
-        OD.ResBlock: dict(norm_type="rms_norm", time_emb_porj=None),
-        OD.EfficientViTBlock: {}, OD.DCDownBlock2d: dict(downsample=True), OD.DCUpBlock2d: dict(interpolate=False),
-        OD.Encoder: dict(out_shortcut=True), OD.Decoder: dict(in_shortcut=True, conv_act=nn.ReLU()), OD.AutoencoderDC: {},
-    }
-    bound = 0
-    for mod in ae.modules():
-        for cls, attrs in shims.items():
-            if type(mod) is cls:
-                for k, v in attrs.items():
-                    object.__setattr__(mod, k, v)  # plain attributes (not registered sub-modules: the state dict stays the oracle's)
-                for meth in methods[cls.__name__]:
-                    object.__setattr__(mod, meth, types.MethodType(ns[f"{cls.__name__}_{meth}"], mod))
-                bound += 1
-    assert bound >= 12, bound
+    assert bind(ae, False) >= 12
     f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
     with torch.no_grad():  # AutoencoderDC.encode / decode / forward are the reference's too (models/DCAE.py:948-1087)
         z = ae.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
@@ -331,7 +350,19 @@ def dcae_forward_fixtures():
         y_nostatic = ae.decode(z, return_dict=False)[0]
         full = ae.forward(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).sample
     assert y_nostatic.shape[1] == y.shape[1] - 5 and torch.equal(full, y_nostatic)
-    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy(), y_nostatic=y_nostatic.numpy())
+    # round 5: the timestep-conditioned variant (temb_channels; models/DCAE.py:36-64,147-153,193-198,256-257,351-365,845-850,982-984,1067-1071):
+    # ResBlock scale / shift, AdaLayerNormZeroSingle4Sana + gate in the linear-attention blocks, raw timesteps through time_proj +
+    # timestep_embedder in encode / decode, `time_elapsed` in forward - all the reference's own code; Timesteps / TimestepEmbedding /
+    # FP32LayerNorm are diffusers leaves (the oracle's restatements)
+    aet = make_dcae(dict(tiny_dcae_config(), temb_channels=48))
+    assert bind(aet, True) >= 16
+    tt = torch.tensor([0.3, 1.7])
+    with torch.no_grad():
+        zt = aet.encode(f, temb=tt, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        yt = aet.decode(zt, temb=tt, return_static=True).sample
+        fullt = aet.forward(f, time_elapsed=tt, static_conditioning_tensor=st.expand(2, -1, -1, -1), return_static=True).sample
+    assert torch.equal(fullt, yt) and (zt - z).abs().max() > 0.1
+    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy(), y_nostatic=y_nostatic.numpy(), z_temb=zt.numpy(), y_temb=yt.numpy())
 
 
 def _strip_inner_imports(fn_node):

@@ -144,3 +144,49 @@ def test_product_dcae_reproduces_the_reference_forward_code(golden_dir):
         rec = g.decode(zz, return_static=True).sample
         plain = g.decode(zz).sample
         assert _rel(lat, torch.from_numpy(z["z"])) < tol and _rel(rec, torch.from_numpy(z["y"])) < tol and _rel(plain, torch.from_numpy(z["y_nostatic"])) < tol
+
+
+def test_product_timestep_conditioned_dcae_reproduces_the_reference_forward_code(golden_dir):
+    """`temb_channels` (round 5; models/DCAE.py:36-64,147-153,193-198,256-257,351-365,845-850,982-984,1067-1085): the timestep-conditioned ResBlock
+    (scale / shift between its convs) and linear-attention block (AdaLayerNormZeroSingle4Sana before, gate after), raw timesteps through
+    time_proj + timestep_embedder.  The HIP autoencoder with the oracle's seeded weights (strict load: same parameter names) against the
+    fixture made by the REFERENCE's forward code (`z_temb`, `y_temb` of dcae_forward_ref.npz), three arithmetic modes, eager and graph;
+    `forward(time_elapsed=...)`; an already-embedded temb; and the error for a missing temb."""
+    import pytest
+
+    from ladcast_amd.models import AutoencoderDC
+    from tests.synth import make_dcae, synth_field, tiny_dcae_config
+
+    z = np.load(f"{golden_dir}/dcae_forward_ref.npz")
+    cfg = dict(tiny_dcae_config(), temb_channels=48)
+    o = make_dcae(cfg)
+    g = AutoencoderDC.from_config(cfg)
+    g.load_state_dict(o.state_dict(), strict=True)
+    g = g.cuda().eval()
+    f, st = synth_field(2, 8, 48, 64).cuda(), synth_field(1, 5, 48, 64, seed=1).cuda()
+    tt = torch.tensor([0.3, 1.7]).cuda()
+    zt, yt = torch.from_numpy(z["z_temb"]), torch.from_numpy(z["y_temb"])
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 2e-2)):
+        g.set_gemm_precision(prec)
+        lat = g.encode(f, temb=tt, static_conditioning_tensor=st).latent
+        rec = g.decode(zt.cuda(), temb=tt, return_static=True).sample
+        e1, e2 = _rel(lat, zt), _rel(rec, yt)
+        print(f"\ntimestep-conditioned tiny DC-AE [{prec}]: encode {e1:.2e}, decode {e2:.2e}")
+        assert e1 < tol and e2 < tol, (prec, e1, e2)
+        g.enable_hip_graph(True)
+        assert torch.equal(g.encode(f, temb=tt, static_conditioning_tensor=st).latent, lat) and torch.equal(g.decode(zt.cuda(), temb=tt, return_static=True).sample, rec)
+        g.enable_hip_graph(False)
+    g.set_gemm_precision("fp32")
+    full = g(f, time_elapsed=tt, static_conditioning_tensor=st, return_static=True).sample
+    assert _rel(full, yt) < 5e-5  # decode of its OWN latent: both halves' errors
+    with torch.no_grad():  # an already-embedded temb (embedded_t=True), as AutoencoderDC.forward hands it to encode / decode
+        from oracle.layers import get_timestep_embedding
+
+        emb = o.timestep_embedder(get_timestep_embedding(tt.cpu(), 256)).cuda()
+    assert _rel(g.encode(f, temb=emb, embedded_t=True, static_conditioning_tensor=st).latent, zt) < 2e-5
+    with pytest.raises(ValueError):
+        g.encode(f, static_conditioning_tensor=st)  # built with temb_channels: the blocks need it
+    plain = AutoencoderDC.from_config(tiny_dcae_config()).cuda().eval()
+    with pytest.raises(ValueError):
+        plain.decode(torch.zeros(1, 8, 6, 8).cuda(), temb=tt[:1])  # and the unconditioned model refuses one
+

@@ -182,3 +182,14 @@ def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
     for got, name in ((lat, "z"), (rec, "y"), (plain, "y_nostatic")):
         want = torch.from_numpy(z[name])
         assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
+    # round 5: the timestep-conditioned variant (temb_channels), raw timesteps in encode / decode and `time_elapsed` in forward
+    aet = make_dcae(dict(tiny_dcae_config(), temb_channels=48))
+    tt = torch.tensor([0.3, 1.7])
+    with torch.no_grad():
+        zt = aet.encode(f, temb=tt, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        yt = aet.decode(zt, temb=tt, return_static=True).sample
+        ft = aet(f, time_elapsed=tt, static_conditioning_tensor=st.expand(2, -1, -1, -1), return_static=True).sample
+    for got, name in ((zt, "z_temb"), (yt, "y_temb"), (ft, "y_temb")):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
+    assert ((zt - lat).norm() / lat.norm()).item() > 1e-2  # the conditioning really changes the latent
