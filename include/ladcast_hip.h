@@ -188,6 +188,14 @@ int ldc_linear_small_grouped(const ldc_linear_small_problem* problems, int n, vo
  * ------------------------------------------------------------------------- */
 int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
                  int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream);
+/* (ABI 4) the same with a workspace of ldc_attn_fwd_workspace_bytes() bytes (16-byte aligned, ZERO-FILLED ONCE by the caller, one per
+ * stream: the launch leaves its counters zero).  With it, a launch whose query blocks x heads x batch do not fill whole rounds of the 256
+ * CUs is cut into one contiguous range of (unit, key tile) items per CU - 216 units (one member of the 375M model) take 0.84 of a round,
+ * 288 / 432 units 1.13 / 1.69 rounds instead of two; pieces of a unit meet through write-through slabs and are combined by the last
+ * arriver in range order (bitwise reproducible).  workspace == NULL (or too small): the one-unit-per-workgroup grids of ldc_attn_fwd. */
+long long ldc_attn_fwd_workspace_bytes(void);
+int ldc_attn_fwd_ws(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv, long long qkv_bs,
+                    int ldo, long long o_bs, const float* key_bias, void* workspace, long long workspace_bytes, void* stream);
 
 /* (ABI 2: the second-generation split attention - ldc_attn_pack_bf16x3 / ldc_attn_fwd_packed_bf16x3 / ldc_attn_packed_bytes, a
  * pack pass writing LDS tile images + the attention on them - was removed; ldc_attn_qkv_prepare_split / the fused QKV epilogue +

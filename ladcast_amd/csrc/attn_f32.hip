@@ -23,6 +23,12 @@
 // the first half of the key tiles and waves 4-7 the second, each group through its own double buffer (133 KiB, one workgroup per CU),
 // merged through LDS at the end - as in attn_split.hip.  With one 4-wave workgroup per CU every SIMD held a single wave, whose MFMAs
 // waited for its own softmax and LDS traffic (0.59 of the fp32 matrix peak); two waves per SIMD overlap them.
+// BAL (round 5, needs the caller's workspace): the launch's (unit, key tile) items are cut into one contiguous range per CU - 216 units of
+// 71 key tiles (one member of the 375M model) are 59.9 tiles for each of 256 workgroups instead of 71 for 216 of them.  A range covers
+// the end of one unit and the start of the next ("pieces"): each piece runs the same two-group sweep over its tiles, a piece that is not a
+// whole unit publishes its un-normalised (O, m, l) in a write-through slab, takes a ticket on the unit's counter, and the piece with the
+// last ticket re-reads ALL pieces of the unit in range order (bitwise reproducible whatever the arrival order), normalises and stores -
+// the hand-off of gemm_bf16x3_v3.hip's stream-K cut.
 #include "common.h"
 
 namespace {
@@ -43,10 +49,23 @@ struct AttnArgs {
   float qscale;
   int nq;  // query blocks per (batch, head)
   const float* kbias;  // additive per-key score bias (an SDPA float mask that only depends on the key), [S] or nullptr
+  // BAL: range g = tile-items [g * upg + min(g, urem), ...) of the launch's units x nt items; slabs [2 G][SLAB_FLOATS]; one counter per unit
+  int nt;
+  unsigned upg, urem;
+  float* ws;
+  unsigned* counters;
 };
+constexpr int SLAB_FLOATS = 66 * 256;  // [64 O values + m + l][256 threads of key group 0]
 
-template <int NGRP>
+__device__ __forceinline__ unsigned range_start(unsigned g, const AttnArgs& p) { return g * p.upg + (g < p.urem ? g : p.urem); }
+__device__ __forceinline__ unsigned range_of(unsigned x, const AttnArgs& p) {  // the range that holds tile-item x
+  const unsigned big = p.urem * (p.upg + 1);
+  return x < big ? x / (p.upg + 1) : p.urem + (x - big) / p.upg;
+}
+
+template <int NGRP, bool BAL = false>
 __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_kernel(AttnArgs p) {
+  static_assert(!BAL || NGRP == 2, "the balanced schedule runs the 8-wave form");
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int grp = NGRP == 2 ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 8) : 0;  // key-range group (wave-uniform)
   float* const smem = smem_all + grp * 2 * STAGE;
@@ -59,17 +78,32 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
   // XCD-aware placement (speed only): the query blocks of one (batch, head) re-read the same K/V (2.3 MB at
   // S = 2250), so lay the 1-D grid out as [batch][head][query block] and give each XCD a contiguous run of it
   // (blocks are dealt round-robin over the 8 XCDs; bijective remap for any grid size).
-  int head, b, qblk;
+  // BAL: the same numbering over the ranges - an XCD's workgroups sweep consecutive units
+  int lin;
   {
-    const int nq = p.nq, T = gridDim.x;
+    const int T = gridDim.x;
     const int bid = blockIdx.x;
     const int q = T >> 3, r = T & 7, xcd = bid & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    qblk = lin % nq;
-    const int hb = lin / nq;
-    head = hb % p.H;
-    b = hb / p.H;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  const int nt = (S + KT - 1) / KT;
+  unsigned u = 0, u_end = 0, u_first = 0;
+  if constexpr (BAL) {
+    u_first = u = range_start(static_cast<unsigned>(lin), p);
+    u_end = range_start(static_cast<unsigned>(lin) + 1u, p);
+  }
+  do {  // BAL: the pieces of this workgroup's range; otherwise one pass = one whole unit
+  int unit = lin, t_lo = 0, t_hi = nt;
+  if constexpr (BAL) {
+    unit = static_cast<int>(u / static_cast<unsigned>(nt));
+    t_lo = static_cast<int>(u) - unit * nt;
+    const int left = static_cast<int>(u_end - u);
+    t_hi = t_lo + left < nt ? t_lo + left : nt;
+  }
+  const int qblk = unit % p.nq;
+  const int hb = unit / p.nq;
+  const int head = hb % p.H;
+  const int b = hb / p.H;
   const int q0 = qblk * QB + wave * 32;
 
   const long long base = static_cast<long long>(b) * p.qkv_bs + static_cast<long long>(head) * HD;
@@ -131,10 +165,10 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
   float m_run = -1.0e30f;
   float l_run = 0.f;
 
-  const int nt = (S + KT - 1) / KT;
-  const int nhalf = NGRP == 2 ? (nt + 1) >> 1 : nt;  // iterations of the longer group
-  const int t_begin = grp ? nhalf : 0;
-  const int t_end = grp ? nt : nhalf;                // group 1 may have one tile fewer (or none)
+  const int nspan = t_hi - t_lo;                             // key tiles of this pass (all of the unit's unless BAL)
+  const int nhalf = NGRP == 2 ? (nspan + 1) >> 1 : nspan;  // iterations of the longer group
+  const int t_begin = t_lo + (grp ? nhalf : 0);
+  const int t_end = grp ? t_hi : t_lo + nhalf;             // group 1 may have one tile fewer (or none)
   if (t_begin < t_end) {
     gload(t_begin * KT);
     sstore(0);
@@ -231,36 +265,113 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
       xch[65 * 256] = l_run;
     }
     __syncthreads();
-    if (grp == 1) return;
-    const float m1 = xch[64 * 256], l1 = xch[65 * 256];
-    const float m = fmaxf(m_run, m1);
-    const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
-    l_run = l_run * a0 + l1 * a1;
+    if constexpr (!BAL) {
+      if (grp == 1) return;
+    }
+    if (grp == 0) {
+      const float m1 = xch[64 * 256], l1 = xch[65 * 256];
+      const float m = fmaxf(m_run, m1);
+      const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
+      l_run = l_run * a0 + l1 * a1;
+      m_run = m;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(d * 16 + r) * 256] * a1;
+        for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(d * 16 + r) * 256] * a1;
+    }
   }
 
   // ---- normalise and store: lane holds O[q0+l31][32d + 8g + 4half + (0..3)] in o[d][4g..4g+3]
-  const int qrow = q0 + l31;
-  if (qrow < S) {
-    const float inv = 1.0f / l_run;
-    float* op = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD + 4 * half;
+  auto store_rows = [&]() {
+    const int qrow = q0 + l31;
+    if (qrow < S) {
+      const float inv = 1.0f / l_run;
+      float* op = p.O + static_cast<long long>(b) * p.o_bs + static_cast<long long>(qrow) * p.ldo + head * HD + 4 * half;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+          *reinterpret_cast<float4*>(op + 32 * d + 8 * g) = v;
+        }
+    }
+  };
+  if constexpr (!BAL) {
+    store_rows();
+  } else {
+    if (t_lo == 0 && t_hi == nt) {  // (workgroup-uniform) a whole unit inside the range
+      if (grp == 0) store_rows();
+    } else {
+      // publish this piece: write-through slab, drained, ONE ticket per workgroup on the unit's counter
+      const unsigned slot_id = 2u * static_cast<unsigned>(lin) + (u != u_first ? 1u : 0u);
+      if (grp == 0) {
+        float* slot = p.ws + static_cast<long long>(slot_id) * SLAB_FLOATS + tid;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) __hip_atomic_store(slot + (d * 16 + r) * 256, o[d][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 64 * 256, m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 65 * 256, l_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned f = static_cast<unsigned>(unit) * static_cast<unsigned>(nt);
+      const unsigned g_first = range_of(f, p), g_last = range_of(f + static_cast<unsigned>(nt) - 1u, p);
+      unsigned* flag = reinterpret_cast<unsigned*>(smem_all + SLAB_FLOATS);  // behind the exchange area, ring memory (idle)
+      if (threadIdx.x == 0) {
+        unsigned* cnt = p.counters + unit;
+        const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = (ticket == g_last - g_first) ? 1u : 0u;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      if (*flag != 0u && grp == 0) {  // the last arriver: all pieces of the unit, in range order, from the slabs (its own too)
+        m_run = -1.0e30f;
+        l_run = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        for (unsigned gp = g_first; gp <= g_last; ++gp) {
+          const unsigned s0 = range_start(gp, p);
+          const float* sl = p.ws + static_cast<long long>(2u * gp + (s0 < f ? 1u : 0u)) * SLAB_FLOATS + tid;  // (slot 1: the piece does not start its range)
+          const float mi = sl[64 * 256], li = sl[65 * 256];
+          const float m = fmaxf(m_run, mi);
+          const float a0 = exp2f(m_run - m), a1 = exp2f(mi - m);
+          l_run = l_run * a0 + li * a1;
+          m_run = m;
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + sl[(d * 16 + r) * 256] * a1;
+        }
+        store_rows();
+      }
+    }
+    u += static_cast<unsigned>(nspan);
+    __syncthreads();  // exchange area / flag word are ring memory of the next piece
   }
+  } while (BAL && u < u_end);
 }
 
 }  // namespace
 
-extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
-                            int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream) {
+// workspace of the balanced schedule: [one counter per unit, zero between launches | 2 x 256 slabs].  The caller zero-fills it ONCE.
+constexpr long long BAL_MAX_UNITS = 65536;
+constexpr int BAL_G = 256;
+constexpr long long BAL_COUNTER_BYTES = BAL_MAX_UNITS * 4;
+extern "C" long long ldc_attn_fwd_workspace_bytes(void) {
+  return BAL_COUNTER_BYTES + 2LL * BAL_G * SLAB_FLOATS * static_cast<long long>(sizeof(float));
+}
+
+extern "C" int ldc_attn_fwd_ws(const float* Q, const float* K, const float* V, float* O, int B, int S, int H, int ld_qkv,
+                               long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* workspace,
+                               long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(Q);
   LDC_CHECK_PTR(K);
   LDC_CHECK_PTR(V);
@@ -276,23 +387,50 @@ extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, floa
              0.08838834764831845f * 1.4426950408889634f};  // 1/sqrt(128) * log2(e)
   p.nq = ldc_cdiv(S, QB);
   p.kbias = key_bias;
-  dim3 grid(static_cast<unsigned>(p.nq) * H * B);
-  // at most one workgroup per CU anyway -> 8 waves with the keys split over two wave groups; more -> 4 waves, two workgroups per CU
-  // NOTE the choice looks at the whole launch (B included), and the two forms add the key tiles in different orders: a member's fp32
-  // result can differ at rounding level (~1e-7) with how many members share the launch, like the stream-K cut of the GEMMs.  Partition
-  // independence of the sharded rollout is therefore "to fp32 rounding", bitwise only for equal per-rank batches (pipelines/distributed.py).
-  static const bool one_group_forced = LDC_AB_GETENV("LDC_ATTN_F32_ONE_GROUP") != nullptr;  // measurement aid, read once
-  const bool two = grid.x <= 256 && !one_group_forced;
-  const size_t lds = (two ? 4 : 2) * STAGE * sizeof(float);
+  p.nt = ldc_cdiv(S, KT);
+  const long long units = static_cast<long long>(p.nq) * H * B;
+  dim3 grid(static_cast<unsigned>(units));
   static const bool attr_set = [&] {  // once per process; thread-safe (C++11 static initialisation)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(2 * STAGE * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(4 * STAGE * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(4 * STAGE * sizeof(float)));
     return true;
   }();
   (void)attr_set;
+  // balanced schedule: whenever the units do not fill whole rounds of the 256 CUs (216 units: 0.84 of a round's time; 288 / 432 units:
+  // 1.13 / 1.69 rounds instead of two) and every range still holds a few key tiles
+  const long long items = units * p.nt;
+  bool bal = workspace != nullptr && workspace_bytes >= ldc_attn_fwd_workspace_bytes() && units <= BAL_MAX_UNITS && units % BAL_G != 0 &&
+             units <= 4 * BAL_G && items >= 8LL * BAL_G && items < (1LL << 31);
+  static const char* const force_bal = LDC_AB_GETENV("LDC_ATTN_F32_BAL");  // measurement aid, read once: 0 = never, 1 = whenever possible
+  if (force_bal) bal = workspace != nullptr && workspace_bytes >= ldc_attn_fwd_workspace_bytes() && units <= BAL_MAX_UNITS &&
+                       items >= 2LL * BAL_G && items < (1LL << 31) && atoi(force_bal) != 0;
+  if (bal) {
+    LDC_CHECK_ALIGN16(workspace);
+    p.counters = static_cast<unsigned*>(workspace);
+    p.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + BAL_COUNTER_BYTES);
+    p.upg = static_cast<unsigned>(items / BAL_G);
+    p.urem = static_cast<unsigned>(items % BAL_G);
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<2, true>), dim3(BAL_G), dim3(512), 4 * STAGE * sizeof(float), static_cast<hipStream_t>(stream), p);
+    return ldc_launch_status();
+  }
+  // at most one workgroup per CU anyway -> 8 waves with the keys split over two wave groups; more -> 4 waves, two workgroups per CU
+  // NOTE the choice looks at the whole launch (B included), and the forms add the key tiles in different orders: a member's fp32
+  // result can differ at rounding level (~1e-7) with how many members share the launch, like the stream-K cut of the GEMMs.  Partition
+  // independence of the sharded rollout is therefore "to fp32 rounding", bitwise only for equal per-rank batches (pipelines/distributed.py).
+  static const bool one_group_forced = LDC_AB_GETENV("LDC_ATTN_F32_ONE_GROUP") != nullptr;  // measurement aid, read once
+  const bool two = grid.x <= 256 && !one_group_forced;
+  const size_t lds = (two ? 4 : 2) * STAGE * sizeof(float);
   if (two) hipLaunchKernelGGL(attn_fwd_f32_kernel<2>, grid, dim3(512), lds, static_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(attn_fwd_f32_kernel<1>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return ldc_launch_status();
+}
+
+// without a workspace: the one-unit-per-workgroup grids
+extern "C" int ldc_attn_fwd(const float* Q, const float* K, const float* V, float* O, int B, int S, int H,
+                            int ld_qkv, long long qkv_bs, int ldo, long long o_bs, const float* key_bias, void* stream) {
+  return ldc_attn_fwd_ws(Q, K, V, O, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, key_bias, nullptr, 0, stream);
 }

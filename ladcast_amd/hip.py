@@ -84,6 +84,8 @@ def _load():
         "ldc_linear_small_mod": (I, [P, I, P, P, P, I, P, I, P, I, I, I, I, I, P]),
         "ldc_gate_residual_layernorm": (I, [P, P, P, P, I, I, I, I, L, I, L, I, I, L, P, P, F, I, P]),
         "ldc_attn_fwd": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P]),
+        "ldc_attn_fwd_ws": (I, [P, P, P, P, I, I, I, I, L, I, L, P, P, L, P]),
+        "ldc_attn_fwd_workspace_bytes": (L, []),
         "ldc_qk_rmsnorm_rope": (I, [P, P, I, I, I, I, I, L, P, P, F, P, P, P]),
         "ldc_sphere_conv_nhwc_split": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P]),
         "ldc_sphere_conv_plan": (I, [I, I, I, I, I, I, I, P, P]),
@@ -281,12 +283,35 @@ def linear_small_grouped(problems):
     _check(lib.ldc_linear_small_grouped(arr, n, _stream()), "ldc_linear_small_grouped")
 
 
-def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, key_bias=None):
-    """exact-fp32 attention on fp32 q / k / v views (ldc_attn_fwd); key_bias: [S] additive score bias per key (or None)"""
+_attn_f32_ws = {}
+
+
+def _attn_f32_workspace(device):
+    """counters + slabs of the exact-fp32 attention's balanced schedule (ldc_attn_fwd_ws), one per (device, stream), zero-filled once
+    (the launches leave the counters zero) and never replaced: captured hipGraphs hold its pointer.  As `_attn_workspace`: the first
+    call on a stream must be made outside a capture."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _attn_f32_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attn_fwd: the first call on a stream must be made outside a graph capture (run one warm-up forward)")
+        ws = torch.zeros((lib.ldc_attn_fwd_workspace_bytes() + 3) // 4, device=device, dtype=torch.float32)
+        _attn_f32_ws[key] = ws
+    return ws
+
+
+def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, key_bias=None, use_workspace=True):
+    """exact-fp32 attention on fp32 q / k / v views (ldc_attn_fwd_ws); key_bias: [S] additive score bias per key (or None).
+    use_workspace=False: never the balanced schedule (ldc_attn_fwd; A/B, tests)"""
     _dev(Q, K, V, O, key_bias)
     if key_bias is not None and key_bias.numel() < S:
         raise ValueError("key_bias must hold one value per key")
-    _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _stream()), "ldc_attn_fwd")
+    if not use_workspace:
+        _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _stream()), "ldc_attn_fwd")
+        return
+    ws = _attn_f32_workspace(Q.device)
+    _check(lib.ldc_attn_fwd_ws(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _p(ws), ws.numel() * 4, _stream()),
+           "ldc_attn_fwd_ws")
 
 
 _score_ws = {}

@@ -261,3 +261,16 @@ def test_gemv_first_read_guard_is_in_the_shipped_kernels():
     uses = [ln for ln in mk.splitlines() if "LDC_LS_NO_FIRST_READ" in ln and not ln.lstrip().startswith("#")]
     assert len(uses) == 1 and "first_read_repro" not in uses[0] and "$(REPRO_F)" in uses[0] and "$@" in uses[0]
     assert "first_read_repro_unguarded:" in mk
+
+
+def test_bare_make_builds_the_library():
+    """`__graft_entry__.build()` runs `make -C ladcast_amd/csrc` with no target: the FIRST rule of the Makefile must lead to the shared
+    library (an earlier revision had put the reproducer's rule first - a bare make then left a stale libladcast_hip.so in place)."""
+    import re
+    import subprocess
+
+    mk = open(os.path.join(ROOT, "ladcast_amd", "csrc", "Makefile")).read()
+    first = next(ln for ln in mk.splitlines() if re.match(r"^[A-Za-z_$(][^=\t]*:(?!=)", ln))
+    assert first.startswith("default: all"), first
+    plan = subprocess.run(["make", "-n", "-B", "-C", os.path.join(ROOT, "ladcast_amd", "csrc")], capture_output=True, text=True, check=True).stdout
+    assert "-o ../libladcast_hip.so" in plan and "attn_f32.hip" in plan and "conv_halo.hip" in plan
