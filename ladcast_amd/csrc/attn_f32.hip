@@ -400,11 +400,13 @@ extern "C" int ldc_attn_fwd_ws(const float* Q, const float* K, const float* V, f
     return true;
   }();
   (void)attr_set;
-  // balanced schedule: whenever the units do not fill whole rounds of the 256 CUs (216 units: 0.84 of a round's time; 288 / 432 units:
-  // 1.13 / 1.69 rounds instead of two) and every range still holds a few key tiles
+  // balanced schedule: whenever the units do not fill whole rounds of the 256 CUs and every range still holds two key tiles.  Measured
+  // (profiles/r05_m_attn_f32_balanced.log, us plain -> balanced): 216 units (one 375M member) 317 -> 285, 288 (1.6B) 603 -> 376, 432 (two
+  // members) 606 -> 549, 864 1196 -> 1084; 48 units of 15 tiles (the refiner's 450 tokens) 74 -> 33, 24 units of 32 tiles 146 -> 42.  Whole
+  // rounds (256, 512 units) and long launches (1728 units) are as fast or faster on the plain grids (4 waves, two workgroups per CU).
   const long long items = units * p.nt;
   bool bal = workspace != nullptr && workspace_bytes >= ldc_attn_fwd_workspace_bytes() && units <= BAL_MAX_UNITS && units % BAL_G != 0 &&
-             units <= 4 * BAL_G && items >= 8LL * BAL_G && items < (1LL << 31);
+             units <= 4 * BAL_G && items >= 2LL * BAL_G && items < (1LL << 31);
   static const char* const force_bal = LDC_AB_GETENV("LDC_ATTN_F32_BAL");  // measurement aid, read once: 0 = never, 1 = whenever possible
   if (force_bal) bal = workspace != nullptr && workspace_bytes >= ldc_attn_fwd_workspace_bytes() && units <= BAL_MAX_UNITS &&
                        items >= 2LL * BAL_G && items < (1LL << 31) && atoi(force_bal) != 0;

@@ -340,6 +340,44 @@ def test_attention(hip, B, S, H):
     assert torch.isnan(out[:, :, D:]).all()  # pad columns untouched
 
 
+@pytest.mark.parametrize("B,S,H,bias", [(1, 2250, 12, False), (1, 2250, 16, True), (2, 700, 13, True), (1, 450, 12, False), (5, 300, 4, True), (8, 129, 7, False),
+                                         (3, 1000, 20, False)])
+def test_attention_f32_balanced_schedule(hip, B, S, H, bias):
+    """exact-fp32 attention with its workspace (ldc_attn_fwd_ws, round 5): the launch's (unit, key tile) items in one contiguous range per
+    CU, pieces of a unit combined by the last arriver.  216 units (one 375M member: every unit has 2 or 3 pieces), 288 (1.6B), 13.4-tile
+    ranges over 22-tile units (2 x 700 x 13), ranges that hold a whole unit between two partial ones (3 x 1000 x 20: 60 tiles per range,
+    32 per unit), ranges of 2 - 3 tiles (450 tokens: a unit's 15 tiles over ~5 workgroups; 5 x 300 x 4), two query blocks with one valid
+    row in the second (S = 129).  Against fp64 sdpa, bitwise repeatable (the
+    counters return to zero after every launch: 4 launches on the same workspace), and equal to fp32 rounding to the plain grids."""
+    D = H * 128
+    units, nt = -(-S // 128) * H * B, -(-S // 32)
+    assert units % 256 != 0 and units <= 1024 and units * nt >= 512, "shape does not take the balanced schedule"
+    qkv = rnd(B, S, 3 * D, seed=31)
+    qkv[..., :D] *= 2.0
+    kb = dev(0.5 * rnd(S, seed=32)) if bias else None
+    d_qkv = dev(qkv)
+    kw = dict(B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D + 64, o_bs=S * (D + 64), key_bias=kb)
+    outs = []
+    for rep in range(4):
+        o = torch.full((B, S, D + 64), float("nan"), device="cuda")
+        hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], o, **kw)
+        outs.append(o)
+    assert all(torch.equal(outs[0][:, :, :D], o[:, :, :D]) for o in outs[1:])
+    assert torch.isnan(outs[0][:, :, D:]).all() and torch.isfinite(outs[0][:, :, :D]).all()  # pad columns untouched, every row written
+    plain = torch.full((B, S, D + 64), float("nan"), device="cuda")
+    hip.attn_fwd(d_qkv[:, :, :D], d_qkv[:, :, D : 2 * D], d_qkv[:, :, 2 * D :], plain, use_workspace=False, **kw)
+    q, k, v = [t.reshape(B, S, H, 128).transpose(1, 2).double() for t in qkv.split(D, dim=-1)]
+    mask = None if kb is None else kb.cpu().double().view(1, 1, 1, S)
+    want = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, S, D)
+    assert rel(outs[0][:, :, :D], want) < 2e-6 and rel(plain[:, :, :D], want) < 2e-6
+    assert rel(outs[0][:, :, :D], plain[:, :, :D].cpu()) < 2e-6
+    assert not torch.equal(outs[0][:, :, :D], plain[:, :, :D])  # (it IS another schedule: the key tiles are summed in another grouping)
+    # the workspace's counter block is all zero again
+    ws = hip._attn_f32_workspace(d_qkv.device)
+    torch.cuda.synchronize()
+    assert int(ws[: 65536].view(torch.int32).abs().sum().item()) == 0
+
+
 def test_split_activation_producers(hip):
     """LayerNorm and the split attention can write their output in the split activation format: it must be the
     hi / lo split of exactly the fp32 values they write otherwise"""
