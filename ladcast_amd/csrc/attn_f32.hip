@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
   }
   __syncthreads();
 
+  // (tried in round 5 and dropped, profiles/r05_m_attn_f32_balanced.log: the two key groups half an iteration apart - a second barrier
+  // between the score phase and the softmax, group 1 one barrier late, so that one wave of a SIMD is in its softmax while the other issues
+  // MFMAs: 270.2 us against 271.3; a second score accumulator to break the 64-MFMA chain: 276 us)
   for (int it = 0; it < nhalf; ++it) {
     const int t = t_begin + it;
     if (t >= t_end) {  // (wave-uniform) the shorter group only keeps the barrier count
@@ -190,14 +193,52 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     const float* kb = Ks + l31 * KP + 4 * half;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float4 kf = *reinterpret_cast<const float4*>(kb + 8 * c);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c][0], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c][1], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c][2], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c][3], s, 0, 0, 0);
+    // K fragments three chunks ahead of their MFMAs (the 64 MFMAs are one dependent chain: a fragment read only one chunk ahead - what the
+    // compiler schedules from plain loads - leaves its LDS latency exposed every 8 MFMAs, in both waves of the SIMD at once: the barrier
+    // keeps the two key groups in step).  Hand-placed reads and counted waits; nothing else may move into this block.
+    {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const unsigned ka = static_cast<unsigned>(reinterpret_cast<unsigned long long>(kb));
+      f4v k0, k1, k2, k3;
+#define LDC_RDK(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ka), "n"(off) : "memory")
+#define LDC_MM4(kv, c)                                                          \
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[0], qf[c][0], s, 0, 0, 0);        \
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[1], qf[c][1], s, 0, 0, 0);        \
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[2], qf[c][2], s, 0, 0, 0);        \
+  s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[3], qf[c][3], s, 0, 0, 0);
+#define LDC_STEP(kv, knext, c, WAIT)                                            \
+  if ((c) + 3 < 16) LDC_RDK(knext, 32 * ((c) + 3 < 16 ? (c) + 3 : 15));         \
+  asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(kv));                      \
+  LDC_MM4(kv, c)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (whatever the compiler had in flight: the counted waits below start from zero)
+      LDC_RDK(k0, 0);
+      LDC_RDK(k1, 32);
+      LDC_RDK(k2, 64);
+      LDC_STEP(k0, k3, 0, 3)
+      LDC_STEP(k1, k0, 1, 3)
+      LDC_STEP(k2, k1, 2, 3)
+      LDC_STEP(k3, k2, 3, 3)
+      LDC_STEP(k0, k3, 4, 3)
+      LDC_STEP(k1, k0, 5, 3)
+      LDC_STEP(k2, k1, 6, 3)
+      LDC_STEP(k3, k2, 7, 3)
+      LDC_STEP(k0, k3, 8, 3)
+      LDC_STEP(k1, k0, 9, 3)
+      LDC_STEP(k2, k1, 10, 3)
+      LDC_STEP(k3, k2, 11, 3)
+      LDC_STEP(k0, k3, 12, 3)
+      LDC_STEP(k1, k0, 13, 2)
+      LDC_STEP(k2, k1, 14, 1)
+      LDC_STEP(k3, k2, 15, 0)
+      __builtin_amdgcn_sched_barrier(0);
+#undef LDC_STEP
+#undef LDC_MM4
+#undef LDC_RDK
     }
+    // the next tile's K / V go to their LDS stage now (it has been free since the barrier; the loads were issued a whole S phase ago):
+    // the 32 staging registers are dead through the softmax and the P.V phase
+    if (t + 1 < t_end) sstore((it + 1) & 1);
 
     // ---- online softmax over the key axis (registers + the other lane half) --
     const int key_base = t * KT + 4 * half;
@@ -220,11 +261,11 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
     for (int r = 1; r < 16; ++r) m_t = fmaxf(m_t, s[r]);
     m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
     const float m_new = fmaxf(m_run, m_t);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // (v_exp_f32: arguments <= 0; what would be denormal is 0)
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = exp2f(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       rs += s[r];
     }
     rs += __shfl_xor(rs, 32, 64);
@@ -238,18 +279,51 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
     }
 
     // ---- O^T += V^T . P^T ------------------------------------------------------
-    const float* vb = Vs + (4 * half) * HD + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kappa = (r & 3) + 8 * (r >> 2);
-      const float* vr = vb + kappa * HD;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 * d], s[r], o[d], 0, 0, 0);
-      }
+    // V fragments (one scalar per (key kappa, d tile): V[4 half + kappa][32 d + l31]) three keys ahead of their MFMAs, hand-placed like
+    // the K reads: ds_read2st64_b32 fetches the d / d + 2 pair of a key from one base (offsets in units of 256 B, all immediates)
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const unsigned va = static_cast<unsigned>(reinterpret_cast<unsigned long long>(Vs + (4 * half) * HD + l31));
+      const unsigned vb1 = va + 128u;  // d tiles 1 and 3
+      f2v a0, a1, a2, a3, b0, b1, b2, b3;
+#define LDC_KAPPA(r) (((r) & 3) + 8 * ((r) >> 2))
+#define LDC_RDV(da, db, r)                                                                                                             \
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(da) : "v"(va), "n"(2 * LDC_KAPPA(r)), "n"(2 * LDC_KAPPA(r) + 1) : "memory"); \
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(db) : "v"(vb1), "n"(2 * LDC_KAPPA(r)), "n"(2 * LDC_KAPPA(r) + 1) : "memory");
+#define LDC_PV(da, db, na, nb, r, WAIT)                                          \
+  if ((r) + 3 < 16) { LDC_RDV(na, nb, ((r) + 3 < 16 ? (r) + 3 : 15)) }           \
+  asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(da), "+v"(db));             \
+  o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[0], s[r], o[0], 0, 0, 0);       \
+  o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(db[0], s[r], o[1], 0, 0, 0);       \
+  o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[1], s[r], o[2], 0, 0, 0);       \
+  o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(db[1], s[r], o[3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging stores / softmax shuffles above: the counted waits start from zero
+      LDC_RDV(a0, b0, 0)
+      LDC_RDV(a1, b1, 1)
+      LDC_RDV(a2, b2, 2)
+      LDC_PV(a0, b0, a3, b3, 0, 6)
+      LDC_PV(a1, b1, a0, b0, 1, 6)
+      LDC_PV(a2, b2, a1, b1, 2, 6)
+      LDC_PV(a3, b3, a2, b2, 3, 6)
+      LDC_PV(a0, b0, a3, b3, 4, 6)
+      LDC_PV(a1, b1, a0, b0, 5, 6)
+      LDC_PV(a2, b2, a1, b1, 6, 6)
+      LDC_PV(a3, b3, a2, b2, 7, 6)
+      LDC_PV(a0, b0, a3, b3, 8, 6)
+      LDC_PV(a1, b1, a0, b0, 9, 6)
+      LDC_PV(a2, b2, a1, b1, 10, 6)
+      LDC_PV(a3, b3, a2, b2, 11, 6)
+      LDC_PV(a0, b0, a3, b3, 12, 6)
+      LDC_PV(a1, b1, a0, b0, 13, 4)
+      LDC_PV(a2, b2, a1, b1, 14, 2)
+      LDC_PV(a3, b3, a2, b2, 15, 0)
+      __builtin_amdgcn_sched_barrier(0);
+#undef LDC_PV
+#undef LDC_RDV
+#undef LDC_KAPPA
     }
 
-    if (t + 1 < t_end) sstore((it + 1) & 1);
     __syncthreads();
   }
 
