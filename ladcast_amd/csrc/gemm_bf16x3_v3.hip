@@ -750,6 +750,9 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
   };
   const int st = launch(problems, epi, n, small, true);
   if (st != LDC_SPLIT_GROUP) return st;
+  // (no partial output on a bad argument: launch_v3 returns LDC_SPLIT_GROUP only after it has validated EVERY problem of the group - the
+  // per-problem checks run before the cut is chosen - and the workspace checks that follow it fail on the first single launch, before
+  // anything has been queued)
   for (int i = 0; i < n; ++i) {  // the group has no good aligned cut: its problems one after the other (independent; same stream)
     const ldc_gemm_desc& d = problems[i].d;
     bool sm = static_cast<long long>(d.batch) * ldc_cdiv(d.M, 256) * ldc_cdiv(d.N, BN) < (force_thr ? atoll(force_thr) : 400);
