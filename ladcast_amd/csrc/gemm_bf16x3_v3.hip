@@ -149,9 +149,45 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     sg.bm = __builtin_amdgcn_readfirstlane(static_cast<int>(sr) * Q.rm + static_cast<int>(r_in - bn_ * h_sr));
     return sg;
   };
+  // Round 5 (exact-fp32 instances): the NEXT segment's first two k-steps leave for stages 0 / 1 as soon as this segment's loop has released the ring - before its
+  // epilogue / hand-off instead of after it: the 2.3 - 2.8 us between "tile done" and "first DMA of the next tile landed" (launch stamps,
+  // profiles/r04_x_gemm_launch_stamps.log) overlap the 2.8 - 4 us epilogue.  The sources are formed exactly as the segment's own prologue
+  // forms them (same order of issue); every static vmcnt below still holds - the epilogue's loads and stores are issued AFTER these DMAs,
+  // so a wait that leaves the N youngest operations outstanding covers at least what it covered before.
+  auto prefetch_next = [&](const Seg& sg) __attribute__((always_inline)) {
+    const DevProblem& Q = a.pr[sg.pi];
+    const int ln = fresh_lane();
+    const int lr_ = ln >> 3, lp_ = ln & 7;
+    const float* __restrict__ An = Q.A + static_cast<long long>(sg.b) * Q.d.a_bs;
+    const long long wrb = static_cast<long long>(Q.d.K) * (TERMS == 1 ? 2 : 4);
+    unsigned char* dump = smem + NSTAGE * STAGE_B + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool live = sg.k0 + j < sg.k1;
+      const long long koff = static_cast<long long>(live ? sg.k0 + j : sg.k1 - 1) * (BK * 4);
+      unsigned char* sA = smem + j * STAGE_B;
+      unsigned char* sW = sA + BM * ROW_B;
+#pragma unroll
+      for (int i = 0; i < NAI; ++i) {
+        const int r = 8 * (wave + 8 * i) + lr_;
+        int gm = sg.bm * BM + r;
+        gm = gm < Q.d.M ? gm : Q.d.M - 1;
+        dma16(reinterpret_cast<const unsigned char*>(An + static_cast<long long>(gm) * Q.d.lda) + ((lp_ ^ swz(r)) << 4) + koff,
+              live ? sA + (wave + 8 * i) * 1024 : dump);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (wave + 8 * i) + lr_;
+        int gn = sg.bn * BN + r;
+        gn = gn < Q.d.N ? gn : Q.d.N - 1;
+        dma16(Q.W + static_cast<long long>(gn) * wrb + ((lp_ ^ swz(r)) << 4) + koff, live ? sW + (wave + 8 * (i)) * 1024 : dump);
+      }
+    }
+  };
   long long u = u_begin;
   Seg cur{};
   if (u < u_end) cur = decode(u);
+  bool prefetched = false;  // (wave-uniform) this segment's prologue DMAs are already in flight
   while (u < u_end) {
     const int pi = cur.pi;
     const DevProblem& P = a.pr[pi];
@@ -397,10 +433,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #ifdef LDC_GEMM_STAMPS_PROLOGUE
     if (seg_ == 0) { LDC_STAMP(10) }
 #endif
+    if (!prefetched) {
 #pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
+      for (int i = 0; i < ND; ++i) issue_one(k0, 0, i);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+      for (int i = 0; i < ND; ++i) issue_one(k0 + 1, 1, i);
+    }
 #ifdef LDC_GEMM_STAMPS_PROLOGUE
     if (seg_ == 0) { LDC_STAMP(11) }
 #endif
@@ -447,6 +485,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #undef LDC_SB
     // all waves must be done reading the ring before the next segment's prologue overwrites stage 0/1
     __builtin_amdgcn_s_barrier();
+    prefetched = false;
+    // exact-fp32 mode only: measured same-box (profiles/r05_q_gemm_prologue_prefetch_ab.log) 3.051 -> 3.077 member-steps/s there (the chip
+    // is at 2.39 GHz / 1190 W: idle time is lost time) and nothing in the split mode (dual QKV 99.7 vs 100.3 us, chunk 109.5 vs 109.6 ms: at
+    // the power cap the gap's energy comes back as clock), where it also costs the 256-row instance 79 more spilled registers
+    if constexpr (!CONV && TERMS == 0) {
+#if !defined(LDC_GEMM_DIAG_NODMA) && !defined(LDC_GEMM_NO_PREFETCH)
+      if (u_next < u_end) {
+        prefetch_next(nxt);
+        prefetched = true;
+      }
+#endif
+    }
     if (seg_ == 0) { LDC_STAMP_CLK(14) }
     LDC_STAMP(2 + 4 * seg_)
 
@@ -472,7 +522,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       while (g_last + 1 < a.G && range_start(g_last + 1, a) < l) ++g_last;
       const unsigned pieces = static_cast<unsigned>(g_last - g_first + 1);
       unsigned* cnt = a.counters + (P.tile0 + tile);
-      unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle here (barrier above)
+      // (the ring may already hold the next segment's first k-steps: the flag lives in wave 0's dump slot behind the ring.  Thread 0
+      // writes it after its own vmcnt(0) above, so none of wave 0's clamped DMAs can land on it afterwards; the other waves' clamped
+      // DMAs go to their own slots)
+      unsigned* flag = reinterpret_cast<unsigned*>(smem + NSTAGE * STAGE_B);
       if (wave == 0 && lane_h == 0) {
         const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned last = (ticket == pieces - 1) ? 1u : 0u;
@@ -486,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       __syncthreads();
       LDC_STAMP(3 + 4 * seg_)
       const unsigned is_last = *flag;
-      __syncthreads();  // flag word is ring memory: everyone has read it before the next prologue's DMA lands
+      __syncthreads();  // everyone has read the flag word before wave 0's next clamped DMA can land on it
       if (is_last) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
