@@ -237,6 +237,13 @@ typedef struct ldc_qkv_epilogue {
 int ldc_sizeof_qkv_epilogue(void);
 int ldc_gemm_grouped_bf16x3_qkv(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
                                 long long workspace_bytes, void* stream);
+/* (ABI 4) exact-fp32 counterpart: the same grouped launch on fp32 operands (ldc_gemm_grouped's problems, flags 0) where problem i with
+ * epi[i].heads > 0 is a QKV projection whose epilogue applies bias -> per-head RMSNorm * weight -> adjacent-pair rotary embedding to the q
+ * and k heads (v: bias only) and writes PLAIN fp32 rows - what ldc_qk_rmsnorm_rope does in place afterwards, without its launches and its
+ * round trip (pass qscale = 1: ldc_attn_fwd scales q itself).  LDC_ERR_UNSUPPORTED (K % 32 != 0, strided weights, rows not 16-byte
+ * aligned): run ldc_gemm_grouped + ldc_qk_rmsnorm_rope. */
+int ldc_gemm_grouped_qkv_f32(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
+                             long long workspace_bytes, void* stream);
 int ldc_attn_qkv_prepare_split(float* Q, float* K, float* V, int B, int S, int H, int ld_qkv, long long qkv_bs, int split_row,
                                const float* wq0, const float* wk0, const float* cos0, const float* sin0, const float* wq1,
                                const float* wk1, const float* cos1, const float* sin1, float eps, void* stream);

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     LDC_STAMP(2 + 4 * seg_)
 
     if (k0 == 0 && k1 == P.kt) {
-      tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
+      tile_epilogue<BM, !CONV, LinearRows<BM>, true, TERMS == 0>(P, b, bm, bn, acc, wave, lane);
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
       // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][r] += sl[((wave * NACC + i) * 4 + r) * 64 + lane_h];
           }
         }
-        tile_epilogue<BM, !CONV>(P, b, bm, bn, acc, wave, lane);
+        tile_epilogue<BM, !CONV, LinearRows<BM>, true, TERMS == 0>(P, b, bm, bn, acc, wave, lane);
       }
     }
     u = u_next;
@@ -627,7 +627,11 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       auto al16 = [](const void* q_) { return (reinterpret_cast<unsigned long long>(q_) & 15ull) == 0; };
       if (d.N != 3 * e.heads * BN || d.act != LDC_ACT_NONE || q.gate != nullptr || q.R != nullptr) return LDC_ERR_ARG;
       if ((e.wq == nullptr) != (e.wk == nullptr) || e.reserved != nullptr || e.rope_row0 < 0) return LDC_ERR_ARG;
-      if ((d.ldc & 7) || (d.c_bs & 7) || (reinterpret_cast<unsigned long long>(q.C) & 31ull)) return LDC_ERR_ALIGN;
+      if constexpr (TERMS == 0) {  // plain fp32 rows out
+        if ((d.ldc & 3) || (d.c_bs & 3) || !al16(q.C)) return LDC_ERR_ALIGN;
+      } else {
+        if ((d.ldc & 7) || (d.c_bs & 7) || (reinterpret_cast<unsigned long long>(q.C) & 31ull)) return LDC_ERR_ALIGN;
+      }
       if (!al16(e.wq) || !al16(e.wk) || !al16(e.rope) || (q.bias && !al16(q.bias))) return LDC_ERR_ALIGN;
       P.qkv_heads = e.heads;
       P.rope_row0 = e.rope_row0;
@@ -818,7 +822,8 @@ static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epil
 
 // exact-fp32 grouped GEMM on the ring kernel (TERMS = 0); LDC_ERR_UNSUPPORTED -> the caller (ldc_gemm_grouped, gemm_streamk.hip) runs
 // its register-staged stream-K kernel instead (K % 32 != 0, strided weights, unaligned rows)
-int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+static int gemm_f32_ring(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace, long long workspace_bytes,
+                         void* stream) {
   LDC_CHECK_PTR(problems);
   if (n <= 0 || n > MAXP) return LDC_ERR_ARG;
   for (int i = 0; i < n; ++i)  // the caller's choice (include/ladcast_hip.h): this launch stays on the register-staged kernel
@@ -836,9 +841,21 @@ int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* wor
   // the 256-row tile (375M model in fp32 mode, same box: 113.6 TFLOP/s against 111.0 with 256 rows forced; profiles/r03_j_*)
 #ifdef LDC_AB_BUILD
   static const char* const force_bm = getenv("LDC_F32_RING_BM");  // A/B build only: 256-row tiles for the exact-fp32 GEMMs
-  if (force_bm && atoi(force_bm) == 256) return launch_v3<256, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
+  if (force_bm && atoi(force_bm) == 256) return launch_v3<256, 0>(problems, epi, n, workspace, workspace_bytes, stream);
 #endif
-  return launch_v3<128, 0>(problems, nullptr, n, workspace, workspace_bytes, stream);
+  return launch_v3<128, 0>(problems, epi, n, workspace, workspace_bytes, stream);
+}
+
+int ldc_gemm_grouped_f32_ring(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes, void* stream) {
+  return gemm_f32_ring(problems, nullptr, n, workspace, workspace_bytes, stream);
+}
+
+// exact-fp32 QKV projection with per-head RMSNorm + rotary embedding as its epilogue, plain fp32 rows out (include/ladcast_hip.h);
+// LDC_ERR_UNSUPPORTED (K % 32 != 0, strided weights, unaligned rows): run ldc_gemm_grouped and ldc_qk_rmsnorm_rope instead
+extern "C" int ldc_gemm_grouped_qkv_f32(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
+                                        long long workspace_bytes, void* stream) {
+  LDC_CHECK_PTR(epi);
+  return gemm_f32_ring(problems, epi, n, workspace, workspace_bytes, stream);
 }
 
 int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,

@@ -73,6 +73,7 @@ def _load():
         "ldc_gemm_grouped_bf16x3": (I, [POINTER(GemmProblem), I, P, L, P]),
         "ldc_sizeof_qkv_epilogue": (I, []),
         "ldc_gemm_grouped_bf16x3_qkv": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
+        "ldc_gemm_grouped_qkv_f32": (I, [POINTER(GemmProblem), POINTER(QkvEpilogue), I, P, L, P]),
         "ldc_attn_qkv_prepare_split": (I, [P, P, P, I, I, I, I, L, I, P, P, P, P, P, P, P, P, F, P]),
         "ldc_attn_fwd_split_workspace_bytes": (L, [I, I, I]),
         "ldc_attn_fwd_split_workspace_max_bytes": (L, []),
@@ -352,6 +353,23 @@ def qkv_epilogue(wq=None, wk=None, rope=None, *, eps=1e-7, heads, rope_row0=0, q
 
 ERR_UNSUPPORTED = -3  # LDC_ERR_UNSUPPORTED
 _DEFAULT_QSCALE = ctypes.c_float(0.08838834764831845 * 1.4426950408889634).value  # log2(e) / sqrt(128) as the library rounds it
+
+
+def gemm_grouped_qkv_f32(problems, epilogues):
+    """exact-fp32 `gemm_grouped` where problem i with a non-None epilogue is a QKV projection whose epilogue applies the per-head RMSNorm
+    and the rotary embedding (ldc_gemm_grouped_qkv_f32; epilogues built with qscale=1).  Returns False - and launches nothing - when the
+    ring kernel does not serve the launch (LDC_ERR_UNSUPPORTED): the caller then runs `gemm_grouped` + `qk_rmsnorm_rope`."""
+    n = len(problems)
+    if not 1 <= n <= MAX_GROUPED or len(epilogues) != n:
+        raise ValueError(f"gemm_grouped_qkv_f32 takes 1..{MAX_GROUPED} problems and one epilogue (or None) per problem")
+    arr = (GemmProblem * n)(*[p[0] for p in problems])
+    epi = (QkvEpilogue * n)(*[(e[0] if e is not None else QkvEpilogue()) for e in epilogues])
+    ws = _grouped_workspace(problems[0][1][2].device)
+    st = lib.ldc_gemm_grouped_qkv_f32(arr, epi, n, c_void_p(ws.data_ptr()), ws.numel() * 4, _stream())
+    if st == ERR_UNSUPPORTED:
+        return False
+    _check(st, "ldc_gemm_grouped_qkv_f32")
+    return True
 
 
 def gemm_grouped_qkv(problems, epilogues, force_fallback=False):

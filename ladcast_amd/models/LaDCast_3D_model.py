@@ -562,7 +562,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         hip.linear_small(ws.p1, tx.linear_2.weight, out, rows=B, N=D, K=D, bias=tx.linear_2.bias, add=t2, add_rows=Bt, mod=te,
                          mod_rows=1 if te is None else te.shape[0])
 
-    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False, key_bias=None):
+    def _attention(self, ws, B, row0, Sx, Sc, out, ldo, o_bs, seg_x, seg_c, out_split=False, key_bias=None, normed=False):
         """Attention over token rows [row0, row0 + Sx + Sc) of the fused qkv buffer -> out.
         fp32 mode: q/k RMSNorm + RoPE per segment in place (seg = (norm_q, norm_k, cos, sin): rows [row0, row0+Sx) use seg_x, the
         next Sc rows seg_c; ldc_qk_rmsnorm_rope) + ldc_attn_fwd.  Split-bf16 / bf16 modes: the QKV projection's epilogue has already
@@ -578,7 +578,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.attn_fwd_split(q, k, v, out, B=B, S=S, H=H, ld_qkv=3 * D, qkv_bs=full * 3 * D, ldo=ldo, o_bs=o_bs, out_split=out_split,
                                one_term=self.gemm_precision == "bf16", key_bias=key_bias)
             return
-        segs = [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]
+        segs = [] if normed else [sg for sg in ((Sx, seg_x), (Sc, seg_c)) if sg[0] > 0]  # normed: the QKV projection's epilogue did it
         r0 = row0
         for rows, (nq, nk, c, s_) in segs:
             hip.qk_rmsnorm_rope(qkv[:, :, 0:D], qkv[:, :, D : 2 * D], B=B, row0=r0, rows=rows, H=H, ld=3 * D, bs=full * 3 * D,
@@ -590,7 +590,9 @@ class LaDCastTransformer3DModel(ModelMixin):
         """epilogue descriptor of a fused QKV projection (split modes): per-head RMSNorm weights + compact rotary table (None = no RoPE)"""
         if norm_q.eps != norm_k.eps:
             raise NotImplementedError("the fused QKV epilogue takes one RMSNorm eps for q and k")
-        return hip.qkv_epilogue(norm_q.weight, norm_k.weight, rope, eps=norm_q.eps, heads=self.config.num_attention_heads)
+        # (exact-fp32 mode: q is not scaled here - ldc_attn_fwd folds the softmax scale into its Q fragments)
+        return hip.qkv_epilogue(norm_q.weight, norm_k.weight, rope, eps=norm_q.eps, heads=self.config.num_attention_heads,
+                                qscale=0.0 if self.gemm_precision in ("bf16x3", "bf16") else 1.0)
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -772,11 +774,16 @@ class LaDCastTransformer3DModel(ModelMixin):
             hip.gemm_grouped([G(A, W, C, **kw)], split_bf16=split)
 
         def run_qkv(problems, epis):
-            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split)
+            # QKV projections: in the split modes their epilogue writes the attention operand rows (norm, RoPE, scale, split); in the
+            # exact-fp32 mode it applies the per-head RMSNorm and the rotary embedding (plain fp32 rows).  Returns True when q / k leave
+            # the launch normed and rotated, False when `_attention` still has to do it (ldc_qk_rmsnorm_rope)
             if split:
                 hip.gemm_grouped_qkv(problems, epis)
-            else:
-                hip.gemm_grouped(problems, split_bf16=split)
+                return True
+            if hip.gemm_grouped_qkv_f32(problems, epis):
+                return True
+            hip.gemm_grouped(problems, split_bf16=False)
+            return False
 
         return AS, CS, fmt, G, run, run1, run_qkv
 
@@ -862,9 +869,9 @@ class LaDCastTransformer3DModel(ModelMixin):
                 a, _ = self._call_processor(blk.attn, nh_c, None, m_cond, (cc, cs), None)
                 ws.att.copy_(a)
             else:
-                run_qkv([G(nh_c, pa.wqkv, ws.qkv, M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
-                        [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
-                self._attention(ws, B, Nx, Nc, 0, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond)
+                nd = run_qkv([G(nh_c, pa.wqkv, ws.qkv, M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS)],
+                             [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, ck)])
+                self._attention(ws, B, Nx, Nc, 0, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, cc, cs), None, key_bias=kb_cond, normed=nd)
             hip.linear_small(ws.temb_r, blk.norm_out.linear.weight, ws.mod_a, rows=B, N=2 * D, K=D, bias=blk.norm_out.linear.bias, act_in=hip.ACT_SILU)
             # gated attention residual + norm2 in one launch
             hip.gate_residual_layernorm(h_c, ws.att, ws.mod_a, nh_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=SD, gate_bs=2 * D,
@@ -961,12 +968,12 @@ class LaDCastTransformer3DModel(ModelMixin):
                 hip.gate_residual(h_x, a, mx[:, 2 * D :], h_x, B=B, rows=Nx, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=Nx * D, gate_bs=NM)
                 hip.gate_residual(h_c, ca, mc[:, 2 * D :], h_c, B=B, rows=Nc, D=D, ld_res=D, res_bs=SD, ld_y=D, y_bs=Nc * D, gate_bs=NM)
             else:
-                run_qkv([
+                nd = run_qkv([
                     G(nh_x, pa.wqkv, ws.qkv, M=Nx, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                     G(nh_c, pa.wqkv_c, ws.qkv[:, Nx:], M=Nc, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv_c, flags=AS),
                 ], [self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, pk), self._qkv_epi(blk.attn.norm_added_q, blk.attn.norm_added_k, None)])
                 self._attention(ws, B, 0, Nx, Nc, ws.att, D, SD, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                                (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=fmt, key_bias=kb_all)
+                                (blk.attn.norm_added_q, blk.attn.norm_added_k, None, None), out_split=fmt, key_bias=kb_all, normed=nd)
                 o, oc = blk.attn.to_out[0], blk.attn.to_add_out
                 run([
                     G(ws.att, o.weight, h_x, M=Nx, N=D, K=D, batch=B, a_bs=SD, c_bs=SD, bias=o.bias, gate=mx[:, 2 * D :], gate_bs=NM, R=h_x, ldr=D, r_bs=SD, flags=AS),
@@ -1001,13 +1008,13 @@ class LaDCastTransformer3DModel(ModelMixin):
                 ws.cat[:, :Nx, :D].copy_(a)
                 ws.cat[:, Nx:, :D].copy_(ca)
             else:
-                run_qkv([
+                nd = run_qkv([
                     G(ws.nh, blk.proj_mlp.weight, cat_mlp, M=S, N=F, K=D, batch=B, a_bs=SD, ldc=W5, c_bs=S * W5, bias=blk.proj_mlp.bias, act=hip.ACT_GELU_TANH,
                       flags=AS | CS),
                     G(ws.nh, pa.wqkv, ws.qkv, M=S, N=3 * D, K=D, batch=B, a_bs=SD, c_bs=S * 3 * D, bias=pa.bqkv, flags=AS),
                 ], [None, self._qkv_epi(blk.attn.norm_q, blk.attn.norm_k, jk)])
                 self._attention(ws, B, 0, Nx, Nc, ws.cat, W5, S * W5, (blk.attn.norm_q, blk.attn.norm_k, pc, ps),
-                                (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=fmt, key_bias=kb_all)
+                                (blk.attn.norm_q, blk.attn.norm_k, cc, cs), out_split=fmt, key_bias=kb_all, normed=nd)
             run1(ws.cat, blk.proj_out.weight, ws.h, M=S, N=D, K=W5, batch=B, a_bs=S * W5, c_bs=SD, bias=blk.proj_out.bias,
                         gate=mod[:, 2 * D :], gate_bs=NM, R=ws.h, ldr=D, r_bs=SD, flags=AS)
 

@@ -909,6 +909,61 @@ def test_gemm_qkv_epilogue_feeds_the_attention(hip, Nx, Nc, H, batch):
     assert rel(mlp, F.gelu(A.double() @ Wm.double().T + bm.double(), approximate="tanh")) < 1e-5
 
 
+@pytest.mark.parametrize("Nx,Nc,H,batch", [(1800, 450, 12, 1), (37, 11, 2, 2), (450, 0, 12, 1), (300, 100, 3, 3)])
+def test_gemm_qkv_epilogue_exact_fp32(hip, Nx, Nc, H, batch):
+    """ldc_gemm_grouped_qkv_f32 (round 5): the exact-fp32 QKV projection applies per-head RMSNorm + rotary embedding in its epilogue and
+    writes plain fp32 rows - against the two-step route it replaces in the model (ldc_gemm_grouped, then ldc_qk_rmsnorm_rope in place: same
+    arithmetic in the same order), and the attention on those rows against oracle layers + sdpa on the fp64 projection.  A RoPE'd stream,
+    a plain one and an ordinary GELU problem in one launch, as in the model's blocks."""
+    D, K = H * 128, 256
+    S = Nx + Nc
+    A = rnd(batch, S, K, seed=1)
+    Wx, Wc = rnd(3 * D, K, seed=2) / math.sqrt(K), rnd(3 * D, K, seed=3) / math.sqrt(K)
+    bx, bc = rnd(3 * D, seed=4) * 0.1, rnd(3 * D, seed=5) * 0.1
+    Wm, bm = rnd(512, K, seed=6) / math.sqrt(K), rnd(512, seed=7)
+    wq0, wk0, wq1, wk1 = [1 + 0.1 * rnd(128, seed=s_) for s_ in (12, 13, 14, 15)]
+    cos0, sin0 = L.get_1d_rotary_pos_embed(128, torch.arange(Nx).float() * 0.37, 256.0)
+    dA = dev(A)
+    qkv = torch.full((batch, S, 3 * D), float("nan"), device="cuda")
+    mlp = torch.empty(batch, S, 512, device="cuda")
+
+    def problems(qkv_, mlp_):
+        pr = [hip.gemm_problem(dA, dev(Wx), qkv_, M=Nx, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D, bias=dev(bx))]
+        if Nc:
+            pr.append(hip.gemm_problem(dA[:, Nx:], dev(Wc), qkv_[:, Nx:], M=Nc, N=3 * D, K=K, batch=batch, a_bs=S * K, c_bs=S * 3 * D, bias=dev(bc)))
+        pr.append(hip.gemm_problem(dA, dev(Wm), mlp_, M=S, N=512, K=K, batch=batch, a_bs=S * K, c_bs=S * 512, bias=dev(bm), act=2))
+        return pr
+
+    epis = [hip.qkv_epilogue(dev(wq0), dev(wk0), hip.compact_rope_table(dev(cos0), dev(sin0)), eps=1e-7, heads=H, qscale=1.0)]
+    if Nc:
+        epis.append(hip.qkv_epilogue(dev(wq1), dev(wk1), None, eps=1e-7, heads=H, qscale=1.0))
+    epis.append(None)
+    assert hip.gemm_grouped_qkv_f32(problems(qkv, mlp), epis)
+    # the route it replaces: plain projection, then the q / k norm + rotary kernel in place, segment by segment
+    qkv2 = torch.full((batch, S, 3 * D), float("nan"), device="cuda")
+    mlp2 = torch.empty(batch, S, 512, device="cuda")
+    hip.gemm_grouped(problems(qkv2, mlp2))
+    hip.qk_rmsnorm_rope(qkv2[:, :, :D], qkv2[:, :, D : 2 * D], B=batch, row0=0, rows=Nx, H=H, ld=3 * D, bs=S * 3 * D, wq=dev(wq0), wk=dev(wk0), eps=1e-7,
+                        cos=dev(cos0), sin=dev(sin0))
+    if Nc:
+        hip.qk_rmsnorm_rope(qkv2[:, :, :D], qkv2[:, :, D : 2 * D], B=batch, row0=Nx, rows=Nc, H=H, ld=3 * D, bs=S * 3 * D, wq=dev(wq1), wk=dev(wk1), eps=1e-7)
+    assert torch.isfinite(qkv).all() and torch.equal(mlp, mlp2)
+    assert rel(qkv, qkv2) < 3e-7 and torch.equal(qkv[..., 2 * D :], qkv2[..., 2 * D :])  # v: bias only - the same bits
+    out = torch.empty(batch, S, D, device="cuda")
+    hip.attn_fwd(qkv[:, :, :D], qkv[:, :, D : 2 * D], qkv[:, :, 2 * D :], out, B=batch, S=S, H=H, ld_qkv=3 * D, qkv_bs=S * 3 * D, ldo=D, o_bs=S * D)
+    proj = torch.cat([A[:, :Nx].double() @ Wx.double().T + bx.double(), A[:, Nx:].double() @ Wc.double().T + bc.double()], dim=1)
+    want = _norm_rope_sdpa(proj, batch, S, H, Nx, Nc, (wq0, wk0, wq1, wk1), (cos0, sin0), None)
+    assert rel(out, want) < 3e-6
+    with pytest.raises(RuntimeError):  # N must be 3 * heads * 128
+        hip.gemm_grouped_qkv_f32(problems(qkv, mlp)[:1], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, heads=H + 1, qscale=1.0)])
+    # a shape the ring kernel does not serve (K % 32 != 0): nothing is launched, the caller takes the two-step route
+    A2, W2 = dev(rnd(1, 40, 24, seed=8)), dev(rnd(3 * 128, 24, seed=9))
+    c2 = torch.full((1, 40, 384), float("nan"), device="cuda")
+    assert not hip.gemm_grouped_qkv_f32([hip.gemm_problem(A2, W2, c2, M=40, N=384, K=24)], [hip.qkv_epilogue(dev(wq0), dev(wk0), None, heads=1, qscale=1.0)])
+    torch.cuda.synchronize()
+    assert torch.isnan(c2).all()
+
+
 # -- launch merges: each fused launch is bit-identical to the two launches it replaces ---------------------------------------------------
 def test_timestep_sinusoid_inside_the_first_linear_is_bitwise(hip):
     D = 1536
