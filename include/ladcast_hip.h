@@ -444,7 +444,11 @@ int ldc_sphere_conv_nhwc_split(const float* X, const void* Wp, const float* bias
  * into the source addresses - instead of once per (tap, chunk); same arguments, same arithmetic per output element (k order: chunk-major
  * instead of tap-major, so results differ from the gathered kernel in the last bits of the fp32 accumulation only).
  * ldc_sphere_conv_plan tells which kernel a call shape gets: returns 1 and the tile (rows = TH x TW: 128 | 256; width TW) for the
- * halo-staged kernel, 0 for the gathered one (ksize != 3, fp32 rows, images that would leave most of the tiles' rows empty). */
+ * halo-staged kernel, 0 for the gathered one (ksize != 3, fp32 rows, images that would leave most of the tiles' rows empty).  The plan
+ * assumes the caller passes the full grouped-GEMM workspace (ldc_gemm_grouped_workspace_bytes): shapes that put two workgroups on a
+ * tile need LDC_GEMM_COUNTER_BYTES + 2 * tiles * 128 KiB of it, and a call with less runs the gathered kernel whatever the plan says.
+ * Both kernels validate alike: X 32-byte / Wp and workspace 16-byte aligned, ldx % 8 == 0 (LDC_ERR_ALIGN), act in range
+ * (LDC_ERR_UNSUPPORTED), ldr >= cout when R is given (LDC_ERR_ARG). */
 int ldc_sphere_conv_plan(int B, int H, int W, int cin, int cout, int ksize, int in_fmt, int* tile_rows, int* tile_w);
 /* Producers of operand rows.  `ys` = operand copy in format `fmt` (LDC_FMT_SPLIT | LDC_FMT_BF16; lds % 8 == 0, >= C rounded up to
  * 8, 32-byte aligned; pad columns zeroed), `y` = fp32 copy (the residual stream / inputs of depthwise convs); either may be NULL,

@@ -485,6 +485,13 @@ int ldc_conv_halo_dispatch(const float* X, const void* Wp, const float* bias, co
   int best_bm = 0, best_tw = 0, ksplit = 1;
   if (!halo_plan(B, H, W, cout, ldc_cdiv(cin, cpk), &best_bm, &best_tw, &ksplit)) return LDC_ERR_UNSUPPORTED;
   if (workspace == nullptr || workspace_bytes < LDC_GEMM_COUNTER_BYTES) return LDC_ERR_ARG;
+  // the argument checks of the gathered kernel's launcher (launch_v3, gemm_bf16x3_v3.hip), with its error codes: this path issues 16-byte
+  // global -> LDS DMAs of X and Wp and takes `act` as a table index, so a misaligned view or a bad activation must not get past here
+  LDC_CHECK_ALIGN16(Wp);
+  LDC_CHECK_ALIGN16(workspace);
+  if ((ldx & 7) || (reinterpret_cast<unsigned long long>(X) & 31ull)) return LDC_ERR_ALIGN;
+  if (act < LDC_ACT_NONE || act > LDC_ACT_RELU) return LDC_ERR_UNSUPPORTED;
+  if (R != nullptr && ldr < cout) return LDC_ERR_ARG;
   HaloArgs a{};
   DevProblem& P = a.P;
   P.A = X;

@@ -429,6 +429,70 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     sb = sb1;                                                                                                \
   }
 
+    // Round 6, exact-fp32 128-row instances: the same k-step with the column tiles taken in PAIRS whose MFMAs alternate.
+    // v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a dependent MFMA only after 40 (MI355X_MICROARCH.md, cycle constants), and the
+    // k-step above runs the 8 MFMAs of a column tile as ONE accumulation chain (RT = 1: one accumulator per column tile): whenever the SIMD's other
+    // wave is not issuing (waits, DMA issue, barrier skew) the chain runs at 40 cycles per MFMA - 75.7 % MFMA busy in round 5.  Two column tiles
+    // (two accumulators) alternating put 64 cycles between dependent MFMAs.  Per accumulator the order of its 8 MFMAs is unchanged: results are
+    // bit-identical.  Fragment window: tiles (0,1) | reload 4,5 | (2,3) | reload 6,7 | (4,5) | barrier | A(kt+1), W(kt+1; 0,1) | (6,7) | W(kt+1; 2,3);
+    // reads return in order, so at entry 10 are outstanding [A x2, W0 x2, W1 x2, W2 x2, W3 x2] and every wait below leaves the 4 youngest.
+#define LDC_CT2(C0, WH0, WL0, C1, WH1, WL1, AH, AL)                              \
+  if (wave_rows) {                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                           \
+      LDC_MMF(acc[(C0)], WH0, AH[0], j_)                                         \
+      LDC_MMF(acc[(C1)], WH1, AH[0], j_)                                         \
+    }                                                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                           \
+      LDC_MMF(acc[(C0)], WL0, AL[0], j_)                                         \
+      LDC_MMF(acc[(C1)], WL1, AL[0], j_)                                         \
+    }                                                                            \
+  }
+#define LDC_KSTEP_P(AH, AL, AHN, ALN)                                                                        \
+  {                                                                                                          \
+    const int st1 = st == NSTAGE - 1 ? 0 : st + 1;                                                           \
+    const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;                                                         \
+    const unsigned sb1 = st1 * STAGE_B;                                                                      \
+    const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                     \
+    const unsigned anh = a_hi + sb1, anl = a_lo + sb1;                                                       \
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1)); \
+    LDC_SB;                                                                                                  \
+    LDC_CT2(0, wh0, wl0, 1, wh1, wl1, AH, AL)                                                                \
+    LDC_RD_W(wh0, wl0, wch, wcl, 4)                                                                          \
+    LDC_RD_W(wh1, wl1, wch, wcl, 5)                                                                          \
+    issue_one(kt + 2, st2, NDH + 0);                                                                         \
+    issue_one(kt + 2, st2, NDH + 1);                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));                       \
+    LDC_SB;                                                                                                  \
+    LDC_CT2(2, wh2, wl2, 3, wh3, wl3, AH, AL)                                                                \
+    LDC_RD_W(wh2, wl2, wch, wcl, 6)                                                                          \
+    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1));                       \
+    LDC_SB;                                                                                                  \
+    LDC_CT2(4, wh0, wl0, 5, wh1, wl1, AH, AL)                                                                \
+    /* barrier(kt+1): done READING stage kt (tiles 6, 7 were requested a pair of column tiles ago); DMAs of kt+1 landed */ \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));                       \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                         \
+    LDC_KSTEP_BARRIER                                                                                        \
+    LDC_SB;                                                                                                  \
+    LDC_RD_A(AHN, ALN, anh, anl)                                                                             \
+    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                          \
+    LDC_RD_W(wh1, wl1, wnh, wnl, 1)                                                                          \
+    issue_one(kt + 3, st, 0);                                                                                \
+    issue_one(kt + 3, st, 1);                                                                                \
+    LDC_SB;                                                                                                  \
+    LDC_CT2(6, wh2, wl2, 7, wh3, wl3, AH, AL)                                                                \
+    LDC_RD_W(wh2, wl2, wnh, wnl, 2)                                                                          \
+    LDC_RD_W(wh3, wl3, wnh, wnl, 3)                                                                          \
+    LDC_SB;                                                                                                  \
+    st = st1;                                                                                                \
+    sb = sb1;                                                                                                \
+  }
+#if defined(LDC_AB_BUILD) && defined(LDC_GEMM_F32_NO_PAIRS)  // A/B aid (make variant DIAG=-DLDC_GEMM_F32_NO_PAIRS): round 5's k-step
+  constexpr bool PAIRED = false;
+#else
+  constexpr bool PAIRED = TERMS == 0 && RT == 1;
+#endif
+
     // prologue: k-steps k0 and k0+1 in flight, fragments of k0 (A, W column tiles 0-3) loading
 #ifdef LDC_GEMM_STAMPS_PROLOGUE
     if (seg_ == 0) { LDC_STAMP(10) }
@@ -466,16 +530,27 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     unsigned sb = 0;  // LDS byte offset of stage kt
     int st = 0;       // stage index of k-step kt
     for (int kt = k0; kt < k1; ++kt) {
-      LDC_KSTEP(ah0, al0, ah1, al1)
+      if constexpr (PAIRED) {
+        static_assert(!PAIRED || ND == 4, "the paired k-step is written for the 128-row tile's 4 DMA pieces");
+        LDC_KSTEP_P(ah0, al0, ah1, al1)
+      } else {
+        LDC_KSTEP(ah0, al0, ah1, al1)
+      }
       ++kt;
       if (kt >= k1) break;
-      LDC_KSTEP(ah1, al1, ah0, al0)
+      if constexpr (PAIRED) {
+        LDC_KSTEP_P(ah1, al1, ah0, al0)
+      } else {
+        LDC_KSTEP(ah1, al1, ah0, al0)
+      }
     }
     // drain the (unused) reads of the last k-step before their registers are reused
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1), "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(ah0[rt]), "+v"(al0[rt]), "+v"(ah1[rt]), "+v"(al1[rt]));
 #undef LDC_KSTEP
+#undef LDC_KSTEP_P
+#undef LDC_CT2
 #undef LDC_WAIT
 #undef LDC_CT
 #undef LDC_MMF

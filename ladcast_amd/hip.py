@@ -311,8 +311,21 @@ def attn_fwd(Q, K, V, O, *, B, S, H, ld_qkv, qkv_bs, ldo, o_bs, key_bias=None, u
         _check(lib.ldc_attn_fwd(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _stream()), "ldc_attn_fwd")
         return
     ws = _attn_f32_workspace(Q.device)
-    _check(lib.ldc_attn_fwd_ws(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _p(ws), ws.numel() * 4, _stream()),
-           "ldc_attn_fwd_ws")
+    st = lib.ldc_attn_fwd_ws(_p(Q), _p(K), _p(V), _p(O), B, S, H, ld_qkv, qkv_bs, ldo, o_bs, _p(key_bias), _p(ws), ws.numel() * 4, _stream())
+    if st != 0 and not torch.cuda.is_current_stream_capturing():
+        ws.zero_()  # a launch that did not complete may leave ticket counters non-zero: re-arm them before anyone launches again
+    _check(st, "ldc_attn_fwd_ws")
+
+
+def rearm_attention_workspaces(device=None):
+    """Zero the ticket counters + slabs of the balanced exact-fp32 attention for every stream of `device` (all devices when None).  The launches
+    leave their counters zero, so this is needed only after a faulted / aborted launch, and is what the models call before they (re)capture a
+    hipGraph.  Must not be called while a graph that uses the workspace is running.  One workspace serves ONE stream: a graph captured on
+    stream A and replayed on stream B shares A's counters - replay it on A, or give B its own capture."""
+    want = None if device is None else torch.device(device).index
+    for ws in _attn_f32_ws.values():
+        if want is None or ws.device.index == want:
+            ws.zero_()
 
 
 _score_ws = {}

@@ -46,6 +46,12 @@ class _RMSNormP(nn.Module):
         self.weight = nn.Parameter(torch.ones(dim))
         self.bias = nn.Parameter(torch.zeros(dim))
 
+    def forward(self, x):
+        """torch arithmetic, reached ONLY from a user-supplied attention processor (`attn.processor = ...`): diffusers RMSNorm with bias over the
+        last axis - fp32 statistics, x * rsqrt(mean(x^2) + eps) * weight + bias.  The built-in path runs ldc_rmsnorm_rows."""
+        var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        return x * torch.rsqrt(var + self.eps) * self.weight + self.bias
+
 
 class SanaMultiscaleAttentionProjection(nn.Module):
     def __init__(self, in_channels, num_attention_heads, kernel_size):
@@ -53,6 +59,17 @@ class SanaMultiscaleAttentionProjection(nn.Module):
         ch = 3 * in_channels
         self.proj_in = SphereConv2d(ch, ch, kernel_size, padding=kernel_size // 2, groups=ch, bias=False)
         self.proj_out = nn.Conv2d(ch, ch, 1, 1, 0, groups=3 * num_attention_heads, bias=False)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """NCHW in, NCHW out (models/DCAE.py:87-93), reached ONLY from a user-supplied attention processor: the depthwise sphere conv through
+        SphereConv2d.forward (HIP), the grouped 1 x 1 conv as one batched matrix product over the groups.  The built-in path runs
+        ldc_sphere_dwconv_nhwc + ldc_grouped_conv1x1_nhwc on NHWC rows."""
+        h = self.proj_in(x)
+        B, C, H, W = h.shape
+        G = self.proj_out.groups
+        w = self.proj_out.weight.reshape(G, C // G, C // G)  # [group][out][in]
+        return torch.einsum("goi,bgip->bgop", w, h.reshape(B, G, C // G, H * W)).reshape(B, C, H, W)
 
 
 class SanaMultiscaleAttnProcessor2_0:
@@ -97,21 +114,34 @@ class SanaMultiscaleLinearAttention(nn.Module):
         self.to_qkv_multiscale = nn.ModuleList([SanaMultiscaleAttentionProjection(inner, self.heads, ks) for ks in kernel_sizes])
         self.to_out = nn.Linear(inner * (1 + len(kernel_sizes)), out_channels, bias=False)
         self.norm_out = _RMSNormP(out_channels, 1e-5)  # diffusers get_normalization("rms_norm") default eps
-        self._processor = SanaMultiscaleAttnProcessor2_0()
+        # what a processor written against the reference's module reads from it (models/DCAE.py:119-120,143,205-267)
+        self.nonlinearity = nn.ReLU()
+        self.norm_type = "rms_norm"
+        self.residual_connection = True
+        self.processor = SanaMultiscaleAttnProcessor2_0()
 
-    # models/DCAE.py:156: the reference keeps its processor in a plain attribute.  Here the block runs fused (ldc_relu_linear_attn_nhwc_fmt
-    # between the conv GEMMs); a foreign processor is REFUSED, not ignored.
+    # models/DCAE.py:156,205-210: the reference keeps its processor in a plain attribute and calls `self.processor(self, hidden_states, gate=gate_msa)`.
+    # An instance of the built-in class (the default) is a MARKER: the block runs fused (conv GEMMs + ldc_relu_linear_attn_nhwc_fmt) and the
+    # processor is never called.  Any other object is a FOREIGN processor: AutoencoderDC._evit CALLS it with the reference's protocol on torch
+    # tensors (NCHW, fp32 mode, eager launches only) - it is never ignored.
     @property
-    def processor(self):
-        return self._processor
+    def foreign_processor(self):
+        p = self.processor
+        return None if isinstance(p, SanaMultiscaleAttnProcessor2_0) else p
 
-    @processor.setter
-    def processor(self, value):
-        if not isinstance(value, SanaMultiscaleAttnProcessor2_0):
-            raise NotImplementedError(
-                "the DCAE's multiscale linear attention runs fused on the HIP path (ldc_sphere_conv_nhwc_split + ldc_relu_linear_attn_nhwc_fmt); "
-                "a user-supplied processor is not supported - change the arithmetic through the C ABI (include/ladcast_hip.h)")
-        self._processor = value
+    def apply_linear_attention(self, query, key, value):
+        """torch arithmetic for user-supplied processors (models/DCAE.py:158-175): ReLU linear attention in fp32, the all-ones row appended to
+        `value` carries the normaliser"""
+        value = torch.nn.functional.pad(value, (0, 0, 0, 1), mode="constant", value=1)
+        scores = torch.matmul(value.to(torch.float32), key.transpose(-1, -2).to(torch.float32))
+        hs = torch.matmul(scores, query.to(torch.float32))
+        return hs[:, :, :-1] / (hs[:, :, -1:] + self.eps)
+
+    def apply_quadratic_attention(self, query, key, value):
+        """torch arithmetic for user-supplied processors (models/DCAE.py:177-186)"""
+        scores = torch.matmul(key.transpose(-1, -2), query).to(torch.float32)
+        scores = scores / (torch.sum(scores, dim=2, keepdim=True) + self.eps)
+        return torch.matmul(value, scores)
 
 
 class GLUMBConv(nn.Module):
@@ -261,6 +291,8 @@ class AutoencoderDC(ModelMixin):
         """Replay one captured hipGraph per (encode | decode, input shape) instead of ~400 launches from Python.  Same kernels and
         arguments, bit-identical results.  Measured on one MI355X it buys nothing on an idle host (one frame: 5.5 ms either way - the
         ~400 small kernels, not their launches, are the time); it takes the host out of the loop when 8 ranks share one box."""
+        if flag and any(m.foreign_processor is not None for m in self.modules() if isinstance(m, SanaMultiscaleLinearAttention)):
+            raise NotImplementedError("a user-supplied DCAE attention processor runs eagerly (torch tensors): it cannot be captured into a hipGraph")
         self.use_hip_graph = bool(flag)
         if not flag:
             self._graphs = {}
@@ -452,6 +484,22 @@ class AutoencoderDC(ModelMixin):
                               eps=1e-15)
             x = self._stream(xn, M, C)
             gate = mod[:, 2 * C :]
+        if at.foreign_processor is not None:
+            # a user-supplied processor (models/DCAE.py:156,205-210): CALLED with the reference's protocol `(attn, hidden_states NCHW, gate=gate_msa)`;
+            # it returns the block's attention output (norm_out and the residual applied, as the reference's processor does).  torch tensors,
+            # exact-fp32 mode, eager launches only.
+            if split:
+                raise NotImplementedError("a user-supplied DCAE attention processor runs in the exact-fp32 mode only (set_gemm_precision('fp32')): "
+                                          "the split modes keep activations as operand rows the processor cannot read")
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("a user-supplied DCAE attention processor is not graph-capturable: enable_hip_graph(False)")
+            xin = x[0][:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+            g4 = None if gate is None else gate.reshape(B, C, 1, 1)  # AdaLayerNormZeroSingle4Sana returns gate_msa[:, :, None, None] (:64)
+            out = at.foreign_processor(at, xin, gate=g4)
+            if tuple(out.shape) != (B, C, H, W):
+                raise ValueError(f"the attention processor returned {tuple(out.shape)}, expected {(B, C, H, W)}")
+            y = self._stream(out.to(torch.float32).permute(0, 2, 3, 1).reshape(M, C).contiguous(), M, C)
+            return self._glumb(blk, y, B, H, W)
         n_ms = len(at.to_qkv_multiscale)
         wide = 3 * inner * (1 + n_ms)
         qkv = torch.empty(M, wide, device=dev, dtype=torch.float32)
@@ -471,7 +519,11 @@ class AutoencoderDC(ModelMixin):
             hip.gate_residual(torch.zeros_like(o), o, gate, og, B=B, rows=H * W, D=C, ld_res=C, res_bs=H * W * C, ld_y=C, y_bs=H * W * C, gate_bs=3 * C)
             o = og
         y = self._norm(o, at.norm_out, x[0], M, C)
-        # GLUMBConv, models/DCAE.py:304-324
+        return self._glumb(blk, y, B, H, W)
+
+    def _glumb(self, blk, y, B, H, W):
+        """GLUMBConv, models/DCAE.py:304-324"""
+        M, C, dev, split = B * H * W, blk.attn.to_q.in_features, y[0].device, self._split
         g = blk.conv_out
         hid2 = g.conv_inverted.out_channels
         h1 = torch.empty(M, hid2, device=dev, dtype=torch.float32)

@@ -657,6 +657,7 @@ class LaDCastTransformer3DModel(ModelMixin):
                 with torch.cuda.stream(self._capture_stream):
                     self._forward_device(sx, st, sk, te)
                 torch.cuda.synchronize()
+                hip.rearm_attention_workspaces(dev)  # ticket counters of the balanced fp32 attention: zeroed before a (re)capture, with nothing in flight (hip.py)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
                     sout = self._forward_device(sx, st, sk, te)

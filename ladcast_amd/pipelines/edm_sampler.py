@@ -100,6 +100,7 @@ def edm_AR_sampler(
             with torch.cuda.stream(side):  # warm-up on the capture stream: per-stream workspaces are created here
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps, prepare)
             torch.cuda.synchronize()
+            hip.rearm_attention_workspaces(device)  # ticket counters of the balanced fp32 attention: zeroed before a (re)capture, with nothing in flight (hip.py)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):  # other threads (the RCCL watchdog) may touch the runtime
                 _heun_chunk(net.forward_launch_only, noise_scheduler, t_steps, cn, st_lat, st_known, te, st_out, shape, device, num_inference_steps, prepare)

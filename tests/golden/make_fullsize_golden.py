@@ -13,6 +13,10 @@ their norm (tests/synth.py: Sub); small ones (latents, one network input) in ful
                                input 20 in full, de-normalised latents (full), the four decoded frames (stride 16)
   fullsize_1p6b_chunk.npz      1.6B, 1 member, 20-step Heun chunk (39 forwards): sample (full), per-evaluation inputs / outputs (stride 32)
   fullsize_375m_2members.npz   375M, 2 members, 20-step Heun chunk (39 forwards, batch 2): sample (full), per-evaluation inputs / outputs
+  fullsize_1p6b_literal_chain.npz, fullsize_375m_2members_literal_chain.npz   (`literal_chain`, not in the default list: ~25 min of oracle)
+                               the same chained runs at the reference's 20 solver steps (39 forwards per chunk): 1.6B, 1 member, 10 lead steps = 3 chunks
+                               (last cut to 2 frames) = BASELINE configs[3] per GPU; 375M, 2 members, 12 lead steps = 3 chained chunks = configs[2]'s
+                               share of one GPU (first 3 of its 10 chunks); latents in full
   fullsize_1p6b_truncated_chunks.npz, fullsize_375m_2members_3chunks.npz
                                the chained roll_out_serial runs of tests/test_gpu_chain.py (3 solver steps per chunk): 1.6B, 6 lead steps = chunk +
                                truncated chunk; 375M, 2 members, 12 lead steps = 3 chained chunks
@@ -108,9 +112,10 @@ def chunk(name, cfg, members):
     print(f"{name}: {out['seconds'][0]:.0f} s", flush=True)
 
 
-def chained_rollout(name, cfg, members, lead_hours, stride):
-    """oracle side of tests/test_gpu_chain.py's chained roll_out_serial tests: 3 solver steps per chunk (5 forwards), chunks chained through
-    each member's own last frame; the IC latent comes from a stand-in encoder (the DCAE is not part of these tests)"""
+def chained_rollout(name, cfg, members, lead_hours, stride, solver_steps=3):
+    """oracle side of tests/test_gpu_chain.py's chained roll_out_serial tests: `solver_steps` per chunk (3 = 5 forwards for the short chains, 20 = the
+    reference's literal 39 forwards for the *_literal_chain files), chunks chained through each member's own last frame; the IC latent comes from a
+    stand-in encoder (the DCAE is not part of these tests)"""
     from datetime import datetime
 
     o = make_ar(dict(cfg))
@@ -126,7 +131,7 @@ def chained_rollout(name, cfg, members, lead_hours, stride):
 
     t0 = time.perf_counter()
     want = OP.roll_out_serial(lambda t: torch.zeros(84, 1, 120, 240), [datetime(2018, 1, 1, 0)], OP.AutoRegressive2DPipeline(o, OracleScheduler()), encdec_model=FakeAE(),
-                              static_tensor4encdec=torch.zeros(5, 120, 240), ensemble_size=members, num_inference_steps=3, return_seq_len=4,
+                              static_tensor4encdec=torch.zeros(5, 120, 240), ensemble_size=members, num_inference_steps=solver_steps, return_seq_len=4,
                               latent_transform_args=targs, total_lead_time_hour=lead_hours, sampler_type="edm", return_latent=True)
     out = {"seconds": np.array([time.perf_counter() - t0])}
     put(out, "want", want, stride)
@@ -139,6 +144,9 @@ if __name__ == "__main__":
     if "chained" in which:
         chained_rollout("fullsize_1p6b_truncated_chunks.npz", CONFIG_1_6B, 1, 36, None)   # (1, 1, 84, 7, 15, 30): kept in full (1 MB)
         chained_rollout("fullsize_375m_2members_3chunks.npz", CONFIG_375M, 2, 72, 2)      # (1, 2, 84, 13, 15, 30): every 2nd value
+    if "literal_chain" in which:  # BASELINE configs[3] / configs[2] at the reference's 20 solver steps = 39 forwards per chunk
+        chained_rollout("fullsize_1p6b_literal_chain.npz", CONFIG_1_6B, 1, 60, None, solver_steps=20)          # cfg 4 per GPU: 10 lead steps = 2 chunks + one cut to 2 frames
+        chained_rollout("fullsize_375m_2members_literal_chain.npz", CONFIG_375M, 2, 72, None, solver_steps=20)  # cfg 3's share of one GPU, first 3 of its 10 chunks
     if "dcae375" in which:
         dcae_and_375m()
     if "2members" in which:

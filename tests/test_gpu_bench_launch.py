@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_self_launches_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--steps", "2", "--warmup", "1",
-           "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--no-strong-cfg3"]
+           "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--no-strong-cfg3", "--precision", "bf16x3"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -37,7 +37,7 @@ def test_bench_strong_scaling_fixed_ensemble_over_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     for E, want in ((3, [2, 1]), (1, [1, 0])):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--steps", "1", "--warmup", "0",
-               "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--ensemble-size", str(E), "--solver-steps", "4"]
+               "--cpu-forwards", "0", "--sustained-seconds", "0", "--no-kernel-timers", "--ensemble-size", str(E), "--solver-steps", "4", "--precision", "bf16x3"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -51,6 +51,51 @@ def test_bench_strong_scaling_fixed_ensemble_over_two_ranks():
         assert s3["speedup_vs_n1"] is None  # 4 solver steps here: not the workload of the committed N = 1 figure, no ratio is printed
         assert line["config"]["ensemble_size"] == E and line["config"]["members_on_rank"] == want and line["config"]["members_per_gpu"] is None
         assert abs(line["value"] - E * 1 * 1 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3  # value = E x lead steps x steps / time
+
+
+def test_default_line_carries_like_for_like_dcae_cfg5_and_rccl_blocks():
+    """the default `--gpus 1` line - what the driver records as BENCH_rNN.json - must carry (i) `value` in the reference's own
+    arithmetic (exact fp32) with the split-bf16 fast mode as its own block, `like_for_like` saying which is which; (ii) a `dcae` block (BASELINE
+    configs[0] on the GPU in the three arithmetic modes, the dominant conv's roofline row, configs[0]'s cpu_baseline); (iii) a `cfg5` block; and
+    `ranks.rccl_version` from the world-size-1 RCCL child.  Reduced step counts here; every leg runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-forwards", "1", "--sustained-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["metric"] == "ensemble-member-steps/sec" and line["n_gpus"] == 1 and line["vs_baseline"] is None and line["value"] > 0
+    # (i) arithmetic: the top level is exact fp32; the fast mode has its own block and is faster, the two are never confusable
+    assert line["dtype"] == "f32" and "bf16x3_mode" in line["value_dtype_note"] and line["config"]["workload"].endswith("arithmetic fp32")
+    lfl = line["like_for_like"]
+    assert lfl["dtype"] == "f32" and lfl["source"] == "top level" and lfl["value"] == line["value"] and lfl["roofline"] == line["roofline"]
+    fast = line["bf16x3_mode"]
+    assert fast["dtype"].startswith("bf16x3") and fast["value"] > 1.5 * line["value"] and fast["steps"] >= 10 and len(fast["step_ms"]) == fast["steps"]
+    for roof, peak in ((line["roofline"], 157.3), (fast["roofline"], 2500.0)):
+        assert roof["bound"] == "mfma" and roof["peak"] == peak and roof["unit"] == "TFLOP/s" and 0 < roof["frac"] < 1
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof and roof["variants"]
+        dom = [v for v in roof["variants"] if v["kernel"] == roof["kernel"]][0]
+        assert abs(dom["flops_per_launch"] / (dom["avg_launch_us"] * 1e-6) / 1e12 - dom["achieved"]) / dom["achieved"] < 2e-3  # achieved = measured, not modelled
+    assert line["roofline"]["kernel"] == "gemm_bf16x3_v3_kernel<128, 0, false>" and "frac_of_attainable" in fast["roofline"]
+    assert line["attention_kernel"]["kernel"] == "attn_fwd_f32_kernel" and fast["attention_kernel"]["kernel"] == "attn_fwd_split_kernel"
+    # (ii) the autoencoder: BASELINE configs[0]
+    d = line["dcae"]
+    for prec in ("fp32", "bf16x3", "bf16"):
+        for k in ("frames_1", "frames_8", "frames_1_graph"):
+            assert d[prec][k]["encode_ms"] > 0 and d[prec][k]["decode_ms"] > 0, (prec, k)
+    assert d["bf16x3"]["frames_1"]["encode_ms"] < d["fp32"]["frames_1"]["encode_ms"]
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["flops_per_launch"] > 1e9 and d["roofline"]["avg_launch_us"] > 0 and "traffic" in d["roofline"]
+    cb1 = d["cpu_baseline"]
+    assert cb1["kind"] == "port" and cb1["cores"] >= 1 and cb1["encode_ms"] > 0 and cb1["decode_ms"] > 0 and line["cpu_baseline_cfg1"] == cb1 and d["gpu_over_cpu_fp32"] > 1
+    # (iii) cfg 5: encode -> chunk -> decode in both reduced-precision modes; the AR cpu_baseline of cfg 2
+    for prec in ("bf16x3", "bf16"):
+        c = line["cfg5"][prec]
+        assert c["value"] > 0 and c["ms_per_step"] > c["chunk_only_ms"] > 0
+    assert line["cfg5"]["bf16"]["ms_per_step"] < line["cfg5"]["bf16x3"]["ms_per_step"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["gpu_over_cpu"] > 20  # north_star: >= 20x the CPU reference
+    # RCCL ran for real at world size 1
+    assert line["rccl_world1"]["ok"] and line["ranks"]["rccl_version"] == line["rccl_world1"]["rccl_version"] and line["ranks"]["backend"] == "none"
 
 
 def test_bench_rejects_mismatched_world():

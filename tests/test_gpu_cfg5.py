@@ -94,6 +94,16 @@ def test_cfg5_end_to_end_three_chunks_bf16_mixed_vs_oracle_and_autocast():
     got_graph = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, **hip_kw)
     gar.enable_hip_graph(False)
     assert torch.equal(got_graph[:, :, :, 1:], got[:, :, :, 1:])
+    # round 6: `decode_batch_frames` - the chunks' latents stay in HBM and are decoded after the last chunk in large batches (32: all 12 lead
+    # steps x 2 members in one decoder call; 5: two lead steps per call, six calls).  Same decoder, same latents: equal to the per-chunk order to
+    # fp32 rounding (the conv kernels pick their schedule from the launch size); slot 0 (the raw IC field) bit for bit
+    for nb in (32, 5):
+        got_def = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, decode_batch_frames=nb, **hip_kw)
+        e_def = rel_l2(got_def[:, :, :, 1:], got[:, :, :, 1:])
+        print(f"cfg5 tiny, decode deferred in batches of <= {nb} frames vs per-chunk decode: rel-L2 {e_def:.1e}")
+        assert got_def.shape == got.shape and e_def < 1e-5 and torch.equal(got_def[:, :, :, 0], got[:, :, :, 0])
+    mean_def = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, return_ensemble_mean=True, decode_batch_frames=32, **hip_kw)
+    assert mean_def.shape == (1, 1, 84, 1 + R * chunks, 120, 240) and rel_l2(mean_def[:, 0, :, 1:], got[:, :, :, 1:].mean(dim=1)) < 1e-5
     e_dec, e_lat = per_chunk(got, want), per_chunk(got_lat, want_lat)
     e_ic = rel_l2(got_lat[:, :, :, 0], want_lat[:, :, :, 0])
     print(f"cfg5 tiny, HIP bf16 mode vs fp32 oracle: IC latent {e_ic:.1e}; per chunk: decoded {_fmt(e_dec)} | latent {_fmt(e_lat)}")

@@ -646,3 +646,101 @@ def test_interpolate_upsampling_variant_matches_oracle(golden_dir):
     g.enable_hip_graph(True)
     assert torch.equal(g.decode(zz.cuda()).sample, g.decode(zz.cuda()).sample)
     g.enable_hip_graph(False)
+
+
+class _ReferenceProtocolProcessor:
+    """A user-supplied DC-AE attention processor written against the reference's protocol (models/DCAE.py:205-267: `proc(attn, hidden_states NCHW,
+    gate=None)`, reading `attn.to_q / to_k / to_v / to_qkv_multiscale / nonlinearity / apply_linear_attention / to_out / norm_type / norm_out /
+    residual_connection / attention_head_dim`), in plain torch on whatever device the tensors live."""
+
+    def __init__(self):
+        self.seen = []
+
+    def __call__(self, attn, hidden_states, gate=None):
+        self.seen.append((tuple(hidden_states.shape), None if gate is None else tuple(gate.shape), hidden_states.is_cuda))
+        B, _, H, W = hidden_states.shape
+        residual = hidden_states
+        hl = hidden_states.movedim(1, -1)
+        qkv = torch.cat([attn.to_q(hl), attn.to_k(hl), attn.to_v(hl)], dim=3).movedim(-1, 1)
+        hs = torch.cat([qkv] + [blk(qkv) for blk in attn.to_qkv_multiscale], dim=1).to(torch.float32)
+        q, k, v = hs.reshape(B, -1, 3 * attn.attention_head_dim, H * W).chunk(3, dim=2)
+        q, k = attn.nonlinearity(q), attn.nonlinearity(k)
+        out = attn.apply_linear_attention(q, k, v) if H * W > attn.attention_head_dim else attn.apply_quadratic_attention(q, k, v)
+        out = attn.to_out(out.reshape(B, -1, H, W).movedim(1, -1)).movedim(-1, 1)
+        if gate is not None:
+            out = out * gate
+        assert attn.norm_type == "rms_norm"
+        out = attn.norm_out(out.movedim(1, -1)).movedim(-1, 1)
+        return out + residual if attn.residual_connection else out
+
+
+def test_foreign_dcae_attention_processor_is_called_not_ignored():
+    """`attn.processor` of the DC-AE's SanaMultiscaleLinearAttention (models/DCAE.py:156,205-210; SURVEY 8(b) operator plug-points): an object that
+    is not the built-in processor is CALLED with the reference's protocol `(attn, hidden_states, gate=gate_msa)` - round 5 refused it.
+    (1) the reference-protocol processor above, installed on every attention block of the HIP autoencoder, reproduces the oracle and the fused path;
+    (2) a processor with other arithmetic changes the result - it really ran; (3) the timestep-conditioned model hands it the AdaLN gate; (4) the
+    split modes and hipGraph capture refuse it; (5) re-installing the built-in processor restores the fused path bit for bit."""
+    from ladcast_amd.models.DCAE import SanaMultiscaleAttnProcessor2_0, SanaMultiscaleLinearAttention
+
+    o, g = _pair(tiny_dcae_config())
+    f, st = synth_field(2, 8, 48, 64), synth_field(1, 5, 48, 64, seed=1)
+    with torch.no_grad():
+        zo = o.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        yo = o.decode(zo).sample
+    fused_z = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+    fused_y = g.decode(zo.cuda()).sample
+    attns = [m for m in g.modules() if isinstance(m, SanaMultiscaleLinearAttention)]
+    assert len(attns) == 4 and all(a.foreign_processor is None for a in attns)  # 2 EfficientViT stages x 1 layer, encoder + decoder
+    proc = _ReferenceProtocolProcessor()
+    for a in attns:
+        a.processor = proc  # the reference's plug-point: a plain attribute (models/DCAE.py:156)
+    try:
+        z = g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent
+        y = g.decode(zo.cuda()).sample
+        assert len(proc.seen) == 4 and all(s[1] is None and s[2] for s in proc.seen)
+        assert sorted(s[0] for s in proc.seen) == sorted([(2, 64, 12, 16), (2, 128, 6, 8)] * 2)  # NCHW at the two EfficientViT stages
+        ez, ey = rel_l2(z.cpu(), zo), rel_l2(y.cpu(), yo)
+        print(f"\nforeign DC-AE attention processor vs oracle: encode {ez:.2e}, decode {ey:.2e}; vs fused path {rel_l2(z, fused_z):.2e} / {rel_l2(y, fused_y):.2e}")
+        assert ez < 2e-5 and ey < 2e-5 and rel_l2(z, fused_z) < 2e-5 and rel_l2(y, fused_y) < 2e-5
+
+        class DropAttention(_ReferenceProtocolProcessor):  # other arithmetic: the attention branch is dropped, only the residual passes
+            def __call__(self, attn, hidden_states, gate=None):
+                super().__call__(attn, hidden_states, gate)
+                return hidden_states
+
+        attns[0].processor = DropAttention()
+        assert rel_l2(g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent, fused_z) > 1e-3
+        attns[0].processor = proc
+        g.set_gemm_precision("bf16x3")
+        with pytest.raises(NotImplementedError):
+            g.encode(f.cuda(), static_conditioning_tensor=st.cuda())
+        g.set_gemm_precision("fp32")
+        with pytest.raises(NotImplementedError):
+            g.enable_hip_graph(True)
+    finally:
+        g.set_gemm_precision("fp32")
+        for a in attns:
+            a.processor = SanaMultiscaleAttnProcessor2_0()
+    assert torch.equal(g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent, fused_z)
+    g.enable_hip_graph(True)  # ... and graph capture works again
+    assert torch.equal(g.encode(f.cuda(), static_conditioning_tensor=st.cuda()).latent, fused_z)
+    g.enable_hip_graph(False)
+
+    # the timestep-conditioned variant: the processor receives AdaLayerNormZeroSingle4Sana's gate as (B, C, 1, 1) and the NORMALISED tensor
+    cfg = dict(tiny_dcae_config(), temb_channels=48)
+    ot, gt = _pair(cfg)
+    tt = torch.tensor([0.3, 1.7])
+    from oracle.layers import get_timestep_embedding
+
+    with torch.no_grad():
+        emb = ot.timestep_embedder(get_timestep_embedding(tt, 256))
+        zt = ot.encode(f, temb=emb, embedded_t=True, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+    fused_t = gt.encode(f.cuda(), temb=tt.cuda(), static_conditioning_tensor=st.cuda()).latent
+    proc_t = _ReferenceProtocolProcessor()
+    for a in (m for m in gt.modules() if isinstance(m, SanaMultiscaleLinearAttention)):
+        a.processor = proc_t
+    got_t = gt.encode(f.cuda(), temb=tt.cuda(), static_conditioning_tensor=st.cuda()).latent
+    assert sorted(s[1] for s in proc_t.seen) == [(2, 64, 1, 1), (2, 128, 1, 1)]
+    et = rel_l2(got_t.cpu(), zt)
+    print(f"timestep-conditioned: foreign processor vs oracle {et:.2e}, vs fused {rel_l2(got_t, fused_t):.2e}")
+    assert et < 2e-5 and rel_l2(got_t, fused_t) < 2e-5

@@ -243,10 +243,23 @@ def test_attention_processor_surface_is_honest():
 
     ae = AutoencoderDC.from_config(tiny_dcae_config())
     attn = next(mod for mod in ae.modules() if hasattr(mod, "to_qkv_multiscale"))
-    assert isinstance(attn.processor, SanaMultiscaleAttnProcessor2_0)
+    assert isinstance(attn.processor, SanaMultiscaleAttnProcessor2_0) and attn.foreign_processor is None
+    # round 6 (models/DCAE.py:156,205-210): the DC-AE's plug-point is honoured like the transformer's - a foreign processor is kept and CALLED
+    # (tests/test_gpu_dcae.py), and the graph mode refuses it; what such a processor reads from the module exists
+    attn.processor = Foreign()
+    assert attn.foreign_processor is attn.processor
+    assert attn.norm_type == "rms_norm" and attn.residual_connection and callable(attn.apply_linear_attention) and callable(attn.nonlinearity)
     with pytest.raises(NotImplementedError):
-        attn.processor = Foreign()
+        ae.enable_hip_graph(True)
     attn.processor = SanaMultiscaleAttnProcessor2_0()
+    assert attn.foreign_processor is None
+    ae.enable_hip_graph(True)
+    # torch arithmetic of the helpers a foreign processor calls (CPU tensors): linear attention == quadratic attention on the same q, k, v
+    q, k, v = (torch.rand(1, 2, 32, 40, generator=torch.Generator().manual_seed(i)) for i in range(3))
+    lin = attn.apply_linear_attention(q, k, v)
+    scores = torch.matmul(k.transpose(-1, -2), q)
+    quad = torch.matmul(v, scores) / (scores.sum(dim=2, keepdim=True) + attn.eps)
+    assert torch.allclose(lin, quad, rtol=1e-4, atol=1e-5)
 
 
 def test_gemv_first_read_guard_is_in_the_shipped_kernels():
