@@ -36,7 +36,7 @@ class KernelTimer:
                 ring = all(p[0].d.K % 32 == 0 and p[0].d.ldw == p[0].d.K for p in problems) and os.environ.get("LDC_F32_RING", "1") != "0"
                 name = "gemm_bf16x3_v3_kernel<128, 0, false>" if ring else "gemm_streamk_kernel"
             elif all(p[0].d.K % 32 == 0 for p in problems):
-                name = timer.v3_variant(problems) if all(p[0].d.flags & 1 for p in problems) else "gemm_bf16x3_dma_kernel"
+                name = timer.v3_variant(problems) if all(p[0].d.flags & 1 for p in problems) else "gemm_streamk_bf16x3_kernel"
             else:
                 name = "gemm_streamk_bf16x3_kernel"
             return timer._bracket(name, flops(problems), orig["gemm_grouped"], problems, split_bf16=split_bf16)

@@ -422,7 +422,7 @@ int ldc_pixel_shuffle_shortcut(const float* cv, const float* x, float* y, int B,
 int ldc_chan_regroup(const float* x, float* y, long long M, int cin, int cout, void* stream);
 
 /* ldc_sphere_conv_nhwc (dense SphereConv2d, same contract) on PRE-SPLIT activations (the DCAE's `bf16x3` path since round 2; round 1's
- * fp32-rows-in entry point ldc_sphere_conv_nhwc_bf16x3 left the ABI in version 3 - it survives in the `make ab` build for tools/conv_bench.py): X holds NHWC rows in the split format
+ * fp32-rows-in entry point ldc_sphere_conv_nhwc_bf16x3 left the ABI in version 3 - it left the tree with round 1's kernel in round 6): X holds NHWC rows in the split format
  * (in_fmt = LDC_FMT_SPLIT: columns 8g..8g+7 in 32 bytes [hi x8 | lo x8]; ldx % 8 == 0, ldx >= cin rounded up to 8, pad columns
  * zero), written by the producers below, so the conv's main loop is the pre-split GEMM kernel (gemm_bf16x3_v3.hip: 16x16x32 MFMA, no
  * VALU in the loop) with the sphere gather as per-lane LDS-DMA source addresses.  Wp: ldc_pack_weight_bf16x2 of the tap-major weight

@@ -1,7 +1,7 @@
 // Split-bf16 ("bf16x3") stream-K GEMM, third generation: pre-split activations (LDC_GEMM_A_SPLIT) only,
 // v_mfma_f32_16x16x32_bf16, 8 waves for both tile heights.
 //
-// Why a third kernel (measurements of gemm_bf16x3_dma.hip, in-kernel clock stamps, tools/gemm_stamps.py):
+// Why a third kernel (measurements of round 1's fp32-activation LDS-DMA kernel, removed in round 6; in-kernel clock stamps, tools/gemm_stamps.py):
 //   * the chip is at its power limit in these loops -- the 256-row kernel at 76 % MFMA busy ran at 1.30 GHz, the
 //     128-row kernel at 52 % busy at 1.88 GHz, both delivering about the same FLOP/s per CU -- so what is left to
 //     gain is energy per FLOP.  MI355X_MICROARCH.md (DVFS give-back, item 7) measures the 16x16x32 shape at
@@ -12,7 +12,7 @@
 //     at one per SIMD, which is what made the half-height tile 20 % slower per CU.
 // Tile BM x 128 x 32 per k-step, BM = 256 (wave = 2 row tiles of 16) or 128 (1 row tile); operands through the same
 // 3-stage LDS-DMA ring, unit-range stream-K scheduling, XCD-aware placement and in-launch "last arriver reduces"
-// hand-off as gemm_bf16x3_dma.hip (see there for the protocol); only the LDS image swizzle, the k-step body and the
+// hand-off as the round-1 kernel it replaced (protocol: the publish / ticket / last-arriver block below); only the LDS image swizzle, the k-step body and the
 // accumulator layout differ:
 //   * a row of a stage is 4 k-groups x [hi 16 B | lo 16 B]; chunk c = 2 kg + (0 hi | 1 lo) of row r sits in slot
 //     c ^ f(r), f(r) = ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1): conflict-free for the four 16-lane groups of
@@ -31,6 +31,7 @@
 namespace {
 
 #include "gemm_v3_common.inc"
+#include "gemm_v3_kstep_f32.inc"
 
 struct SKArgs {
   DevProblem pr[MAXP];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
   int seg_ = 0;
   (void)seg_;
   int g;
-  {  // XCD-aware placement: each XCD gets a contiguous run of unit ranges (gemm_bf16x3_dma.hip)
+  {  // XCD-aware placement: each XCD gets a contiguous run of unit ranges
     const int bid = blockIdx.x, G = a.G;
     const int q = G >> 3, r = G & 7, xcd = bid & 7;
     g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -429,64 +430,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     sb = sb1;                                                                                                \
   }
 
-    // Round 6, exact-fp32 128-row instances: the same k-step with the column tiles taken in PAIRS whose MFMAs alternate.
-    // v_mfma_f32_16x16x4_f32 issues every 32 cycles but its result feeds a dependent MFMA only after 40 (MI355X_MICROARCH.md, cycle constants), and the
-    // k-step above runs the 8 MFMAs of a column tile as ONE accumulation chain (RT = 1: one accumulator per column tile): whenever the SIMD's other
-    // wave is not issuing (waits, DMA issue, barrier skew) the chain runs at 40 cycles per MFMA - 75.7 % MFMA busy in round 5.  Two column tiles
-    // (two accumulators) alternating put 64 cycles between dependent MFMAs.  Per accumulator the order of its 8 MFMAs is unchanged: results are
-    // bit-identical.  Fragment window: tiles (0,1) | reload 4,5 | (2,3) | reload 6,7 | (4,5) | barrier | A(kt+1), W(kt+1; 0,1) | (6,7) | W(kt+1; 2,3);
-    // reads return in order, so at entry 10 are outstanding [A x2, W0 x2, W1 x2, W2 x2, W3 x2] and every wait below leaves the 4 youngest.
-#define LDC_CT2(C0, WH0, WL0, C1, WH1, WL1, AH, AL)                              \
-  if (wave_rows) {                                                               \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                           \
-      LDC_MMF(acc[(C0)], WH0, AH[0], j_)                                         \
-      LDC_MMF(acc[(C1)], WH1, AH[0], j_)                                         \
-    }                                                                            \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                           \
-      LDC_MMF(acc[(C0)], WL0, AL[0], j_)                                         \
-      LDC_MMF(acc[(C1)], WL1, AL[0], j_)                                         \
-    }                                                                            \
-  }
-#define LDC_KSTEP_P(AH, AL, AHN, ALN)                                                                        \
-  {                                                                                                          \
-    const int st1 = st == NSTAGE - 1 ? 0 : st + 1;                                                           \
-    const int st2 = st1 == NSTAGE - 1 ? 0 : st1 + 1;                                                         \
-    const unsigned sb1 = st1 * STAGE_B;                                                                      \
-    const unsigned wch = w_hi + sb, wcl = w_lo + sb, wnh = w_hi + sb1, wnl = w_lo + sb1;                     \
-    const unsigned anh = a_hi + sb1, anl = a_lo + sb1;                                                       \
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(AH[0]), "+v"(AL[0]), "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1)); \
-    LDC_SB;                                                                                                  \
-    LDC_CT2(0, wh0, wl0, 1, wh1, wl1, AH, AL)                                                                \
-    LDC_RD_W(wh0, wl0, wch, wcl, 4)                                                                          \
-    LDC_RD_W(wh1, wl1, wch, wcl, 5)                                                                          \
-    issue_one(kt + 2, st2, NDH + 0);                                                                         \
-    issue_one(kt + 2, st2, NDH + 1);                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));                       \
-    LDC_SB;                                                                                                  \
-    LDC_CT2(2, wh2, wl2, 3, wh3, wl3, AH, AL)                                                                \
-    LDC_RD_W(wh2, wl2, wch, wcl, 6)                                                                          \
-    LDC_RD_W(wh3, wl3, wch, wcl, 7)                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wh0), "+v"(wl0), "+v"(wh1), "+v"(wl1));                       \
-    LDC_SB;                                                                                                  \
-    LDC_CT2(4, wh0, wl0, 5, wh1, wl1, AH, AL)                                                                \
-    /* barrier(kt+1): done READING stage kt (tiles 6, 7 were requested a pair of column tiles ago); DMAs of kt+1 landed */ \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wh2), "+v"(wl2), "+v"(wh3), "+v"(wl3));                       \
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                         \
-    LDC_KSTEP_BARRIER                                                                                        \
-    LDC_SB;                                                                                                  \
-    LDC_RD_A(AHN, ALN, anh, anl)                                                                             \
-    LDC_RD_W(wh0, wl0, wnh, wnl, 0)                                                                          \
-    LDC_RD_W(wh1, wl1, wnh, wnl, 1)                                                                          \
-    issue_one(kt + 3, st, 0);                                                                                \
-    issue_one(kt + 3, st, 1);                                                                                \
-    LDC_SB;                                                                                                  \
-    LDC_CT2(6, wh2, wl2, 7, wh3, wl3, AH, AL)                                                                \
-    LDC_RD_W(wh2, wl2, wnh, wnl, 2)                                                                          \
-    LDC_RD_W(wh3, wl3, wnh, wnl, 3)                                                                          \
-    LDC_SB;                                                                                                  \
-    st = st1;                                                                                                \
-    sb = sb1;                                                                                                \
-  }
+    // Round 6, exact-fp32 128-row instances: LDC_KSTEP_Q (gemm_v3_kstep_f32.inc, generated by tools/gen_gemm_f32_kstep.py) - column tiles in pairs
+    // whose MFMAs alternate, every fragment read / DMA issue in the gap behind one of the wave's own MFMAs.  MM: the MFMA itself, or nothing for a
+    // wave whose rows all lie past the end of a ragged tile (the branch sits around the whole loop, not around every MFMA).
+#define LDC_MM_ON(ACC, WF, AF, J) LDC_MMF(ACC, WF, AF, J)
+#define LDC_MM_OFF(ACC, WF, AF, J)
 #if defined(LDC_AB_BUILD) && defined(LDC_GEMM_F32_NO_PAIRS)  // A/B aid (make variant DIAG=-DLDC_GEMM_F32_NO_PAIRS): round 5's k-step
   constexpr bool PAIRED = false;
 #else
@@ -518,29 +466,43 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
     __builtin_amdgcn_s_barrier();
     LDC_STAMP(1 + 4 * seg_)
     if (seg_ == 0) { LDC_STAMP_CLK(13) }
-    LDC_RD_A(ah0, al0, a_hi, a_lo)
-    LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
-    LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
-    LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
-    LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
+    if constexpr (PAIRED) {
+      LDC_KSTEP_Q_PROLOGUE(ah0, al0)
+    } else {
+      LDC_RD_A(ah0, al0, a_hi, a_lo)
+      LDC_RD_W(wh0, wl0, w_hi, w_lo, 0)
+      LDC_RD_W(wh1, wl1, w_hi, w_lo, 1)
+      LDC_RD_W(wh2, wl2, w_hi, w_lo, 2)
+      LDC_RD_W(wh3, wl3, w_hi, w_lo, 3)
+    }
 #pragma unroll
     for (int i = 0; i < NDH; ++i) issue_one(k0 + 2, 2, i);
     LDC_SB;
 
     unsigned sb = 0;  // LDS byte offset of stage kt
     int st = 0;       // stage index of k-step kt
-    for (int kt = k0; kt < k1; ++kt) {
-      if constexpr (PAIRED) {
-        static_assert(!PAIRED || ND == 4, "the paired k-step is written for the 128-row tile's 4 DMA pieces");
-        LDC_KSTEP_P(ah0, al0, ah1, al1)
+    if constexpr (PAIRED) {
+      static_assert(!PAIRED || ND == 4, "the interleaved k-step is written for the 128-row tile's 4 DMA pieces");
+      if (wave_rows) {
+        for (int kt = k0; kt < k1; ++kt) {
+          LDC_KSTEP_Q(ah0, al0, ah1, al1, LDC_MM_ON)
+          ++kt;
+          if (kt >= k1) break;
+          LDC_KSTEP_Q(ah1, al1, ah0, al0, LDC_MM_ON)
+        }
       } else {
-        LDC_KSTEP(ah0, al0, ah1, al1)
+        for (int kt = k0; kt < k1; ++kt) {
+          LDC_KSTEP_Q(ah0, al0, ah1, al1, LDC_MM_OFF)
+          ++kt;
+          if (kt >= k1) break;
+          LDC_KSTEP_Q(ah1, al1, ah0, al0, LDC_MM_OFF)
+        }
       }
-      ++kt;
-      if (kt >= k1) break;
-      if constexpr (PAIRED) {
-        LDC_KSTEP_P(ah1, al1, ah0, al0)
-      } else {
+    } else {
+      for (int kt = k0; kt < k1; ++kt) {
+        LDC_KSTEP(ah0, al0, ah1, al1)
+        ++kt;
+        if (kt >= k1) break;
         LDC_KSTEP(ah1, al1, ah0, al0)
       }
     }
@@ -549,8 +511,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(ah0[rt]), "+v"(al0[rt]), "+v"(ah1[rt]), "+v"(al1[rt]));
 #undef LDC_KSTEP
-#undef LDC_KSTEP_P
-#undef LDC_CT2
+#undef LDC_MM_ON
+#undef LDC_MM_OFF
 #undef LDC_WAIT
 #undef LDC_CT
 #undef LDC_MMF
@@ -579,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_v3_kernel(SKArgs a) {
       tile_epilogue<BM, !CONV, LinearRows<BM>, true, TERMS == 0>(P, b, bm, bn, acc, wave, lane);
     } else {
       // ---- publish this piece (write-through slab, drained, ONE ticket per workgroup); the piece whose ticket is
-      // the last re-reads all slabs of the tile in workgroup order and applies the epilogue (gemm_bf16x3_dma.hip) ----
+      // the last re-reads all slabs of the tile in workgroup order and applies the epilogue ----
       const int lane_h = fresh_lane();  // slab addresses are formed here, not hoisted to the kernel entry and spilled across the main loop
       float* slot = a.ws + (static_cast<long long>(2 * g) + (k0 > 0 ? 0 : 1)) * SLOT_FLOATS + lane_h;
 #pragma unroll
@@ -730,7 +692,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
       // super-row height: an XCD's share is ~T8 = tiles / 8 consecutive tiles = rm row panels x T8 / rm column panels; per k-step
       // it pulls rm * BM + (T8 / rm) * BN operand rows through the fabric -> minimum at rm = sqrt(T8 * BN / BM); super-rows of
       // (nearly) equal height.  Only when the activation panel is what the one-super-row order over-fetches (every XCD streams all
-      // of A): measured (tools/gemm_rm_ab.py, profiles/r02_c_gemm_tile_order_ab.log) 2250 x 1536 x 7680 -3.4 % time / -31 % fabric
+      // of A): measured (profiles/r02_c_gemm_tile_order_ab.log) 2250 x 1536 x 7680 -3.4 % time / -31 % fabric
       // bytes and 18000 x 1536 x 7680 -10 %, but +3 % on 2250 x 4608 / 10752 x 1536, whose 14 MB A panel stays cached anyway.
       // LDC_BF16X3_RM (measurement aid, read per call): force it; 0 = one super-row
       P.rm = P.tm;
@@ -755,7 +717,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
   }
   if (tiles > LDC_GEMM_COUNTER_BYTES / 4 - 16) return LDC_ERR_UNSUPPORTED;  // in-launch reduction only; last 64 B: zero page
   const long long slot_bytes = SLOT_FLOATS * static_cast<long long>(sizeof(float));
-  // grid size: as gemm_bf16x3_dma.hip (phase-aligned divisor of tiles * s when every problem has the same k-depth)
+  // grid size: (phase-aligned divisor of tiles * s when every problem has the same k-depth)
   long long G = CUS;
   {
     bool same_kt = true;
@@ -853,7 +815,7 @@ int launch_v3(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int
 
 }  // namespace
 
-// returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back to gemm_bf16x3_dma.hip)
+// returns LDC_ERR_UNSUPPORTED when a problem does not fit this kernel (caller falls back to the register-staged kernel of gemm_streamk.hip)
 static int gemm_v3_dispatch(const ldc_gemm_problem* problems, const ldc_qkv_epilogue* epi, int n, void* workspace,
                             long long workspace_bytes, void* stream) {
   LDC_CHECK_PTR(problems);

@@ -561,23 +561,17 @@ extern "C" int ldc_gemm_grouped(const ldc_gemm_problem* problems, int n, void* w
 
 int ldc_gemm_grouped_bf16x3_v3(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
                                void* stream);  // gemm_bf16x3_v3.hip
-#ifdef LDC_AB_BUILD
-int ldc_gemm_grouped_bf16x3_dma(const ldc_gemm_problem* problems, int n, void* workspace, long long workspace_bytes,
-                                void* stream);  // gemm_bf16x3_dma.hip: round 1's 32x32x16 kernel for fp32 activations, A/B build only
-#endif
 
 extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, void* workspace,
                                        long long workspace_bytes, void* stream) {
   // Pre-split activations (LDC_GEMM_A_SPLIT) and K % 32 == 0 - every launch of the models: the 16x16x32 ring kernel
   // (gemm_bf16x3_v3.hip); anything else (fp32 activations, K % 32 != 0): the register-staged kernel below, which splits in its loop.
-  // A/B build only: round 1's LDS-DMA kernel for fp32 activations in between, LDC_BF16X3_KERNEL=regstage / dma forces the older ones.
+  // A/B build only: LDC_BF16X3_KERNEL=regstage forces the register-staged kernel.
   int force = 0;
 #ifdef LDC_AB_BUILD
   static const int force_env = [] {
     const char* e = getenv("LDC_BF16X3_KERNEL");
-    if (e != nullptr && strcmp(e, "regstage") == 0) return 1;
-    if (e != nullptr && strcmp(e, "dma") == 0) return 2;
-    return 0;
+    return (e != nullptr && strcmp(e, "regstage") == 0) ? 1 : 0;
   }();
   force = force_env;
 #endif
@@ -585,12 +579,6 @@ extern "C" int ldc_gemm_grouped_bf16x3(const ldc_gemm_problem* problems, int n, 
     const int st = ldc_gemm_grouped_bf16x3_v3(problems, n, workspace, workspace_bytes, stream);
     if (st != LDC_ERR_UNSUPPORTED) return st;
   }
-#ifdef LDC_AB_BUILD
-  if (force != 1) {
-    const int st = ldc_gemm_grouped_bf16x3_dma(problems, n, workspace, workspace_bytes, stream);
-    if (st != LDC_ERR_UNSUPPORTED) return st;
-  }
-#endif
   return gemm_grouped_impl(problems, n, workspace, workspace_bytes, stream, true);
 }
 

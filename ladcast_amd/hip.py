@@ -614,21 +614,6 @@ def conv_cin_padded(cin, cpk=32):
     return cpk * p2
 
 
-def sphere_conv_nhwc_bf16x3(X, Wp, Y, *, B, H, W, cin, cout, ldx=None, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE):
-    """A/B BUILD ONLY (`make -C ladcast_amd/csrc ab`, LDC_LIB_PATH=ladcast_amd/libladcast_hip_ab.so; tools/conv_bench.py): round 1's conv entry
-    point with fp32 rows in and the split in the loop - it left the shipped ABI in version 3.  Wp: pack_weight_bf16x2 of the
-    [cout, k*k*conv_cin_padded(cin)] tap-major weight (zeros behind cin)"""
-    _dev(X, Wp, Y, bias, R)
-    if not hasattr(lib, "ldc_sphere_conv_nhwc_bf16x3"):
-        raise RuntimeError("ldc_sphere_conv_nhwc_bf16x3 exists in the A/B build only (make ab; LDC_LIB_PATH=.../libladcast_hip_ab.so)")
-    I_, P_, L_ = c_int, c_void_p, c_longlong
-    lib.ldc_sphere_conv_nhwc_bf16x3.restype, lib.ldc_sphere_conv_nhwc_bf16x3.argtypes = I_, [P_] * 5 + [I_] * 10 + [P_, L_, P_]
-    ws = _grouped_workspace(X.device)
-    _check(lib.ldc_sphere_conv_nhwc_bf16x3(_p(X), _p(Wp), _p(bias), _p(R), _p(Y), B, H, W, cin, ldx if ldx is not None else cin, cout,
-                                           ldy if ldy is not None else cout, ldr, ksize, act, _p(ws), ws.numel() * 4, _stream()),
-           "ldc_sphere_conv_nhwc_bf16x3")
-
-
 def sphere_conv_nhwc_split(X, Wp, Y, *, B, H, W, cin, cout, ldx, ldy=None, bias=None, R=None, ldr=0, ksize=3, act=ACT_NONE, in_fmt=FMT_SPLIT,
                            out_fmt=FMT_F32):
     """X: operand rows (FMT_SPLIT: Wp = pack_weight_bf16x2 of the [cout, k*k*conv_cin_padded(cin)] tap-major weight, zeros behind cin | FMT_BF16: Wp = pack_weight_bf16 of the taps padded to 64 * 2^j channels;

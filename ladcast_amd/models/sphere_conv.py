@@ -28,7 +28,7 @@ def pack_dense_weight(w: torch.Tensor) -> torch.Tensor:
 
 def pack_dense_weight_bf16x3(w: torch.Tensor) -> torch.Tensor:
     """[Cout, Cin, k, k] -> split-bf16 packed weight of the tap-major [Cout, k*k*Cin_pp] matrix, Cin_pp = 32 * 2^j >= Cin
-    with zeros behind Cin (ldc_sphere_conv_nhwc_bf16x3)."""
+    with zeros behind Cin (ldc_sphere_conv_nhwc_split, LDC_FMT_SPLIT)."""
     co, ci, k, _ = w.shape
     cpp = hip.conv_cin_padded(ci)
     out = torch.zeros(co, k * k, cpp, device=w.device, dtype=torch.float32)

@@ -255,7 +255,8 @@ def roll_out_serial(
     ``decode_batch_frames`` (extension, decoded mode; default None = decode every chunk right after it, as :580-585): keep the chunks' latents in
     HBM (151 KB per member-chunk) and decode them AFTER the last chunk of an initial time in batches of up to that many frames - the decoder runs
     at its large-batch rate (2.4 instead of 3.3 ms per frame on one MI355X at 32 frames).  The same decoder on the same latents: values agree
-    with the per-chunk order to fp32 rounding (the conv kernels pick their schedule from the launch size), not bit for bit.
+    with the per-chunk order to fp32 rounding in the fp32 / bf16x3 modes (the conv kernels pick their schedule from the launch size), not bit for
+    bit; in the single-term bf16 mode, where every activation is rounded to bf16, at that mode's own error level (tests/test_gpu_cfg5.py).
     """
     if not return_tensor:
         raise NotImplementedError("xarray output is out of scope; use return_tensor=True")

@@ -95,15 +95,28 @@ def test_cfg5_end_to_end_three_chunks_bf16_mixed_vs_oracle_and_autocast():
     gar.enable_hip_graph(False)
     assert torch.equal(got_graph[:, :, :, 1:], got[:, :, :, 1:])
     # round 6: `decode_batch_frames` - the chunks' latents stay in HBM and are decoded after the last chunk in large batches (32: all 12 lead
-    # steps x 2 members in one decoder call; 5: two lead steps per call, six calls).  Same decoder, same latents: equal to the per-chunk order to
-    # fp32 rounding (the conv kernels pick their schedule from the launch size); slot 0 (the raw IC field) bit for bit
+    # steps x 2 members in one decoder call; 5: two lead steps per call, six calls).  Same decoder, same latents; the conv kernels pick their schedule
+    # from the launch size, so the fp32 accumulation order differs - and in THIS mode every activation is then rounded to bf16, which turns a last-bit
+    # difference into an occasional 2^-9 one: the two decode orders agree at the mode's own error level (1.1e-3 measured, against 2.6e-3 to the
+    # oracle), and each is held to the oracle at the stated tolerance.  Slot 0 (the raw IC field) bit for bit.  In the exact-fp32 mode the two orders
+    # agree to rounding (below).
     for nb in (32, 5):
         got_def = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, decode_batch_frames=nb, **hip_kw)
-        e_def = rel_l2(got_def[:, :, :, 1:], got[:, :, :, 1:])
-        print(f"cfg5 tiny, decode deferred in batches of <= {nb} frames vs per-chunk decode: rel-L2 {e_def:.1e}")
-        assert got_def.shape == got.shape and e_def < 1e-5 and torch.equal(got_def[:, :, :, 0], got[:, :, :, 0])
+        e_def, e_or = rel_l2(got_def[:, :, :, 1:], got[:, :, :, 1:]), per_chunk(got_def, want)
+        print(f"cfg5 tiny [bf16 mode], decode deferred in batches of <= {nb} frames: vs per-chunk decode rel-L2 {e_def:.1e}; vs fp32 oracle per chunk {_fmt(e_or)}")
+        assert got_def.shape == got.shape and torch.equal(got_def[:, :, :, 0], got[:, :, :, 0])
+        assert e_def < tolerance("bf16", "rollout_decoded") and max(e_or) < tolerance("bf16", "rollout_decoded")
     mean_def = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, return_ensemble_mean=True, decode_batch_frames=32, **hip_kw)
-    assert mean_def.shape == (1, 1, 84, 1 + R * chunks, 120, 240) and rel_l2(mean_def[:, 0, :, 1:], got[:, :, :, 1:].mean(dim=1)) < 1e-5
+    assert mean_def.shape == (1, 1, 84, 1 + R * chunks, 120, 240) and rel_l2(mean_def[:, 0, :, 1:], got[:, :, :, 1:].mean(dim=1)) < tolerance("bf16", "rollout_decoded")
+    gae.set_gemm_precision("fp32")
+    gar.set_gemm_precision("fp32")
+    f_chunk = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, **hip_kw)
+    f_def = roll_out_serial(lambda t: field, t0, pipe, return_latent=False, decode_batch_frames=32, **hip_kw)
+    e_f = rel_l2(f_def[:, :, :, 1:], f_chunk[:, :, :, 1:])
+    print(f"cfg5 tiny [fp32 mode], decode deferred in one batch vs per-chunk decode: rel-L2 {e_f:.1e}; vs fp32 oracle per chunk {_fmt(per_chunk(f_def, want))}")
+    assert e_f < 1e-5 and max(per_chunk(f_def, want)) < 1e-4
+    gae.set_gemm_precision("bf16")
+    gar.set_gemm_precision("bf16")
     e_dec, e_lat = per_chunk(got, want), per_chunk(got_lat, want_lat)
     e_ic = rel_l2(got_lat[:, :, :, 0], want_lat[:, :, :, 0])
     print(f"cfg5 tiny, HIP bf16 mode vs fp32 oracle: IC latent {e_ic:.1e}; per chunk: decoded {_fmt(e_dec)} | latent {_fmt(e_lat)}")

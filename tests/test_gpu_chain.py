@@ -317,3 +317,62 @@ def test_1_6b_full_length_heun_chunk_vs_committed_oracle(golden_dir):
 def test_375m_two_members_full_length_heun_chunk_vs_committed_oracle(golden_dir):
     """the 375M at batch 2 (cfg 3's share of one GPU) at the literal 20 solver steps: 39 forwards of a 2-member batch"""
     _literal_chunk_vs_golden(golden_dir, "fullsize_375m_2members.npz", CONFIG_375M, 2, "375M")
+
+
+def _literal_chain_vs_golden(golden_dir, name, cfg, members, lead_hours, label, frames_per_chunk):
+    """a chained roll_out_serial at the reference's LITERAL chunk length (20 solver steps = 39 forwards per chunk, pipelines/edm_sampler.py:60-113; chunks
+    chained through each member's own last frame, pipelines/utils.py:533-563) against the committed oracle run (tests/golden/make_fullsize_golden.py
+    literal_chain: ~13 - 26 min of CPU in the build container, < 3 s per mode on the GPU), fp32 and split-bf16, graph-replayed as the product runs it,
+    per-chunk rel-L2 printed; eager launches must give the same bits"""
+    import os
+
+    from ladcast_amd.pipelines import AutoRegressive2DPipeline, roll_out_serial
+    from ladcast_amd.schedulers import EDMDPMSolverMultistepScheduler
+    from tests.synth import load_fullsize_golden
+
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated (python tests/golden/make_fullsize_golden.py literal_chain)")
+    fx = load_fullsize_golden(path)
+    want = fx["want"]
+    total = lead_hours // 6
+    assert tuple(want.shape) == (1, members, 84, 1 + total, 15, 30) and not torch.isnan(want).any()
+    o = make_ar(dict(cfg))  # the same seeded weights the golden run used
+    g = to_hip(o, dict(cfg))
+    del o
+    targs = {"mean": [0.1] * 84, "std": [1.3] * 84, "target_std": 0.5}
+    ic = synth_known(1)[0] * 2.6 + 0.1
+    t0 = [datetime(2018, 1, 1, 0)]
+    kw = dict(ensemble_size=members, num_inference_steps=20, return_seq_len=4, latent_transform_args=targs, total_lead_time_hour=lead_hours, sampler_type="edm",
+              return_latent=True)
+    bounds = [(1 + 4 * c, min(5 + 4 * c, 1 + total)) for c in range(-(-total // 4))]
+    assert [b - a for a, b in bounds] == frames_per_chunk
+    if members > 1:
+        assert rel_l2(want[:, 0], want[:, 1]) > 1e-2  # the members really differ (their own noise)
+    for mode in ("fp32", "bf16x3"):
+        g.set_gemm_precision(mode).enable_hip_graph(True)
+        got = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **kw)
+        g.enable_hip_graph(False)
+        assert got.shape == want.shape and not torch.isnan(got).any() and torch.equal(got[:, :, :, 0], want[:, :, :, 0])  # slot 0: the IC latent
+        per_chunk = [rel_l2(got[:, :, :, a:b], want[:, :, :, a:b]) for a, b in bounds]
+        print(f"\n{label}: {members} member(s) x {total} lead steps = {len(bounds)} chained chunks x 39 forwards (oracle {float(fx['seconds'][0]):.0f} s in the build "
+              f"container) [{mode}] per-chunk rel-L2: {_fmt(per_chunk)}")
+        assert max(per_chunk) < TOL, (mode, per_chunk)
+        if mode == "fp32":  # eager launches = the graph-replayed chunks, bit for bit (first chunk suffices: the chain feeds on it)
+            eager = roll_out_serial(None, t0, AutoRegressive2DPipeline(g, EDMDPMSolverMultistepScheduler()), known_latents_override=ic, **dict(kw, total_lead_time_hour=24))
+            assert torch.equal(eager[:, :, :, 1:5], got[:, :, :, 1:5])
+    g.set_gemm_precision("fp32")
+
+
+def test_cfg4_literal_1_6b_ten_lead_steps_three_chunks_vs_committed_oracle(golden_dir):
+    """BASELINE configs[3] AS WRITTEN, one GPU's share (VERDICT r05 item 4 / missing 2): the 1.6B model, 1 member, 20 solver steps, 10 lead steps = two
+    full chunks and one cut to 2 frames - 117 network evaluations chained through the member's last frame"""
+    from oracle.ar_model import CONFIG_1_6B
+
+    _literal_chain_vs_golden(golden_dir, "fullsize_1p6b_literal_chain.npz", CONFIG_1_6B, 1, 60, "cfg 4 literal (1.6B)", [4, 4, 2])
+
+
+def test_cfg3_literal_375m_two_members_three_chained_chunks_vs_committed_oracle(golden_dir):
+    """BASELINE configs[2] as written, one GPU's share (2 of the 16 members), the first 3 of its 10 chunks at the literal 20 solver steps: 2 members x 3
+    chunks x 39 forwards, every chunk conditioned on its member's previous last frame"""
+    _literal_chain_vs_golden(golden_dir, "fullsize_375m_2members_literal_chain.npz", CONFIG_375M, 2, 72, "cfg 3 literal (375M)", [4, 4, 4])

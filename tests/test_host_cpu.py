@@ -20,14 +20,12 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(hip.lib, name), f"{name} declared in the header but not exported"
     assert declared == set(hip.SIGNATURES), "binding and header disagree"
-    # the shipped library carries no A/B arm: round 1's fp32-activation kernel and its conv entry point live in the `make ab` build only,
+    # the shipped library carries no A/B arm (round 1's fp32-activation kernel and its conv entry point left the tree in round 6),
     # and no kernel source of the shipped build reads the environment
     assert not hasattr(hip.lib, "ldc_sphere_conv_nhwc_bf16x3")
     import glob
 
     for f in glob.glob(os.path.join(ROOT, "ladcast_amd", "csrc", "*.hip")):
-        if os.path.basename(f) == "gemm_bf16x3_dma.hip":  # A/B build only (csrc/Makefile: AB_SRCS)
-            continue
         src = open(f).read()
         src = re.sub(r"#ifdef LDC_AB_BUILD.*?#endif", "", src, flags=re.S)
         assert "getenv(" not in src.replace("LDC_AB_GETENV(", ""), f

@@ -1,5 +1,5 @@
-"""SphereConv2d 3x3 implicit GEMM: exact-fp32 MFMA kernel vs split-bf16 kernel (fp32 rows in, in-loop split) vs the pre-split kernel
-(split rows in) at the DCAE's layer shapes (sustained).  LDC_CONV_SMALL_TILES=<n>: tile-height cross-over of the pre-split kernel."""
+"""SphereConv2d 3x3 implicit GEMM: exact-fp32 MFMA kernel vs the pre-split kernel (split rows in; halo-staged or gathered as ldc_sphere_conv_plan
+decides) at the DCAE's layer shapes (sustained).  LDC_CONV_SMALL_TILES=<n> (A/B build): tile-height cross-over of the gathered kernel."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("LDC_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,12 +12,11 @@ for (ci, co, H, W) in [(252, 252, 120, 240), (504, 504, 60, 120), (504, 504, 30,
     x = torch.randn(B * H * W, ci, device="cuda"); y = torch.empty(B * H * W, co, device="cuda"); bias = torch.randn(co, device="cuda")
     wf, wp = pack_dense_weight(w), pack_dense_weight_bf16x3(w)
     f32 = lambda: hip.sphere_conv_nhwc(x, wf, y, B=B, H=H, W=W, cin=ci, cout=co, bias=bias, ksize=3)
-    b3 = lambda: hip.sphere_conv_nhwc_bf16x3(x, wp, y, B=B, H=H, W=W, cin=ci, cout=co, bias=bias, ksize=3)
     c8 = -(-ci // 8) * 8
     xs = torch.empty(B * H * W, c8, device="cuda"); hip.split_rows(x, xs, rows=B * H * W, C=ci)
     sp = lambda: hip.sphere_conv_nhwc_split(xs, wp, y, B=B, H=H, W=W, cin=ci, ldx=c8, cout=co, bias=bias, ksize=3)
     res = []
-    for fn in (f32, b3, sp):
+    for fn in (f32, sp):
         t_end = time.time() + 0.7
         while time.time() < t_end:
             for _ in range(10): fn()
@@ -28,4 +27,4 @@ for (ci, co, H, W) in [(252, 252, 120, 240), (504, 504, 60, 120), (504, 504, 30,
         e.record(); torch.cuda.synchronize()
         res.append(s.elapsed_time(e) * 1e3 / 50)
     fl = 2.0 * B * H * W * co * 9 * ci
-    print(f"B={B} {ci}->{co} @ {H}x{W}: fp32 {res[0]:8.1f} us {fl / res[0] / 1e6:6.1f} TF/s | bf16x3 {res[1]:8.1f} us {fl / res[1] / 1e6:6.1f} TF/s | pre-split {res[2]:8.1f} us {fl / res[2] / 1e6:6.1f} TF/s")
+    print(f"B={B} {ci}->{co} @ {H}x{W}: fp32 {res[0]:8.1f} us {fl / res[0] / 1e6:6.1f} TF/s | pre-split bf16x3 {res[1]:8.1f} us {fl / res[1] / 1e6:6.1f} TF/s")

@@ -45,6 +45,13 @@ for i, nm in ((0, "entry"), (1, "seg0 first DMA landed"), (2, "seg0 loop done"),
     v = (st[:, i][st[:, i] > 0] - t0) / 100.0
     if len(v):
         print(f"  {nm:34s} min {v.min():7.2f}  median {np.median(v):7.2f}  max {v.max():7.2f} us")
+if os.environ.get("PER_XCD"):  # which workgroups finish early / late: exit time by XCD (blockIdx & 7) and by position inside the XCD's run of unit ranges
+    full = raw[65536:65536 + 256 * 16].cpu().numpy().reshape(256, 16).astype(np.float64)
+    ex = (full[:, 15] - t0) / 100.0
+    for x in range(8):
+        v = ex[x::8][full[x::8, 0] > 0]
+        if len(v):
+            print(f"  XCD {x}: exit min {v.min():7.2f}  median {np.median(v):7.2f}  max {v.max():7.2f} us   first 4 ranges {np.round(v[:4], 1)}  last 4 {np.round(v[-4:], 1)}")
 cyc = st[:, 14] - st[:, 13]
 wall = (st[:, 2] - st[:, 1]) / 100.0
 seg_k = kt if tiles * kt % len(st) == 0 and (tiles * kt // len(st)) % kt == 0 else None

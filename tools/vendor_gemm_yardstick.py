@@ -43,6 +43,15 @@ for name, probs in SHAPES.items():
     row["vendor_bf16_us"], row["vendor_bf16_tflops"] = timed(lambda: [torch.matmul(a, w.t()) for a, w in ops], flops)
     zops = [(torch.zeros_like(a), torch.zeros_like(w)) for a, w in ops]
     row["vendor_bf16_zero_operands_us"], row["vendor_bf16_zero_operands_tflops"] = timed(lambda: [torch.matmul(a, w.t()) for a, w in zops], flops)
+    # exact fp32 (round 6: the arithmetic of the headline): the vendor's fp32 GEMM (torch.matmul on fp32 tensors -> hipBLASLt / rocBLAS) next to this
+    # repo's fp32-input MFMA ring kernel (gemm_bf16x3_v3_kernel<128, 0, false>) on the same shapes
+    if max(M for M, _, _ in probs) <= 4096:
+        fops = [(torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")) for M, N, K in probs]
+        row["vendor_f32_us"], row["vendor_f32_tflops"] = timed(lambda: [torch.matmul(a, w.t()) for a, w in fops], flops)
+        fps = [hip.gemm_problem(a, w, torch.empty(a.shape[0], w.shape[0], device="cuda"), M=a.shape[0], N=w.shape[0], K=a.shape[1]) for a, w in fops]
+        row["ours_f32_us"], row["ours_f32_tflops"] = timed(lambda: hip.gemm_grouped(fps, split_bf16=False), flops)
+        row["ours_f32_over_vendor_f32"] = round(row["ours_f32_tflops"] / row["vendor_f32_tflops"], 3)
+        del fops, fps
     if max(M for M, _, _ in probs) <= 4096:
         for mode, fl in (("split3", hip.GEMM_A_SPLIT), ("single_term", hip.GEMM_A_SPLIT | hip.GEMM_BF16_1TERM)):
             ps = []
