@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 4
+#define LDC_ABI_VERSION 5
 
 #define LDC_OK 0
 #define LDC_ERR_ARG (-1)       /* null pointer / non-positive size */
@@ -465,6 +465,11 @@ int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x, float* y, 
  * (models/DCAE.py:519-522, upsample_block_type = "interpolate"): y[b, 2h+i, 2w+j, :] = x[b, h, w, :], as fp32 rows (y, ldy) and / or operand
  * rows (ys, lds, fmt) for the conv that follows; C % 4 == 0. */
 int ldc_upsample_nearest2x_rows(const float* x, float* y, float* ys, int B, int H, int W, int C, int ldx, int ldy, int lds, int fmt, void* stream);
+/* ABI 5 (round 6): the DC-AE family's `layers_per_block[0] == 0` form (models/DCAE.py:559-579,702-712: no stage at full resolution - the encoder's
+ * conv_in is a DCDownBlock2d and the decoder's conv_out a DCUpBlock2d, both WITHOUT shortcut).  `x` of ldc_pixel_unshuffle_shortcut_split may be
+ * NULL: y = pixel_unshuffle(cv) alone.  ldc_pixel_shuffle_to_chan: pixel_shuffle of the conv's NHWC rows cv [B][H][W][4 cout] written straight as
+ * the NCHW result out [B][keep][2H][2W], the first `keep` <= cout channels (any cout: field counts need not be multiples of 4). */
+int ldc_pixel_shuffle_to_chan(const float* cv, float* out, int B, int H, int W, int cout, int keep, void* stream);
 int ldc_split_rows(const float* x, float* ys, long long rows, int C, int ldx, int lds, int fmt, void* stream);
 /* ldc_sphere_dwconv_nhwc / ldc_relu_linear_attn_nhwc with the output format as an argument (LDC_FMT_F32 | _SPLIT | _BF16). */
 int ldc_sphere_dwconv_nhwc_fmt(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int C, int ldx,

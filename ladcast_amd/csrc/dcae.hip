@@ -531,6 +531,10 @@ __global__ __launch_bounds__(256) void pixel_unshuffle_shortcut_kernel(const flo
   for (int e = 0; e < 4; ++e) {
     const int co = 4 * c + e, i = e >> 1, j = e & 1;
     const float v = cv[(pbase + static_cast<long long>(i) * Wf + j) * cq + c];
+    if (x == nullptr) {  // ABI 5: a block without the shortcut (the encoder's conv_in when layers_per_block[0] == 0, models/DCAE.py:571-579)
+      o[e] = v;
+      continue;
+    }
     float s = 0.f;
     for (int g = 0; g < G; ++g) {
       const int q = co * G + g;
@@ -773,10 +777,9 @@ static int split_out_ok(const float* y, const float* ys, int cout, int lds, int 
 
 extern "C" int ldc_pixel_unshuffle_shortcut_split(const float* cv, const float* x, float* y, float* ys, int B, int H2, int W2,
                                                   int cout, int cin, int lds, int fmt, void* stream) {
-  LDC_CHECK_PTR(cv);
-  LDC_CHECK_PTR(x);
+  LDC_CHECK_PTR(cv);  // x may be NULL (ABI 5): y = pixel_unshuffle(cv) alone, no shortcut term
   if (B <= 0 || H2 <= 0 || W2 <= 0 || cout <= 0 || cin <= 0) return LDC_ERR_ARG;
-  if ((cout & 3) || (4 * cin) % cout) return LDC_ERR_UNSUPPORTED;
+  if ((cout & 3) || (x != nullptr && ((4 * cin) % cout || 4 * cin < cout))) return LDC_ERR_UNSUPPORTED;
   const int ok = split_out_ok(y, ys, cout, lds, fmt);
   if (ok != LDC_OK) return ok;
   const long long total4 = static_cast<long long>(B) * H2 * W2 * (cout >> 2);
@@ -801,6 +804,33 @@ extern "C" int ldc_pixel_shuffle_shortcut_split(const float* cv, const float* x,
   const long long total4 = static_cast<long long>(B) * 4 * H * W * (cout >> 2);
   hipLaunchKernelGGL(pixel_shuffle_shortcut_kernel, dim3(ldc_cdiv(total4, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), cv, x, y, ys, H, W, cout, cin, 4 * cout / cin, lds, fmt, total4);
+  return ldc_launch_status();
+}
+
+// DCUpBlock2d WITHOUT shortcut as the decoder's last layer (conv_out when layers_per_block[0] == 0, models/DCAE.py:706-712,526-536 with shortcut=False):
+// pixel_shuffle of the conv's NHWC rows written straight as the NCHW result, first `keep` of the cout channels (the static channels behind them are
+// dropped there, :1050-1052): out[b][c][2h + i][2w + j] = cv[b][h][w][4 c + 2 i + j].  Any cout (the field count need not be a multiple of 4).
+__global__ __launch_bounds__(256) void pixel_shuffle_to_chan_kernel(const float* __restrict__ cv, float* __restrict__ out, int H, int W, int cout, int keep,
+                                                                     long long total) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int wf = static_cast<int>(idx % (2 * W));
+  const long long r1 = idx / (2 * W);
+  const int hf = static_cast<int>(r1 % (2 * H));
+  const long long r2 = r1 / (2 * H);
+  const int c = static_cast<int>(r2 % keep);
+  const long long b = r2 / keep;
+  const long long src = (b * H + (hf >> 1)) * W + (wf >> 1);
+  out[idx] = cv[src * (4LL * cout) + 4 * c + 2 * (hf & 1) + (wf & 1)];
+}
+
+extern "C" int ldc_pixel_shuffle_to_chan(const float* cv, float* out, int B, int H, int W, int cout, int keep, void* stream) {
+  LDC_CHECK_PTR(cv);
+  LDC_CHECK_PTR(out);
+  if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || keep <= 0 || keep > cout) return LDC_ERR_ARG;
+  const long long total = static_cast<long long>(B) * keep * 4 * H * W;
+  hipLaunchKernelGGL(pixel_shuffle_to_chan_kernel, dim3(ldc_cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), cv, out, H, W, cout, keep,
+                     total);
   return ldc_launch_status();
 }
 

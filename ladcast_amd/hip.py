@@ -23,7 +23,7 @@ ACT_IN_TIMESTEP_SINCOS = 16  # act_in of the small linears: x = one timestep per
 GEMM_A_SPLIT, GEMM_C_SPLIT, GEMM_BF16_1TERM = 1, 2, 4
 GEMM_F32_REGSTAGE = 8  # exact-fp32 problems: stay on the register-staged stream-K kernel (include/ladcast_hip.h)
 ATTN_OUT_SPLIT, ATTN_BF16_1TERM, ATTN_OUT_BF16 = 1, 2, 4
-ABI_VERSION = 4  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
+ABI_VERSION = 5  # LDC_ABI_VERSION of include/ladcast_hip.h this binding was written against
 FMT_F32, FMT_SPLIT, FMT_BF16 = 0, 1, 2  # activation formats of the producers' `out_split` arguments (True == FMT_SPLIT)
 
 
@@ -93,6 +93,7 @@ def _load():
         "ldc_rmsnorm_rows_split": (I, [P, P, P, P, P, P, L, I, I, I, I, I, I, F, I, P]),
         "ldc_pixel_unshuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
         "ldc_pixel_shuffle_shortcut_split": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+        "ldc_pixel_shuffle_to_chan": (I, [P, P, I, I, I, I, I, P]),
         "ldc_split_rows": (I, [P, P, L, I, I, I, I, P]),
         "ldc_upsample_nearest2x_rows": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
         "ldc_sphere_dwconv_nhwc_fmt": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -676,6 +677,12 @@ def pixel_unshuffle_shortcut(cv, x, y, *, B, H2, W2, cout, cin, ys=None, lds=Non
     _check(lib.ldc_pixel_unshuffle_shortcut_split(_p(cv), _p(x), _p(y), _p(ys), B, H2, W2, cout, cin,
                                                   (lds if lds is not None else -(-cout // 8) * 8) if ys is not None else 0, int(fmt), _stream()),
            "ldc_pixel_unshuffle_shortcut_split")
+
+
+def pixel_shuffle_to_chan(cv, out, *, B, H, W, cout, keep):
+    """cv [B*H*W, 4*cout] NHWC conv rows -> out [B, keep, 2H, 2W] NCHW: pixel_shuffle without shortcut, first `keep` channels (ldc_pixel_shuffle_to_chan)"""
+    _dev(cv, out)
+    _check(lib.ldc_pixel_shuffle_to_chan(_p(cv), _p(out), B, H, W, cout, keep, _stream()), "ldc_pixel_shuffle_to_chan")
 
 
 def pixel_shuffle_shortcut(cv, x, y, *, B, H, W, cout, cin, ys=None, lds=None, fmt=FMT_SPLIT):

@@ -173,19 +173,22 @@ class EfficientViTBlock(nn.Module):
 
 
 class DCDownBlock2d(nn.Module):
-    def __init__(self, in_channels, out_channels):
+    """models/DCAE.py:447-490 (pixel_unshuffle form); shortcut=False: the encoder's conv_in when layers_per_block[0] == 0 (:571-579)"""
+
+    def __init__(self, in_channels, out_channels, shortcut=True):
         super().__init__()
         assert out_channels % 4 == 0
-        self.in_channels, self.out_channels = in_channels, out_channels
+        self.in_channels, self.out_channels, self.shortcut = in_channels, out_channels, shortcut
         self.conv = SphereConv2d(in_channels, out_channels // 4, 3, 1, 1)
 
 
 class DCUpBlock2d(nn.Module):
-    """models/DCAE.py:493-536: conv at 4x the width + pixel_shuffle, or (interpolate, `upsample_block_type="interpolate"`) nearest x2 + conv"""
+    """models/DCAE.py:493-536: conv at 4x the width + pixel_shuffle, or (interpolate, `upsample_block_type="interpolate"`) nearest x2 + conv;
+    shortcut=False: the decoder's conv_out when layers_per_block[0] == 0 (:706-712)"""
 
-    def __init__(self, in_channels, out_channels, interpolate=False):
+    def __init__(self, in_channels, out_channels, interpolate=False, shortcut=True):
         super().__init__()
-        self.in_channels, self.out_channels, self.interpolate = in_channels, out_channels, interpolate
+        self.in_channels, self.out_channels, self.interpolate, self.shortcut = in_channels, out_channels, interpolate, shortcut
         self.conv = SphereConv2d(in_channels, out_channels if interpolate else out_channels * 4, 3, 1, 1)
 
 
@@ -201,9 +204,10 @@ class Encoder(nn.Module):
     def __init__(self, in_channels, latent_channels, head_dim, block_type, block_out_channels, layers_per_block, qkv_multiscales, temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
-        if layers_per_block[0] <= 0:
-            raise NotImplementedError("layers_per_block[0] == 0 variant is not used by any shipped config")
-        self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        if layers_per_block[0] > 0:
+            self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        else:  # models/DCAE.py:571-579 (the DC-AE family's f64 / f128 form): no stage at full resolution, conv_in = a down block without shortcut
+            self.conv_in = DCDownBlock2d(in_channels, block_out_channels[1], shortcut=False)
         self.down_blocks = nn.ModuleList()
         for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
             for _ in range(nl):
@@ -218,8 +222,6 @@ class Decoder(nn.Module):
                  upsample_block_type="pixel_shuffle", temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
-        if layers_per_block[0] <= 0:
-            raise NotImplementedError("layers_per_block[0] == 0 variant is not used by any shipped config")
         self.conv_in = SphereConv2d(latent_channels, block_out_channels[-1], 3, 1, 1)
         self.up_blocks = nn.ModuleList()
         for i, (ch, nl) in reversed(list(enumerate(zip(block_out_channels, layers_per_block)))):
@@ -227,8 +229,12 @@ class Decoder(nn.Module):
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, interpolate=upsample_block_type == "interpolate"))
             for _ in range(nl):
                 self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i], temb_channels))
-        self.norm_out = _RMSNormP(block_out_channels[0], 1e-7)
-        self.conv_out = SphereConv2d(block_out_channels[0], out_channels, 3, 1, 1)
+        ch0 = block_out_channels[0] if layers_per_block[0] > 0 else block_out_channels[1]  # models/DCAE.py:696-712
+        self.norm_out = _RMSNormP(ch0, 1e-7)
+        if layers_per_block[0] > 0:
+            self.conv_out = SphereConv2d(ch0, out_channels, 3, 1, 1)
+        else:
+            self.conv_out = DCUpBlock2d(ch0, out_channels, interpolate=upsample_block_type == "interpolate", shortcut=False)
 
 
 # ---------------------------------------------------------------------------
@@ -546,7 +552,8 @@ class AutoencoderDC(ModelMixin):
                 M2 = B * (H // 2) * (W // 2)
                 y = torch.empty(M2, blk.out_channels, device=cv.device, dtype=torch.float32)
                 ys = self._srows(M2, blk.out_channels, cv.device)
-                hip.pixel_unshuffle_shortcut(cv, x[0], y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys, fmt=self._fmt)
+                hip.pixel_unshuffle_shortcut(cv, x[0] if blk.shortcut else None, y, B=B, H2=H // 2, W2=W // 2, cout=blk.out_channels, cin=blk.in_channels, ys=ys,
+                                             fmt=self._fmt)
                 x, H, W = (y, ys), H // 2, W // 2
             elif isinstance(blk, DCUpBlock2d) and blk.interpolate:
                 # nearest x2 (operand rows for the conv) -> conv at the output width with the shortcut as its residual operand (models/DCAE.py:519-532)
@@ -611,8 +618,12 @@ class AutoencoderDC(ModelMixin):
             hip.chan_to_token(st, tok[:, C:], B=B, C=cs, N=H * W, ldo=cp, fill_cols=cp - C)
         if temb is not None and not embedded_t:
             temb = self._embed_t_launch(temb, B)
-        h = self._conv(self._stream(tok, B * H * W, cp), B, H, W, enc.conv_in)
-        h, H, W = self._run_blocks(enc.down_blocks, self._stream(h, B * H * W, enc.conv_in.out_channels), B, H, W, temb)
+        if isinstance(enc.conv_in, DCDownBlock2d):  # layers_per_block[0] == 0: conv + pixel_unshuffle, no shortcut (models/DCAE.py:571-579)
+            h, H, W = self._run_blocks([enc.conv_in], self._stream(tok, B * H * W, cp), B, H, W)
+        else:
+            h = self._conv(self._stream(tok, B * H * W, cp), B, H, W, enc.conv_in)
+            h = self._stream(h, B * H * W, enc.conv_in.out_channels)
+        h, H, W = self._run_blocks(enc.down_blocks, h, B, H, W, temb)
         lc = enc.conv_out.out_channels
         sc = torch.empty(B * H * W, lc, device=dev, dtype=torch.float32)
         hip.chan_regroup(h[0], sc, M=B * H * W, cin=enc.conv_out.in_channels, cout=lc)  # out shortcut, :624-627
@@ -635,12 +646,28 @@ class AutoencoderDC(ModelMixin):
             temb = self._embed_t_launch(temb, B)
         h = self._conv(self._stream(tok, B * H * W, C), B, H, W, dec.conv_in, R=rep)  # in shortcut = repeat_interleave, :720-722
         h, H, W = self._run_blocks(dec.up_blocks, self._stream(h, B * H * W, c0), B, H, W, temb)
-        n = self._norm(h[0], dec.norm_out, None, B * H * W, dec.norm_out.weight.numel(), act=hip.ACT_RELU, want32=False)  # only conv_out reads it
-        y = self._conv(n, B, H, W, dec.conv_out)
+        up_out = isinstance(dec.conv_out, DCUpBlock2d)  # layers_per_block[0] == 0: conv_out = an up block without shortcut (models/DCAE.py:706-712)
+        n = self._norm(h[0], dec.norm_out, None, B * H * W, dec.norm_out.weight.numel(), act=hip.ACT_RELU,
+                       want32=up_out and dec.conv_out.interpolate)  # (only conv_out reads it; the interpolate form up-samples the fp32 rows)
         co = dec.conv_out.out_channels
         keep = co
         if not return_static and self.static_channels is not None:
             keep = co - self.static_channels if self.static_channels else 0  # reference: decoded[:, :-static_channels] (:1050-1052)
+        if up_out and not dec.conv_out.interpolate:
+            cv = self._conv(n, B, H, W, dec.conv_out.conv)  # [B H W][4 co] -> pixel_shuffle straight into the NCHW result
+            out = torch.empty(B, keep, 2 * H, 2 * W, device=dev, dtype=torch.float32)
+            if keep:
+                hip.pixel_shuffle_to_chan(cv, out, B=B, H=H, W=W, cout=co, keep=keep)
+            return out
+        if up_out:  # nearest x2, then the conv at the output width
+            ci = dec.conv_out.in_channels
+            up32 = torch.empty(B * 4 * H * W, ci, device=dev, dtype=torch.float32) if not self._split else None
+            ups = self._srows(B * 4 * H * W, ci, dev)
+            hip.upsample_nearest2x_rows(n[0], up32, B=B, H=H, W=W, C=ci, ldx=n[0].shape[1], ys=ups, fmt=self._fmt)
+            n, H, W = (up32, ups), 2 * H, 2 * W
+            y = self._conv(n, B, H, W, dec.conv_out.conv)
+        else:
+            y = self._conv(n, B, H, W, dec.conv_out)
         out = torch.empty(B, keep, H, W, device=dev, dtype=torch.float32)
         if keep:
             hip.token_to_chan(y, out, B=B, C=keep, N=H * W, ldi=co)
@@ -712,9 +739,15 @@ class AutoencoderDC(ModelMixin):
         return DecoderOutput(sample=out)
 
     def forward(self, sample, return_dict: bool = True, time_elapsed=None, static_conditioning_tensor=None, return_static: bool = False):
-        # models/DCAE.py:1067-1085: `time_elapsed` is embedded once and handed to both halves (embedded_t=True there; the same values here)
-        z = self.encode(sample, return_dict=False, temb=time_elapsed, static_conditioning_tensor=static_conditioning_tensor)[0]
-        y = self.decode(z, return_dict=False, temb=time_elapsed, return_static=return_static)[0]
+        # models/DCAE.py:1067-1085: `time_elapsed` is embedded ONCE (time_proj + timestep_embedder) and handed to both halves with embedded_t=True
+        temb, emb = time_elapsed, False
+        if time_elapsed is not None and self.timestep_embedder is not None:
+            if self._plan is None:
+                self._build_plan()
+            t = torch.as_tensor(time_elapsed).to(device=self.device, dtype=torch.float32).reshape(-1)
+            temb, emb = self._embed_t_launch(t, int(sample.shape[0])), True
+        z = self.encode(sample, return_dict=False, temb=temb, embedded_t=emb, static_conditioning_tensor=static_conditioning_tensor)[0]
+        y = self.decode(z, return_dict=False, temb=temb, embedded_t=emb, return_static=return_static)[0]
         if not return_dict:
             return (y,)
         return DecoderOutput(sample=y)

@@ -236,8 +236,10 @@ class Encoder(nn.Module):
                  temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
-        assert layers_per_block[0] > 0
-        self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        if layers_per_block[0] > 0:
+            self.conv_in = SphereConv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        else:  # models/DCAE.py:571-579: no stage at full resolution - conv_in is a down block WITHOUT shortcut straight to the second width
+            self.conv_in = DCDownBlock2d(in_channels, block_out_channels[1], shortcut=False)
         self.down_blocks = nn.ModuleList()
         for i, (ch, nl) in enumerate(zip(block_out_channels, layers_per_block)):
             for _ in range(nl):
@@ -262,7 +264,6 @@ class Decoder(nn.Module):
                  upsample_block_type="pixel_shuffle", temb_channels=None):
         super().__init__()
         n = len(block_out_channels)
-        assert layers_per_block[0] > 0
         self.conv_in = SphereConv2d(latent_channels, block_out_channels[-1], 3, 1, 1)
         self.in_shortcut_repeats = block_out_channels[-1] // latent_channels
         self.up_blocks = nn.ModuleList()
@@ -271,9 +272,12 @@ class Decoder(nn.Module):
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True, interpolate=upsample_block_type == "interpolate"))  # models/DCAE.py:677-682
             for _ in range(nl):
                 self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i], temb_channels))
-        ch0 = block_out_channels[0]
+        ch0 = block_out_channels[0] if layers_per_block[0] > 0 else block_out_channels[1]  # models/DCAE.py:696-712
         self.norm_out = RMSNorm(ch0, 1e-7, elementwise_affine=True, bias=True)
-        self.conv_out = SphereConv2d(ch0, out_channels, 3, 1, 1)
+        if layers_per_block[0] > 0:
+            self.conv_out = SphereConv2d(ch0, out_channels, 3, 1, 1)
+        else:  # the mirror of the encoder's conv_in: an up block WITHOUT shortcut from the second width to the fields
+            self.conv_out = DCUpBlock2d(ch0, out_channels, shortcut=False, interpolate=upsample_block_type == "interpolate")
 
     def forward(self, z, temb=None):
         x = self.conv_in(z) + z.repeat_interleave(self.in_shortcut_repeats, dim=1)

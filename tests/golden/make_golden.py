@@ -362,7 +362,16 @@ def dcae_forward_fixtures():
         yt = aet.decode(zt, temb=tt, return_static=True).sample
         fullt = aet.forward(f, time_elapsed=tt, static_conditioning_tensor=st.expand(2, -1, -1, -1), return_static=True).sample
     assert torch.equal(fullt, yt) and (zt - z).abs().max() > 0.1
-    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy(), y_nostatic=y_nostatic.numpy(), z_temb=zt.numpy(), y_temb=yt.numpy())
+    # round 6: the `layers_per_block[0] == 0` form of the DC-AE family (models/DCAE.py:559-579,696-712: no stage at full resolution - the encoder's
+    # conv_in is a DCDownBlock2d, the decoder's conv_out a DCUpBlock2d, both WITHOUT shortcut; their forwards are the reference's own code here)
+    ae0 = make_dcae(dict(tiny_dcae_config(), encoder_layers_per_block=(0, 1, 1, 1), decoder_layers_per_block=(0, 1, 1, 1)))
+    assert bind(ae0, False) >= 10 and type(ae0.encoder.conv_in) is OD.DCDownBlock2d and type(ae0.decoder.conv_out) is OD.DCUpBlock2d
+    with torch.no_grad():
+        z0 = ae0.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        y0 = ae0.decode(z0, return_static=True).sample
+    assert z0.shape == z.shape and y0.shape == y.shape
+    np.savez_compressed(os.path.join(HERE, "dcae_forward_ref.npz"), z=z.numpy(), y=y.numpy(), y_nostatic=y_nostatic.numpy(), z_temb=zt.numpy(), y_temb=yt.numpy(),
+                        z_layers0=z0.numpy(), y_layers0=y0.numpy())
 
 
 def _strip_inner_imports(fn_node):

@@ -146,6 +146,47 @@ def test_product_dcae_reproduces_the_reference_forward_code(golden_dir):
         assert _rel(lat, torch.from_numpy(z["z"])) < tol and _rel(rec, torch.from_numpy(z["y"])) < tol and _rel(plain, torch.from_numpy(z["y_nostatic"])) < tol
 
 
+def test_product_dcae_without_a_full_resolution_stage_reproduces_the_reference_forward_code(golden_dir):
+    """`layers_per_block[0] == 0` (round 6; models/DCAE.py:559-579,696-712 - the DC-AE family's f64 / f128 form): no stage at full resolution, the
+    encoder's conv_in is a DCDownBlock2d and the decoder's conv_out a DCUpBlock2d, both WITHOUT shortcut (ABI 5: ldc_pixel_unshuffle_shortcut_split
+    with x = NULL, ldc_pixel_shuffle_to_chan).  Round 5 raised NotImplementedError.  The HIP autoencoder with the oracle's seeded weights (strict
+    load) against the fixture made by the REFERENCE's forward code (`z_layers0`, `y_layers0`), three arithmetic modes, eager and graph; also the
+    interpolate up-sampling form of that conv_out against the oracle."""
+    from ladcast_amd.models import AutoencoderDC
+    from tests.synth import make_dcae, synth_field, tiny_dcae_config
+
+    z = np.load(f"{golden_dir}/dcae_forward_ref.npz")
+    cfg = dict(tiny_dcae_config(), encoder_layers_per_block=(0, 1, 1, 1), decoder_layers_per_block=(0, 1, 1, 1))
+    g = AutoencoderDC.from_config(cfg)
+    g.load_state_dict(make_dcae(cfg).state_dict(), strict=True)
+    g = g.cuda().eval()
+    f, st = synth_field(2, 8, 48, 64).cuda(), synth_field(1, 5, 48, 64, seed=1).cuda()
+    z0, y0 = torch.from_numpy(z["z_layers0"]), torch.from_numpy(z["y_layers0"])
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 2e-2)):
+        g.set_gemm_precision(prec)
+        lat = g.encode(f, static_conditioning_tensor=st).latent
+        rec = g.decode(z0.cuda(), return_static=True).sample
+        plain = g.decode(z0.cuda()).sample
+        e1, e2 = _rel(lat, z0), _rel(rec, y0)
+        print(f"\nDC-AE without a full-resolution stage [{prec}]: encode {e1:.2e}, decode {e2:.2e}")
+        assert lat.shape == z0.shape and rec.shape == y0.shape and e1 < tol and e2 < tol, (prec, e1, e2)
+        assert plain.shape == (2, 8, 48, 64) and torch.equal(plain, rec[:, :8])  # the static channels are dropped by the same kernel
+        g.enable_hip_graph(True)
+        assert torch.equal(g.encode(f, static_conditioning_tensor=st).latent, lat) and torch.equal(g.decode(z0.cuda(), return_static=True).sample, rec)
+        g.enable_hip_graph(False)
+    # the interpolate form of the same conv_out (nearest x2, conv at the output width, no shortcut) against the oracle
+    cfg_i = dict(cfg, upsample_block_type="interpolate")
+    o = make_dcae(cfg_i)
+    gi = AutoencoderDC.from_config(cfg_i)
+    gi.load_state_dict(o.state_dict(), strict=True)
+    gi = gi.cuda().eval()
+    with torch.no_grad():
+        want = o.decode(z0, return_static=True).sample
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5)):
+        gi.set_gemm_precision(prec)
+        assert _rel(gi.decode(z0.cuda(), return_static=True).sample, want) < tol, prec
+
+
 def test_product_timestep_conditioned_dcae_reproduces_the_reference_forward_code(golden_dir):
     """`temb_channels` (round 5; models/DCAE.py:36-64,147-153,193-198,256-257,351-365,845-850,982-984,1067-1085): the timestep-conditioned ResBlock
     (scale / shift between its convs) and linear-attention block (AdaLayerNormZeroSingle4Sana before, gate after), raw timesteps through

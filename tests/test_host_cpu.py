@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         src = re.sub(r"#ifdef LDC_AB_BUILD.*?#endif", "", src, flags=re.S)
         assert "getenv(" not in src.replace("LDC_AB_GETENV(", ""), f
     abi = int(re.search(r"#define LDC_ABI_VERSION (\d+)", header).group(1))
-    assert hip.lib.ldc_abi_version() == abi == hip.ABI_VERSION == 4 and hip.lib.ldc_build_arch() == b"gfx950"
+    assert hip.lib.ldc_abi_version() == abi == hip.ABI_VERSION == 5 and hip.lib.ldc_build_arch() == b"gfx950"
 
 
 def test_kernels_refuse_host_tensors():

@@ -193,3 +193,11 @@ def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
         want = torch.from_numpy(z[name])
         assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
     assert ((zt - lat).norm() / lat.norm()).item() > 1e-2  # the conditioning really changes the latent
+    # round 6: layers_per_block[0] == 0 (models/DCAE.py:559-579,696-712) - conv_in a down block, conv_out an up block, both without shortcut
+    ae0 = make_dcae(dict(tiny_dcae_config(), encoder_layers_per_block=(0, 1, 1, 1), decoder_layers_per_block=(0, 1, 1, 1)))
+    with torch.no_grad():
+        z0 = ae0.encode(f, static_conditioning_tensor=st.expand(2, -1, -1, -1)).latent
+        y0 = ae0.decode(z0, return_static=True).sample
+    for got, name in ((z0, "z_layers0"), (y0, "y_layers0")):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape and ((got.double() - want.double()).norm() / want.double().norm()).item() < 1e-6
