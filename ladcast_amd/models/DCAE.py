@@ -228,7 +228,7 @@ class Decoder(nn.Module):
             if i < n - 1 and nl > 0:
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, interpolate=upsample_block_type == "interpolate"))
             for _ in range(nl):
-                self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn, qkv_multiscales[i], temb_channels))
+                self.up_blocks.append(_get_block(block_type[i], ch, head_dim, act_fn if isinstance(act_fn, str) else act_fn[i], qkv_multiscales[i], temb_channels))
         ch0 = block_out_channels[0] if layers_per_block[0] > 0 else block_out_channels[1]  # models/DCAE.py:696-712
         self.norm_out = _RMSNormP(ch0, 1e-7)
         if layers_per_block[0] > 0:
@@ -269,8 +269,9 @@ class AutoencoderDC(ModelMixin):
         if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
             # ("conv" down-sampling builds a stride-2 SphereConv2d, which the reference's SphereConv2d itself refuses: it asserts stride 1)
             raise NotImplementedError("sampling: pixel_unshuffle down (configs/DC_AE_84_pretrain.yaml:45-46), pixel_shuffle | interpolate up")
-        if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
-            raise NotImplementedError("only rms_norm / silu decoders")
+        acts = (decoder_act_fns,) * len(decoder_block_out_channels) if isinstance(decoder_act_fns, str) else tuple(decoder_act_fns)  # models/DCAE.py:663-664
+        if decoder_norm_types != "rms_norm" or any(a not in ("silu", "relu") for a in acts):
+            raise NotImplementedError("decoder ResBlocks: rms_norm with silu or relu (per stage); relu6 / gelu / mish and batch_norm are not built")
         n = len(encoder_block_out_channels)
         ebt = (encoder_block_types,) * n if isinstance(encoder_block_types, str) else tuple(encoder_block_types)
         dbt = (decoder_block_types,) * n if isinstance(decoder_block_types, str) else tuple(decoder_block_types)
@@ -279,7 +280,8 @@ class AutoencoderDC(ModelMixin):
         # models/DCAE.py:845-850: Timesteps(256) (a sinusoid, no parameters: ldc_timestep_embedding) + TimestepEmbedding(256, temb_channels)
         self.timestep_embedder = TimestepEmbedding(256, temb_channels) if temb_channels is not None else None
         self.decoder = Decoder(out_channels if out_channels is not None else in_channels, latent_channels, attention_head_dim, dbt,
-                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales, upsample_block_type=upsample_block_type, temb_channels=temb_channels)
+                               decoder_block_out_channels, decoder_layers_per_block, decoder_qkv_multiscales, act_fn=acts, upsample_block_type=upsample_block_type,
+                               temb_channels=temb_channels)
         self.spatial_compression_ratio = 2 ** (n - 1)
         self.temporal_compression_ratio = 1
         self.use_slicing = False

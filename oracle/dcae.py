@@ -271,7 +271,7 @@ class Decoder(nn.Module):
             if i < n - 1 and nl > 0:
                 self.up_blocks.append(DCUpBlock2d(block_out_channels[i + 1], ch, shortcut=True, interpolate=upsample_block_type == "interpolate"))  # models/DCAE.py:677-682
             for _ in range(nl):
-                self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn, qkv_multiscales[i], temb_channels))
+                self.up_blocks.append(get_block(block_type[i], ch, attention_head_dim, act_fn if isinstance(act_fn, str) else act_fn[i], qkv_multiscales[i], temb_channels))
         ch0 = block_out_channels[0] if layers_per_block[0] > 0 else block_out_channels[1]  # models/DCAE.py:696-712
         self.norm_out = RMSNorm(ch0, 1e-7, elementwise_affine=True, bias=True)
         if layers_per_block[0] > 0:
@@ -335,7 +335,8 @@ class AutoencoderDC(nn.Module):
         if upsample_block_type not in ("pixel_shuffle", "interpolate") or downsample_block_type != "pixel_unshuffle":
             # (downsample_block_type "conv" builds a stride-2 SphereConv2d, which the reference's SphereConv2d refuses: sphere_conv.py asserts stride 1)
             raise NotImplementedError("sampling: pixel_unshuffle down, pixel_shuffle | interpolate up")
-        if decoder_norm_types != "rms_norm" or decoder_act_fns != "silu":
+        acts = (decoder_act_fns,) * len(decoder_block_out_channels) if isinstance(decoder_act_fns, str) else tuple(decoder_act_fns)  # models/DCAE.py:663-664
+        if decoder_norm_types != "rms_norm" or any(a not in ("silu", "relu") for a in acts):
             raise NotImplementedError
         self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
         n = len(encoder_block_out_channels)
@@ -353,6 +354,7 @@ class AutoencoderDC(nn.Module):
             decoder_block_out_channels,
             decoder_layers_per_block,
             decoder_qkv_multiscales,
+            act_fn=acts,
             upsample_block_type=upsample_block_type,
             temb_channels=temb_channels,
         )

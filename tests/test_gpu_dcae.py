@@ -744,3 +744,19 @@ def test_foreign_dcae_attention_processor_is_called_not_ignored():
     et = rel_l2(got_t.cpu(), zt)
     print(f"timestep-conditioned: foreign processor vs oracle {et:.2e}, vs fused {rel_l2(got_t, fused_t):.2e}")
     assert et < 2e-5 and rel_l2(got_t, fused_t) < 2e-5
+
+
+def test_decoder_relu_stages_match_oracle():
+    """`decoder_act_fns` per stage (models/DCAE.py:647,663-664,688: the activation of the decoder's ResBlocks): "relu" on the ResBlock stages, the
+    rest silu - round 5 refused anything but "silu".  HIP decode against the oracle in the three arithmetic modes."""
+    cfg = dict(tiny_dcae_config(), decoder_act_fns=("relu", "relu", "silu", "silu"))
+    o, g = _pair(cfg)
+    z = synth_field(2, 8, 6, 8, seed=5)
+    with torch.no_grad():
+        want = o.decode(z, return_static=True).sample
+        assert rel_l2(make_dcae(tiny_dcae_config()).decode(z, return_static=True).sample, want) > 1e-2  # the activation really matters
+    for prec, tol in (("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 2e-2)):
+        g.set_gemm_precision(prec)
+        e = rel_l2(g.decode(z.cuda(), return_static=True).sample.cpu(), want)
+        print(f"\ndecoder with relu ResBlock stages [{prec}]: rel-L2 {e:.2e}")
+        assert e < tol, (prec, e)
