@@ -3,8 +3,8 @@
 ``set_gemm_precision(mode)`` of both models, ``bench.py --precision``, ``include/ladcast_hip.h`` and the parity tests all refer to
 this table; the numbers are rel-L2 against the fp32 CPU oracle on identical weights and inputs.
 
-* ``fp32``   - exact-fp32 matrix cores everywhere.
-* ``bf16x3`` - split-bf16 contraction (hi*hi + hi*lo + lo*hi, fp32 accumulation); the bench default.  Both stay inside the north
+* ``fp32``   - exact-fp32 matrix cores everywhere: the reference's own arithmetic and, since round 6, the mode ``bench.py`` reports as ``value``.
+* ``bf16x3`` - split-bf16 contraction (hi*hi + hi*lo + lo*hi, fp32 accumulation); the fast mode (``bench.py``'s ``bf16x3_mode`` block).  Both stay inside the north
   star's 1e-4 budget per sampler chunk / rollout.
 * ``bf16``   - the mixed-precision mode of BASELINE configs[4] ("fp16/bf16 mixed"): ONE bf16 MFMA per product on operands rounded to
   bf16; residual stream, norms, softmax statistics, (B, D)-vector Linears, the DCAE's linear attention and the sampler state stay
