@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
       __syncthreads();
       continue;
     }
+#if !(defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOSTAGE))  // diagnostic builds (make variant_src SRC=attn_f32 ...): results are garbage, timing only
     if (t + 1 < t_end) gload((t + 1) * KT);
+#endif
     const float* Ks = smem + (it & 1) * STAGE;
     const float* Vs = Ks + KT * KP;
 
@@ -200,7 +202,11 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
       typedef float f4v __attribute__((ext_vector_type(4)));
       const unsigned ka = static_cast<unsigned>(reinterpret_cast<unsigned long long>(kb));
       f4v k0, k1, k2, k3;
+#if defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOREADS)
+#define LDC_RDK(dst, off) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(ka) : "memory")
+#else
 #define LDC_RDK(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ka), "n"(off) : "memory")
+#endif
 #define LDC_MM4(kv, c)                                                          \
   s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[0], qf[c][0], s, 0, 0, 0);        \
   s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[1], qf[c][1], s, 0, 0, 0);        \
@@ -238,8 +244,11 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
     }
     // the next tile's K / V go to their LDS stage now (it has been free since the barrier; the loads were issued a whole S phase ago):
     // the 32 staging registers are dead through the softmax and the P.V phase
+#if !(defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOSTAGE))
     if (t + 1 < t_end) sstore((it + 1) & 1);
+#endif
 
+#if !(defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOSOFTMAX))
     // ---- online softmax over the key axis (registers + the other lane half) --
     const int key_base = t * KT + 4 * half;
     if (p.kbias) {  // scale_attn_by_lat (models/LaDCast_3D_model.py:873-882); scores are in log2 units here
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
     }
 
+#endif
     // ---- O^T += V^T . P^T ------------------------------------------------------
     // V fragments (one scalar per (key kappa, d tile): V[4 half + kappa][32 d + l31]) three keys ahead of their MFMAs, hand-placed like
     // the K reads: ds_read2st64_b32 fetches the d / d + 2 pair of a key from one base (offsets in units of 256 B, all immediates)
@@ -287,9 +297,15 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
       const unsigned vb1 = va + 128u;  // d tiles 1 and 3
       f2v a0, a1, a2, a3, b0, b1, b2, b3;
 #define LDC_KAPPA(r) (((r) & 3) + 8 * ((r) >> 2))
+#if defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOREADS)
+#define LDC_RDV(da, db, r)                                               \
+  asm volatile("; no read %0 %1" : "=v"(da) : "v"(va) : "memory");       \
+  asm volatile("; no read %0 %1" : "=v"(db) : "v"(vb1) : "memory");
+#else
 #define LDC_RDV(da, db, r)                                                                                                             \
   asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(da) : "v"(va), "n"(2 * LDC_KAPPA(r)), "n"(2 * LDC_KAPPA(r) + 1) : "memory"); \
   asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(db) : "v"(vb1), "n"(2 * LDC_KAPPA(r)), "n"(2 * LDC_KAPPA(r) + 1) : "memory");
+#endif
 #define LDC_PV(da, db, na, nb, r, WAIT)                                          \
   if ((r) + 3 < 16) { LDC_RDV(na, nb, ((r) + 3 < 16 ? (r) + 3 : 15)) }           \
   asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(da), "+v"(db));             \
@@ -324,7 +340,9 @@ __global__ __launch_bounds__(256 * NGRP, NGRP == 1 ? 2 : 1) void attn_fwd_f32_ke
 #undef LDC_KAPPA
     }
 
+#if !(defined(LDC_AB_BUILD) && defined(LDC_ATTN_DIAG_NOBARRIER))
     __syncthreads();
+#endif
   }
 
   // ---- merge the two key halves: group 1 hands (m, l, O) to group 0 through LDS (the rings are idle: barrier above) ----
