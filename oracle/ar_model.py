@@ -330,8 +330,8 @@ class LaDCastTransformer3DModel(nn.Module):
         super().__init__()
         # nope=True (models/LaDCast_3D_model.py:710-712,897-918): no spatial rotary embedding - the whole head dimension rotates with the
         # temporal coordinate only (see rope_tables)
-        if patch_size != 1 or patch_size_t != 1:
-            raise NotImplementedError("shipped configs use patch size 1")
+        if scale_attn_by_lat and patch_size != 1:
+            raise NotImplementedError("scale_attn_by_lat hard-wires the 15 x 30 token grid (models/LaDCast_3D_model.py:684-693): patch size 1 only")
         self.config = SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
         d = num_attention_heads * attention_head_dim
         out_channels = out_channels or in_channels
@@ -414,6 +414,8 @@ class LaDCastTransformer3DModel(nn.Module):
     ):
         b, _, r, h, w = hidden_states.shape
         t_in = conditioning_tensors.shape[2]
+        p_, pt_ = self.config.patch_size, self.config.patch_size_t  # :866-871: everything below counts PATCHES
+        r, t_in, h, w = r // pt_, t_in // pt_, h // p_, w // p_
         with fp32_island():  # models/embeddings.py:282 (the rotary tables are built inside an fp32 island)
             image_rope, cond_rope = self.rope_tables(r, t_in, h, w, device=hidden_states.device)
 
@@ -440,7 +442,7 @@ class LaDCastTransformer3DModel(nn.Module):
             x, ctx = blk(x, ctx, temb, pred_mask, image_rope, cond_rope)
 
         x = self.proj_out(self.norm_out(x, temb))
-        x = x.reshape(b, r, h, w, -1, 1, 1, 1).permute(0, 4, 1, 5, 2, 6, 3, 7)
+        x = x.reshape(b, r, h, w, -1, pt_, p_, p_).permute(0, 4, 1, 5, 2, 6, 3, 7)  # :1047-1062: (B, C, T', p_t, H', p, W', p)
         x = x.flatten(6, 7).flatten(4, 5).flatten(2, 3)
         if not return_dict:
             return (x,)
