@@ -135,9 +135,12 @@ class _AttentionP(nn.Module):
 
 
 class _PatchEmbedP(nn.Module):
-    def __init__(self, in_chans, dim):
+    """parameter container of HunyuanVideoPatchEmbed (models/embeddings.py:38-59): a Conv3d with kernel = stride = the patch; run as a GEMM over
+    the patch rows the model forms (`_patches`)"""
+
+    def __init__(self, in_chans, dim, patch=(1, 1, 1)):
         super().__init__()
-        self.proj = nn.Conv3d(in_chans, dim, kernel_size=(1, 1, 1), stride=(1, 1, 1))
+        self.proj = nn.Conv3d(in_chans, dim, kernel_size=tuple(patch), stride=tuple(patch))
 
 
 class _RefinerBlockP(nn.Module):
@@ -249,8 +252,10 @@ class LaDCastTransformer3DModel(ModelMixin):
         super().__init__()
         self.register_to_config(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
         # nope=True (models/LaDCast_3D_model.py:710-712,897-918): the rotary tables are temporal-only over the whole head dimension (_rope_tables)
-        if patch_size != 1 or patch_size_t != 1:
-            raise NotImplementedError("shipped configs use patch size 1 (configs/ladcast_375M.yaml:11-12)")
+        # patch sizes != 1 (no shipped YAML; models/LaDCast_3D_model.py:657-663,758,866-871,1044-1062): since round 6 - the model re-orders a patch's
+        # p_t p p values into the channel axis (`_patches`), after which every kernel sees the patch grid as a patch-size-1 problem
+        if scale_attn_by_lat and patch_size != 1:
+            raise NotImplementedError("scale_attn_by_lat hard-wires the 15 x 30 token grid (models/LaDCast_3D_model.py:684-693): patch size 1 only")
         if attention_head_dim != 128 or qk_norm != "rms_norm":
             raise NotImplementedError("the attention kernel is built for head_dim 128 + rms_norm q/k")
         if in_channels % 4 or (conditioning_tensor_in_channels or in_channels) % 4:
@@ -259,10 +264,14 @@ class LaDCastTransformer3DModel(ModelMixin):
         d = heads * hd
         out_channels = out_channels or in_channels
         self.inner_dim = d
-        self.x_embedder = _PatchEmbedP(in_channels, d)
+        ps3 = (patch_size_t, patch_size, patch_size)
+        self._patch_vol = patch_size_t * patch_size * patch_size
+        if (in_channels * self._patch_vol) % 4 or ((conditioning_tensor_in_channels or in_channels) * self._patch_vol) % 4:
+            raise NotImplementedError("channels x patch volume must be a multiple of 4 (16-byte rows)")
+        self.x_embedder = _PatchEmbedP(in_channels, d, ps3)
         if conditioning_tensor_intermediate_proj_dim is None:
             conditioning_tensor_intermediate_proj_dim = d
-        self.context_embedder = _PatchEmbedP(conditioning_tensor_in_channels, d)
+        self.context_embedder = _PatchEmbedP(conditioning_tensor_in_channels, d, ps3)
         self.context_refiner = _TokenRefinerP(conditioning_tensor_intermediate_proj_dim, heads, hd, num_refiner_layers)
         self.time_text_embed = _CombinedTimestepTextProjP(d, d)
         self.time_elapsed_embed = _TimestepEmbeddingP(256, 2 * d) if incl_time_elapsed else None
@@ -276,7 +285,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         self.transformer_blocks = nn.ModuleList([_DualBlockP(heads, hd, mlp_ratio) for _ in range(num_layers)])
         self.single_transformer_blocks = nn.ModuleList([_SingleBlockP(heads, hd, mlp_ratio) for _ in range(num_single_layers)])
         self.norm_out = _AdaLinearP(d, 2 * d)
-        self.proj_out = nn.Linear(d, out_channels)
+        self.proj_out = nn.Linear(d, self._patch_vol * out_channels)  # :758
         self.requires_grad_(False)
         # scale_attn_by_lat (models/LaDCast_3D_model.py:682-693): normalised cos-latitude weights of the (hard-wired) 15 x 30 latent grid,
         # added to the attention scores as a (1, 1, 1, keys) float mask; a plain attribute (not a parameter / buffer) as in the reference
@@ -482,6 +491,26 @@ class LaDCastTransformer3DModel(ModelMixin):
         self._plan_gen += 1
 
     # -- cached tables -----------------------------------------------------------------------
+    def _patches(self, x):
+        """(B, C, T, H, W) -> (B, C p_t p p, T / p_t, H / p, W / p): a patch's values go to the channel axis in the order (c, dt, dh, dw) - the
+        flattening of the Conv3d patch-embed weight [D][C][p_t][p][p] (models/embeddings.py:52-59), so the patch embed is the same per-token GEMM as
+        at patch size 1.  A pure re-ordering (one device copy; launches only, capturable); identity at patch size 1."""
+        p, pt = self.config.patch_size, self.config.patch_size_t
+        if p == 1 and pt == 1:
+            return x
+        B, C, T, H, W = x.shape
+        if T % pt or H % p or W % p:
+            raise ValueError(f"a (T, H, W) = {(T, H, W)} tensor is not a whole number of ({pt}, {p}, {p}) patches")
+        return x.reshape(B, C, T // pt, pt, H // p, p, W // p, p).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, C * pt * p * p, T // pt, H // p, W // p).contiguous()
+
+    def _unpatch(self, y, C_out):
+        """the inverse on the output head's (B, C_out p_t p p, T', H', W') result: the reference's un-patchify permutation (:1047-1062)"""
+        p, pt = self.config.patch_size, self.config.patch_size_t
+        if p == 1 and pt == 1:
+            return y
+        B, _, T, H, W = y.shape
+        return y.reshape(B, C_out, pt, p, p, T, H, W).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, C_out, T * pt, H * p, W * p).contiguous()
+
     def _rope_tables(self, r, t_in, h, w, dev):
         key = (r, t_in, h, w, str(dev))
         if key not in self._rope:
@@ -739,7 +768,7 @@ class LaDCastTransformer3DModel(ModelMixin):
             pk = self._conditioning_device(timesteps.repeat_interleave(B).contiguous(),
                                            conditioning_tensors.unsqueeze(0).expand(N, *shape).reshape(N * B, *shape[1:]).contiguous(), te)
             return SimpleNamespace(ctx=pk.ctx, mods=pk.mods, shape=shape, levels=N)
-        Nc, D, NM = shape[2] * shape[3] * shape[4], self.inner_dim, self._plan.mod_w.shape[0]
+        Nc, D, NM = shape[2] * shape[3] * shape[4] // self._patch_vol, self.inner_dim, self._plan.mod_w.shape[0]  # context TOKENS (patches)
         key = ("pack", N, B, Nc)
         if key not in self._ws:
             self._ws[key] = (torch.empty(N * B, Nc, D, device=dev, dtype=torch.float32), torch.empty(N * B, NM, device=dev, dtype=torch.float32))
@@ -804,6 +833,7 @@ class LaDCastTransformer3DModel(ModelMixin):
         dev = self.device
         cfg = self.config
         D, H = self.inner_dim, cfg.num_attention_heads
+        conditioning_tensors = self._patches(conditioning_tensors)
         B, Cc, T_in, Hh, Ww = conditioning_tensors.shape
         Nx, Nc = 0, T_in * Hh * Ww
         S = Nc
@@ -899,11 +929,12 @@ class LaDCastTransformer3DModel(ModelMixin):
         dev = self.device
         cfg = self.config
         D, H = self.inner_dim, cfg.num_attention_heads
+        hidden_states = self._patches(hidden_states)
         B, C_in, R, Hh, Ww = hidden_states.shape
-        _, Cc, T_in, _, _ = pack.shape
+        T_in = pack.shape[2] // cfg.patch_size_t  # (the pack remembers the conditioning tensor's shape as the caller passed it)
         Nx, Nc = R * Hh * Ww, T_in * Hh * Ww
         S = Nx + Nc
-        C_out = cfg.out_channels or cfg.in_channels
+        C_out = (cfg.out_channels or cfg.in_channels) * self._patch_vol  # columns of the output head per token (:758)
         kpad = max(plan.kx_pad, plan.kc_pad)  # differs between precision modes (k-step of the operand format)
         key = (B, Nx, Nc, kpad)
         if key not in self._ws:
@@ -1025,4 +1056,4 @@ class LaDCastTransformer3DModel(ModelMixin):
         run1(nh_x, self.proj_out.weight, ws.otok, M=Nx, N=C_out, K=D, batch=B, a_bs=SD, c_bs=Nx * C_out, bias=self.proj_out.bias, flags=AS)
         out = torch.empty(B, C_out, R, Hh, Ww, device=dev, dtype=torch.float32)
         hip.token_to_chan(ws.otok, out, B=B, C=C_out, N=Nx, ldi=C_out)
-        return out
+        return self._unpatch(out, cfg.out_channels or cfg.in_channels)

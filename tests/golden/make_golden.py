@@ -436,35 +436,37 @@ def ar_forward_fixtures():
     assert len(body) == 8
     exec(compile(ast.Module(body=body, type_ignores=[]), R + "LaDCast_3D_model.py", "exec"), ns)
 
-    cfg = tiny_ar_config()
-    model = make_ar(cfg)
-
     class RefProcessor:
         __call__ = ns["LaDCastAttnProcessor2_0___call__"]
 
-    bind = {OM.HunyuanVideoAdaNorm: ("HunyuanVideoAdaNorm", dict(nonlinearity=nn.SiLU())), OM.RefinerBlock: ("LaDCastIndividualTokenRefinerBlock", {}),
-            OM.IndividualTokenRefiner: ("LaDCastIndividualTokenRefiner", {}), OM.TokenRefiner: ("LaDCastTokenRefiner", {}),
-            OM.SingleBlock: ("LaDCastSingleTransformerBlock", dict(act_mlp=nn.GELU(approximate="tanh"))), OM.DualBlock: ("LaDCastTransformerBlock", {})}
-    n_bound = 0
-    for mod in model.modules():
-        if isinstance(mod, OL.Attention):
-            object.__setattr__(mod, "processor", RefProcessor())
-            n_bound += 1
-        for cls, (ref_name, attrs) in bind.items():
-            if type(mod) is cls:
-                for k, v in attrs.items():
-                    object.__setattr__(mod, k, v)
-                object.__setattr__(mod, "forward", types.MethodType(ns[f"{ref_name}_forward"], mod))
-                n_bound += 1
-    c = model.config
-    Rope = rope_ns["LaDCastRotaryPosEmbed_from_grid"]
-    for k, v in dict(scale_attn_by_lat=False, gradient_checkpointing=False,
-                     rope=Rope(rope_dim_list=c.rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size], theta=c.rope_theta),
-                     cond_rope=Rope(rope_dim_list=c.conditioning_tensor_rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size],
-                                    theta=c.rope_theta)).items():
-        object.__setattr__(model, k, v)
-    object.__setattr__(model, "forward", types.MethodType(ns["LaDCastTransformer3DModel_forward"], model))
-    assert n_bound >= 9, n_bound
+    def bind_reference_forwards(model):
+      """the reference's forward methods onto one oracle model's containers (in place)"""
+      bind = {OM.HunyuanVideoAdaNorm: ("HunyuanVideoAdaNorm", dict(nonlinearity=nn.SiLU())), OM.RefinerBlock: ("LaDCastIndividualTokenRefinerBlock", {}),
+              OM.IndividualTokenRefiner: ("LaDCastIndividualTokenRefiner", {}), OM.TokenRefiner: ("LaDCastTokenRefiner", {}),
+              OM.SingleBlock: ("LaDCastSingleTransformerBlock", dict(act_mlp=nn.GELU(approximate="tanh"))), OM.DualBlock: ("LaDCastTransformerBlock", {})}
+      n_bound = 0
+      for mod in model.modules():
+          if isinstance(mod, OL.Attention):
+              object.__setattr__(mod, "processor", RefProcessor())
+              n_bound += 1
+          for cls, (ref_name, attrs) in bind.items():
+              if type(mod) is cls:
+                  for k, v in attrs.items():
+                      object.__setattr__(mod, k, v)
+                  object.__setattr__(mod, "forward", types.MethodType(ns[f"{ref_name}_forward"], mod))
+                  n_bound += 1
+      c = model.config
+      Rope = rope_ns["LaDCastRotaryPosEmbed_from_grid"]
+      for k, v in dict(scale_attn_by_lat=False, gradient_checkpointing=False,
+                       rope=Rope(rope_dim_list=c.rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size], theta=c.rope_theta),
+                       cond_rope=Rope(rope_dim_list=c.conditioning_tensor_rope_axes_dim, patch_size_list=[c.patch_size_t, c.patch_size, c.patch_size],
+                                      theta=c.rope_theta)).items():
+          object.__setattr__(model, k, v)
+      object.__setattr__(model, "forward", types.MethodType(ns["LaDCastTransformer3DModel_forward"], model))
+      assert n_bound >= 9, n_bound
+      return model
+
+    model = bind_reference_forwards(make_ar(tiny_ar_config()))
 
     out = {}
     with torch.no_grad(), warnings.catch_warnings():
@@ -504,6 +506,18 @@ def ar_forward_fixtures():
         out["nope"] = y[::7].float().numpy()
         out["nope_norm"] = np.array(y.norm().item())
         model.config.nope = False
+        # round 6: patch sizes != 1 (no shipped YAML; models/LaDCast_3D_model.py:657-663,758,866-871,885-896,1044-1062, models/embeddings.py:38-59):
+        # Conv3d patch embeds with kernel = stride = (p_t, p, p), rotary grids over the PATCH grid, an output head of p_t p p C columns per token and
+        # the reference's un-patchify permutation - all reference code here; the oracle's HunyuanVideoPatchEmbed is pinned by pieces_ref.npz
+        for name, (p_, pt_, t_in) in {"patch3": (3, 1, 1), "patch5_t2": (5, 2, 2)}.items():
+            mp = bind_reference_forwards(make_ar(dict(tiny_ar_config(), patch_size=p_, patch_size_t=pt_)))
+            x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+            known = 0.5 * torch.randn(2, 84, t_in, 15, 30, generator=torch.Generator().manual_seed(2))
+            y = mp(x, torch.tensor([0.3]), known, time_elapsed=torch.tensor([2018010100])).sample
+            assert tuple(y.shape) == (2, 84, 4, 15, 30)
+            y = y.double().flatten()
+            out[name] = y[::7].float().numpy()
+            out[name + "_norm"] = np.array(y.norm().item())
     np.savez_compressed(os.path.join(HERE, "ar_forward_ref.npz"), **out)
 
 

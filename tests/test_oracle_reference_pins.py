@@ -166,6 +166,27 @@ def test_nope_equals_the_reference_forward_code(golden_dir):
     assert ((y_grid[::7] - want).norm() / want.norm()).item() > 1e-3  # the variant really changes the output
 
 
+def test_patch_sizes_equal_the_reference_forward_code(golden_dir):
+    """`patch_size` / `patch_size_t` != 1 (round 6; no shipped YAML; models/LaDCast_3D_model.py:657-663,758,866-871,885-896,1044-1062): Conv3d patch
+    embeds with kernel = stride = the patch, rotary grids over the patch grid, an output head of p_t p p C columns per token and the un-patchify
+    permutation.  Fixtures `patch3` (3 x 3 spatial patches) and `patch5_t2` (5 x 5 x 2, two conditioning frames) were made by the reference's own
+    forward code (make_golden.py::ar_forward_fixtures)."""
+    from tests.synth import make_ar, tiny_ar_config
+
+    z = np.load(f"{golden_dir}/ar_forward_ref.npz")
+    for name, (p_, pt_, t_in) in {"patch3": (3, 1, 1), "patch5_t2": (5, 2, 2)}.items():
+        m = make_ar(dict(tiny_ar_config(), patch_size=p_, patch_size_t=pt_))
+        assert tuple(m.x_embedder.proj.weight.shape[2:]) == (pt_, p_, p_) and m.proj_out.weight.shape[0] == 84 * pt_ * p_ * p_
+        x = torch.randn(2, 84, 4, 15, 30, generator=torch.Generator().manual_seed(3))
+        known = 0.5 * torch.randn(2, 84, t_in, 15, 30, generator=torch.Generator().manual_seed(2))
+        with torch.no_grad():
+            y = m(x, torch.tensor([0.3]), known, time_elapsed=torch.tensor([2018010100])).sample
+        assert tuple(y.shape) == (2, 84, 4, 15, 30)
+        y = y.double().flatten()
+        want = torch.from_numpy(z[name]).double()
+        assert ((y[::7] - want).norm() / want.norm()).item() < 1e-6 and abs(y.norm().item() / float(z[name + "_norm"]) - 1) < 1e-6
+
+
 def test_dcae_forward_equals_the_reference_forward_code(golden_dir):
     """tests/golden/dcae_forward_ref.npz: the tiny autoencoder's latent and reconstruction when the forward of every DCAE class the reference
     defines (ResBlock, GLUMBConv, EfficientViTBlock, the linear-attention container + processor, DCDown/UpBlock2d, Encoder, Decoder) is the
