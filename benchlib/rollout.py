@@ -8,9 +8,9 @@ from datetime import datetime
 
 import torch
 
-from .configs import CONFIG_DCAE_84, CONFIGS, PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS, model_flops_per_forward
+from .configs import CONFIG_DCAE_84, CONFIGS, PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS
 from .host import GpuStateSampler, gpu_state
-from .kernel_timer import KernelTimer, bracket_overhead, rocprof_averages, roofline_rows
+from .kernel_timer import rocprof_averages, roofline_rows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T0 = [datetime(2018, 1, 1, 0)]

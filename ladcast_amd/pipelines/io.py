@@ -11,7 +11,7 @@ Plain host-side numpy: nothing here is a hot path."""
 import glob
 import os
 from datetime import datetime, timedelta
-from typing import Iterable, List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
